@@ -1,0 +1,421 @@
+// gsr_api.hip -- host side of libgsrast: the C ABI declared in include/gsrast.h.
+// Workspace planning, kernel sequencing, error handling, introspection.  No torch types here.
+#include "../../include/gsrast.h"
+#include "gsr_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace gsr;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local bool g_prof = false;
+thread_local float g_fwd_ms[5] = {0, 0, 0, 0, 0};
+thread_local float g_bwd_ms[2] = {0, 0};
+thread_local int g_fwd_valid = 0, g_bwd_valid = 0;
+
+int fail(int code, const char* what, const char* file, int line, hipError_t e = hipSuccess)
+{
+	char buf[512];
+	if (e != hipSuccess)
+		snprintf(buf, sizeof(buf), "[gsrast] %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+	else
+		snprintf(buf, sizeof(buf), "[gsrast] %s (%s:%d)", what, file, line);
+	g_err = buf;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+	do {                                                                               \
+		hipError_t e_ = (expr);                                                        \
+		if (e_ != hipSuccess) return fail(GSR_ERR_HIP, #expr, __FILE__, __LINE__, e_); \
+	} while (0)
+
+// after a kernel launch: catch launch errors; in debug mode also synchronise and surface
+// execution errors per stage (the reference's CHECK_CUDA, auxiliary.h:166-173)
+#define STAGE_CHECK(name, debug, stream)                                                       \
+	do {                                                                                       \
+		hipError_t e_ = hipGetLastError();                                                     \
+		if (e_ != hipSuccess) return fail(GSR_ERR_HIP, name " launch", __FILE__, __LINE__, e_); \
+		if (debug) {                                                                           \
+			e_ = hipStreamSynchronize(stream);                                                 \
+			if (e_ != hipSuccess) return fail(GSR_ERR_HIP, name, __FILE__, __LINE__, e_);      \
+		}                                                                                      \
+	} while (0)
+
+bool is_device_ptr(const void* p)
+{
+	hipPointerAttribute_t attr;
+	hipError_t e = hipPointerGetAttributes(&attr, p);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();   // clear: plain host memory is reported as an error by some runtimes
+		return false;
+	}
+	return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// copies `n` floats that live in host or device memory into device memory at dst
+hipError_t stage_floats(float* dst, const float* src, size_t n, hipStream_t s)
+{
+	if (src == nullptr) return hipMemsetAsync(dst, 0, n * sizeof(float), s);
+	return hipMemcpyAsync(dst, src, n * sizeof(float), is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+}
+
+uint32_t* pinned_words()
+{
+	thread_local uint32_t* p = nullptr;
+	if (!p) {
+		if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+	}
+	return p;
+}
+
+struct Timer {
+	hipEvent_t ev[8];
+	int n = 0;
+	bool on;
+	hipStream_t s;
+	Timer(bool enable, hipStream_t st) : on(enable), s(st)
+	{
+		if (on)
+			for (auto& e : ev) (void)hipEventCreate(&e);
+	}
+	void mark()
+	{
+		if (on && n < 8) (void)hipEventRecord(ev[n++], s);
+	}
+	void collect(float* out, int k)
+	{
+		if (!on) return;
+		(void)hipEventSynchronize(ev[n - 1]);
+		for (int i = 0; i < k && i + 1 < n; i++) (void)hipEventElapsedTime(&out[i], ev[i], ev[i + 1]);
+	}
+	~Timer()
+	{
+		if (on)
+			for (auto& e : ev) (void)hipEventDestroy(e);
+	}
+};
+
+__global__ __launch_bounds__(256) void fill_empty_outputs_kernel(size_t HW, float* out_color, float* out_depth,
+                                                                 float* out_median, float* out_opacity)
+{
+	// image of an empty scene: C = 0, depth = 0, median = (15, 0, 0), opacity = 0 (forward.cu:306-312,385-396)
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= HW) return;
+	out_color[i] = 0.f; out_color[HW + i] = 0.f; out_color[2 * HW + i] = 0.f;
+	out_depth[i] = 0.f;
+	out_median[i] = 15.0f; out_median[HW + i] = 0.f; out_median[2 * HW + i] = 0.f;
+	out_opacity[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void inspect_geometry_kernel(int P, const int* radii, const GsRec* recs,
+                                                               float* means2D, float* depths, float* conic_opacity,
+                                                               float* rgb, unsigned char* clamped,
+                                                               uint32_t* tiles_touched)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	const bool vis = radii[idx] > 0;
+	GsRec r;
+	if (vis) r = recs[idx];
+	if (means2D) { means2D[2 * idx] = vis ? r.q0.x : 0.f; means2D[2 * idx + 1] = vis ? r.q0.y : 0.f; }
+	if (depths) depths[idx] = vis ? r.q1.z : 0.f;
+	if (conic_opacity) {
+		conic_opacity[4 * idx + 0] = vis ? -2.f * r.q0.z : 0.f;
+		conic_opacity[4 * idx + 1] = vis ? -r.q0.w : 0.f;
+		conic_opacity[4 * idx + 2] = vis ? -2.f * r.q1.x : 0.f;
+		conic_opacity[4 * idx + 3] = vis ? r.q1.y : 0.f;
+	}
+	if (rgb) { rgb[3 * idx] = vis ? r.q2.x : 0.f; rgb[3 * idx + 1] = vis ? r.q2.y : 0.f; rgb[3 * idx + 2] = vis ? r.q2.z : 0.f; }
+	if (clamped) {
+		for (int ch = 0; ch < 3; ch++) clamped[3 * idx + ch] = vis ? (unsigned char)((r.q3.z >> ch) & 1u) : 0;
+	}
+	if (tiles_touched) tiles_touched[idx] = vis ? r.q3.w : 0u;
+}
+
+__global__ __launch_bounds__(256) void inspect_image_kernel(int gx, int W, int H, const float* tT, const uint32_t* tN,
+                                                            float* final_T, uint32_t* n_contrib)
+{
+	const int tile = blockIdx.x, tid = threadIdx.x;
+	const int px = (tile % gx) * GSR_BLOCK_X + (tid & 15), py = (tile / gx) * GSR_BLOCK_Y + (tid >> 4);
+	if (px >= W || py >= H) return;
+	const size_t pix = (size_t)W * py + px;
+	if (final_T) final_T[pix] = tT[(size_t)tile * GSR_TILE_PIX + tid];
+	if (n_contrib) n_contrib[pix] = tN[(size_t)tile * GSR_TILE_PIX + tid];
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsr_abi_version(void) { return 1; }
+
+const char* gsr_last_error(void) { return g_err.c_str(); }
+
+void gsr_set_profiling(int enable) { g_prof = enable != 0; }
+
+int gsr_last_forward_ms(float ms[5])
+{
+	for (int i = 0; i < 5; i++) ms[i] = g_fwd_ms[i];
+	return g_fwd_valid;
+}
+int gsr_last_backward_ms(float ms[2])
+{
+	for (int i = 0; i < 2; i++) ms[i] = g_bwd_ms[i];
+	return g_bwd_valid;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     unsigned char* present, void* stream)
+{
+	(void)projmatrix;   // the reference computes p_proj but only tests p_view.z (auxiliary.h:147-154)
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	if (P <= 0) return GSR_OK;
+	if (!means3D || !viewmatrix || !present) return fail(GSR_ERR_ARG, "gsr_mark_visible: NULL argument", __FILE__, __LINE__);
+	const float* view = viewmatrix;
+	float* tmp = nullptr;
+	if (!is_device_ptr(viewmatrix)) {
+		HIP_TRY(hipMallocAsync((void**)&tmp, 16 * sizeof(float), s));
+		HIP_TRY(hipMemcpyAsync(tmp, viewmatrix, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+		view = tmp;
+	}
+	launch_mark_visible(P, means3D, view, present, s);
+	hipError_t e = hipGetLastError();
+	if (tmp) (void)hipFreeAsync(tmp, s);
+	if (e != hipSuccess) return fail(GSR_ERR_HIP, "mark_visible launch", __FILE__, __LINE__, e);
+	return GSR_OK;
+}
+
+int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
+                gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth,
+                float* out_median_depth, float* out_opacity, int* radii, int debug, void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	g_fwd_valid = 0;
+	if (width <= 0 || height <= 0) return fail(GSR_ERR_ARG, "gsr_forward: bad image size", __FILE__, __LINE__);
+	if (!out_color || !out_depth || !out_median_depth || !out_opacity)
+		return fail(GSR_ERR_ARG, "gsr_forward: NULL output", __FILE__, __LINE__);
+	const size_t HW = (size_t)width * height;
+	if (P <= 0) {
+		// rasterize_points.cu:84: nothing is launched, images stay at their fill value
+		hipLaunchKernelGGL(fill_empty_outputs_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, HW,
+		                   out_color, out_depth, out_median_depth, out_opacity);
+		STAGE_CHECK("fill_empty_outputs", debug, s);
+		return 0;
+	}
+	if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !radii)
+		return fail(GSR_ERR_ARG, "gsr_forward: NULL required input", __FILE__, __LINE__);
+	if (!colors_precomp && !shs)
+		return fail(GSR_ERR_ARG, "For non-RGB, provide precomputed Gaussian colors!", __FILE__, __LINE__);
+	if (!cov3D_precomp && (!scales || !rotations))
+		return fail(GSR_ERR_ARG, "gsr_forward: need scales+rotations or cov3D_precomp", __FILE__, __LINE__);
+	if (!colors_precomp && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+		return fail(GSR_ERR_ARG, "gsr_forward: SH degree does not fit the stored coefficients", __FILE__, __LINE__);
+	if (!geometry_alloc || !binning_alloc || !image_alloc)
+		return fail(GSR_ERR_ARG, "gsr_forward: NULL allocator", __FILE__, __LINE__);
+
+	const GeomLayout gl((size_t)P);
+	const ImgLayout il(width, height);
+	if (il.gx > 65535 || il.gy > 65535) return fail(GSR_ERR_ARG, "gsr_forward: image too large", __FILE__, __LINE__);
+	char* geom = geometry_alloc(geometry_ctx, gl.total);
+	char* img = image_alloc(image_ctx, il.total);
+	if (!geom || !img) return fail(GSR_ERR_ALLOC, "gsr_forward: allocator returned NULL", __FILE__, __LINE__);
+
+	GsCam* cam = reinterpret_cast<GsCam*>(geom + gl.cam);
+	GsRec* recs = reinterpret_cast<GsRec*>(geom + gl.recs);
+	GsCtl* ctl = reinterpret_cast<GsCtl*>(img + il.ctl);
+	uint2* ranges = reinterpret_cast<uint2*>(img + il.ranges);
+	uint32_t* tile_count = reinterpret_cast<uint32_t*>(img + il.tile_count);
+	float* final_T = reinterpret_cast<float*>(img + il.final_T);
+	uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + il.n_contrib);
+
+	Timer tm(g_prof, s);
+	// camera block + control words + tile counters
+	HIP_TRY(stage_floats(cam->view, viewmatrix, 16, s));
+	HIP_TRY(stage_floats(cam->proj, projmatrix, 16, s));
+	HIP_TRY(stage_floats(cam->campos, cam_pos, 3, s));
+	HIP_TRY(stage_floats(cam->bg, background, 3, s));
+	HIP_TRY(hipMemsetAsync(img + il.ctl, 0, il.final_T - il.ctl, s));   // ctl + ranges + tile_count
+
+	FwdArgs a;
+	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
+	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
+	a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
+	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.prefiltered = prefiltered;
+
+	tm.mark();
+	launch_preprocess_fwd(a, cam, il, radii, recs, tile_count, ctl, s);
+	STAGE_CHECK("preprocess_fwd", debug, s);
+	tm.mark();
+	launch_tile_scan(il.T, tile_count, ranges, ctl, s);
+	STAGE_CHECK("tile_scan", debug, s);
+
+	// the one host sync of the forward pass: R sizes the binning buffer and is returned to the caller
+	uint32_t* host = pinned_words();
+	if (!host) return fail(GSR_ERR_HIP, "hipHostMalloc", __FILE__, __LINE__);
+	HIP_TRY(hipMemcpyAsync(host, ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	const uint32_t R = host[0], max_tile = host[1], err_pref = host[2];
+	if (err_pref)
+		return fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!",
+		            __FILE__, __LINE__);
+	if (R > 0x7fffffffu) return fail(GSR_ERR_ARG, "gsr_forward: more than 2^31 instances", __FILE__, __LINE__);
+
+	const BinLayout bl((size_t)R);
+	char* bin = binning_alloc(binning_ctx, bl.total);
+	if (!bin) return fail(GSR_ERR_ALLOC, "gsr_forward: binning allocator returned NULL", __FILE__, __LINE__);
+	uint64_t* keys = reinterpret_cast<uint64_t*>(bin + bl.keys);
+	uint32_t* point_list = reinterpret_cast<uint32_t*>(bin + bl.point_list);
+
+	tm.mark();
+	if (R > 0) {
+		launch_bin_scatter(P, il.gx, radii, recs, ranges, tile_count, keys, s);
+		STAGE_CHECK("bin_scatter", debug, s);
+	}
+	tm.mark();
+	if (R > 0) {
+		launch_tile_sort(il.T, max_tile, ranges, keys, point_list, s);
+		STAGE_CHECK("tile_sort", debug, s);
+	}
+	tm.mark();
+	launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
+	                     out_opacity, final_T, n_contrib, s);
+	STAGE_CHECK("composite_fwd", debug, s);
+	tm.mark();
+	if (g_prof) {
+		tm.collect(g_fwd_ms, 5);
+		g_fwd_valid = 1;
+	}
+	return (int)R;
+}
+
+size_t gsr_backward_scratch_bytes(int P)
+{
+	return align_up(sizeof(float) * GSR_ACC_STRIDE * (size_t)(P > 0 ? P : 1)) + 256;
+}
+
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                 const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_median_depth,
+                 const float* dL_dpix_final_opacity, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 char* scratch, int debug, void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	g_bwd_valid = 0;
+	(void)viewmatrix; (void)projmatrix; (void)campos;   // the device copies made by gsr_forward are used
+	if (P <= 0) return GSR_OK;   // rasterize_points.cu:171
+	if (!geom_buffer || !image_buffer || !binning_buffer || !scratch || !radii || !means3D)
+		return fail(GSR_ERR_ARG, "gsr_backward: NULL buffer", __FILE__, __LINE__);
+	if (!dL_dpix || !dL_dpix_depth || !dL_dpix_median_depth || !dL_dpix_final_opacity)
+		return fail(GSR_ERR_ARG, "gsr_backward: NULL upstream gradient", __FILE__, __LINE__);
+	if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
+	    (M > 0 && !dL_dsh))
+		return fail(GSR_ERR_ARG, "gsr_backward: NULL output", __FILE__, __LINE__);
+	if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+		return fail(GSR_ERR_ARG, "gsr_backward: SH degree does not fit the stored coefficients", __FILE__, __LINE__);
+
+	const GeomLayout gl((size_t)P);
+	const ImgLayout il(width, height);
+	const BinLayout bl((size_t)(R > 0 ? R : 0));
+	const GsCam* cam = reinterpret_cast<const GsCam*>(geom_buffer + gl.cam);
+	const GsRec* recs = reinterpret_cast<const GsRec*>(geom_buffer + gl.recs);
+	const uint2* ranges = reinterpret_cast<const uint2*>(image_buffer + il.ranges);
+	const float* final_T = reinterpret_cast<const float*>(image_buffer + il.final_T);
+	const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + il.n_contrib);
+	const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + bl.point_list);
+	float* acc = reinterpret_cast<float*>(scratch);
+
+	// scratch layout = [acc rows P x 12 floats][bg 4 floats].  The background is re-staged here because
+	// the reference reads the backward's own `background` argument (backward.cu:584-587), which the
+	// forward never dereferences.
+	float* bg_dev = reinterpret_cast<float*>(scratch + align_up(sizeof(float) * GSR_ACC_STRIDE * (size_t)P));
+	Timer tm(g_prof, s);
+	HIP_TRY(hipMemsetAsync(acc, 0, sizeof(float) * GSR_ACC_STRIDE * (size_t)P, s));
+	HIP_TRY(stage_floats(bg_dev, background, 3, s));
+
+	BwdArgs a;
+	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
+	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
+	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
+	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.radii = radii;
+
+	tm.mark();
+	if (R > 0) {
+		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, final_T, n_contrib, dL_dpix,
+		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, acc, s);
+		STAGE_CHECK("composite_bwd", debug, s);
+	}
+	tm.mark();
+	launch_preprocess_bwd(a, cam, recs, acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+	                      dL_dscale, dL_drot, s);
+	STAGE_CHECK("preprocess_bwd", debug, s);
+	tm.mark();
+	if (g_prof) {
+		tm.collect(g_bwd_ms, 2);
+		g_bwd_valid = 1;
+	}
+	return GSR_OK;
+}
+
+int gsr_inspect_geometry(const char* geom_buffer, int P, const int* radii, float* means2D, float* depths,
+                         float* conic_opacity, float* rgb, unsigned char* clamped, uint32_t* tiles_touched,
+                         void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	if (P <= 0) return GSR_OK;
+	if (!geom_buffer || !radii) return fail(GSR_ERR_ARG, "gsr_inspect_geometry: NULL buffer", __FILE__, __LINE__);
+	const GeomLayout gl((size_t)P);
+	hipLaunchKernelGGL(inspect_geometry_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii,
+	                   reinterpret_cast<const GsRec*>(geom_buffer + gl.recs), means2D, depths, conic_opacity, rgb,
+	                   clamped, tiles_touched);
+	STAGE_CHECK("inspect_geometry", 0, s);
+	return GSR_OK;
+}
+
+int gsr_inspect_binning(const char* binning_buffer, const char* image_buffer, int R, int width, int height,
+                        uint32_t* point_list, uint32_t* ranges, void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	if (!image_buffer) return fail(GSR_ERR_ARG, "gsr_inspect_binning: NULL buffer", __FILE__, __LINE__);
+	const ImgLayout il(width, height);
+	const BinLayout bl((size_t)(R > 0 ? R : 0));
+	if (ranges) HIP_TRY(hipMemcpyAsync(ranges, image_buffer + il.ranges, sizeof(uint2) * (size_t)il.T, hipMemcpyDeviceToDevice, s));
+	if (point_list && R > 0) {
+		if (!binning_buffer) return fail(GSR_ERR_ARG, "gsr_inspect_binning: NULL binning buffer", __FILE__, __LINE__);
+		HIP_TRY(hipMemcpyAsync(point_list, binning_buffer + bl.point_list, sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+	}
+	return GSR_OK;
+}
+
+int gsr_inspect_image(const char* image_buffer, int width, int height, float* final_T, uint32_t* n_contrib,
+                      void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	if (!image_buffer) return fail(GSR_ERR_ARG, "gsr_inspect_image: NULL buffer", __FILE__, __LINE__);
+	const ImgLayout il(width, height);
+	hipLaunchKernelGGL(inspect_image_kernel, dim3(il.T), dim3(256), 0, s, il.gx, width, height,
+	                   reinterpret_cast<const float*>(image_buffer + il.final_T),
+	                   reinterpret_cast<const uint32_t*>(image_buffer + il.n_contrib), final_T, n_contrib);
+	STAGE_CHECK("inspect_image", 0, s);
+	return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// gsr_common.h -- shared device helpers and private buffer layouts of libgsrast (gfx950 only).
+//
+// Floating-point contract: this library is compiled with -ffp-contract=off; every fused
+// multiply-add is written explicitly (FMA()).  The arithmetic below is the "pinned contraction"
+// of the reference kernels documented in DESIGN.md s3; it makes the forward pass reproducible to
+// the bit against the CPU oracle used by tests/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GSR_BLOCK_X 16   // $RAST/cuda_rasterizer/config.h:16-17
+#define GSR_BLOCK_Y 16
+#define GSR_TILE_PIX 256
+
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+// ---------------------------------------------------------------------------------------------
+// Per-Gaussian record written by preprocess_fwd, gathered by the compositing kernels.
+// 64 bytes, 64-byte aligned: one gather touches exactly one 64-B sector.
+//   q0 = { px, py, -0.5*conic_a, -conic_b }          (pre-scaled: exact power-of-two / sign changes)
+//   q1 = { -0.5*conic_c, opacity, depth, pcut }
+//   q2 = { r, g, b, radius(int bits) }
+//   q3 = { rect_min (x | y<<16), rect_max (x | y<<16), clamped bits, tiles_touched }   (uint bits)
+// pcut: conservative lower bound on `power` below which alpha < 1/255 is certain, see preprocess.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(64))) GsRec {
+	float4 q0, q1, q2;
+	uint4 q3;
+};
+static_assert(sizeof(GsRec) == 64, "GsRec must be 64 bytes");
+
+// Camera block at the head of the geometry buffer (device copy of the host/device inputs).
+struct GsCam {
+	float view[16];
+	float proj[16];
+	float campos[4];
+	float bg[4];
+};
+
+// Control words living in the image buffer.
+struct GsCtl {
+	uint32_t num_rendered;   // R
+	uint32_t max_tile_count; // longest per-tile list
+	uint32_t err_prefiltered;
+	uint32_t pad;
+};
+
+__device__ __forceinline__ float gs_exp(float p)
+{
+	// exp(p), p in [-80, 0]: 2^(p*log2e) with round-to-nearest-even split through the 1.5*2^23
+	// constant, degree-5 minimax polynomial for 2^f on [-0.5, 0.5], exponent added as integer bits.
+	const float LOG2E = 0x1.715476p+0f;
+	const float MAGIC = 12582912.0f;
+	float tm = FMA(p, LOG2E, MAGIC);
+	float nf = tm - MAGIC;
+	float f = FMA(p, LOG2E, -nf);
+	float y = 0x1.5c08e6p-10f;
+	y = FMA(y, f, 0x1.3d0c52p-7f);
+	y = FMA(y, f, 0x1.c6b6e4p-5f);
+	y = FMA(y, f, 0x1.ebf918p-3f);
+	y = FMA(y, f, 0x1.62e428p-1f);
+	y = FMA(y, f, 0x1.000002p+0f);
+	return __int_as_float(__float_as_int(y) + (__float_as_int(tm) << 23));
+}
+
+struct M3 { float m[3][3]; };   // m[col][row]
+
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B)
+{
+	M3 R;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int r = 0; r < 3; r++)
+			R.m[c][r] = FMA(A.m[2][r], B.m[c][2], FMA(A.m[1][r], B.m[c][1], A.m[0][r] * B.m[c][0]));
+	return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3& A)
+{
+	M3 R;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+	return R;
+}
+
+__device__ __forceinline__ float3 xform4x3(const float3 p, const float* m)
+{
+	float3 r;
+	r.x = FMA(m[8], p.z, FMA(m[4], p.y, m[0] * p.x)) + m[12];
+	r.y = FMA(m[9], p.z, FMA(m[5], p.y, m[1] * p.x)) + m[13];
+	r.z = FMA(m[10], p.z, FMA(m[6], p.y, m[2] * p.x)) + m[14];
+	return r;
+}
+__device__ __forceinline__ float4 xform4x4(const float3 p, const float* m)
+{
+	float4 r;
+	r.x = FMA(m[8], p.z, FMA(m[4], p.y, m[0] * p.x)) + m[12];
+	r.y = FMA(m[9], p.z, FMA(m[5], p.y, m[1] * p.x)) + m[13];
+	r.z = FMA(m[10], p.z, FMA(m[6], p.y, m[2] * p.x)) + m[14];
+	r.w = FMA(m[11], p.z, FMA(m[7], p.y, m[3] * p.x)) + m[15];
+	return r;
+}
+
+__device__ __forceinline__ M3 quat_to_R(const float4 q)   // (r,x,y,z), not normalised
+{
+	const float r = q.x, x = q.y, y = q.z, z = q.w;
+	M3 R;
+	R.m[0][0] = FMA(-2.f, FMA(z, z, y * y), 1.f);
+	R.m[0][1] = 2.f * FMA(-r, z, x * y);
+	R.m[0][2] = 2.f * FMA(r, y, x * z);
+	R.m[1][0] = 2.f * FMA(r, z, x * y);
+	R.m[1][1] = FMA(-2.f, FMA(z, z, x * x), 1.f);
+	R.m[1][2] = 2.f * FMA(-r, x, y * z);
+	R.m[2][0] = 2.f * FMA(-r, y, x * z);
+	R.m[2][1] = 2.f * FMA(r, x, y * z);
+	R.m[2][2] = FMA(-2.f, FMA(y, y, x * x), 1.f);
+	return R;
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float3 scale, float mod, const float4 rot, float* cov3D)
+{
+	M3 S;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int r = 0; r < 3; r++) S.m[c][r] = 0.f;
+	S.m[0][0] = mod * scale.x;
+	S.m[1][1] = mod * scale.y;
+	S.m[2][2] = mod * scale.z;
+	M3 R = quat_to_R(rot);
+	M3 M = m3_mul(S, R);
+	M3 Mt = m3_t(M);
+	M3 Sg = m3_mul(Mt, M);
+	cov3D[0] = Sg.m[0][0];
+	cov3D[1] = Sg.m[0][1];
+	cov3D[2] = Sg.m[0][2];
+	cov3D[3] = Sg.m[1][1];
+	cov3D[4] = Sg.m[1][2];
+	cov3D[5] = Sg.m[2][2];
+}
+
+struct Cov2D {
+	float3 t;
+	float txtz, tytz, limx, limy;
+	M3 W, T, Vrk, cov;
+};
+
+__device__ __forceinline__ void cov2d_common(const float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                                             const float* cov3D, const float* view, Cov2D& c)
+{
+	float3 t = xform4x3(mean, view);
+	c.limx = 1.3f * tan_fovx;
+	c.limy = 1.3f * tan_fovy;
+	c.txtz = t.x / t.z;
+	c.tytz = t.y / t.z;
+	t.x = fminf(c.limx, fmaxf(-c.limx, c.txtz)) * t.z;
+	t.y = fminf(c.limy, fmaxf(-c.limy, c.tytz)) * t.z;
+	c.t = t;
+	M3 J;
+	J.m[0][0] = fx / t.z; J.m[0][1] = 0.0f; J.m[0][2] = -(fx * t.x) / (t.z * t.z);
+	J.m[1][0] = 0.0f; J.m[1][1] = fy / t.z; J.m[1][2] = -(fy * t.y) / (t.z * t.z);
+	J.m[2][0] = 0.f; J.m[2][1] = 0.f; J.m[2][2] = 0.f;
+	c.W.m[0][0] = view[0]; c.W.m[0][1] = view[4]; c.W.m[0][2] = view[8];
+	c.W.m[1][0] = view[1]; c.W.m[1][1] = view[5]; c.W.m[1][2] = view[9];
+	c.W.m[2][0] = view[2]; c.W.m[2][1] = view[6]; c.W.m[2][2] = view[10];
+	c.Vrk.m[0][0] = cov3D[0]; c.Vrk.m[0][1] = cov3D[1]; c.Vrk.m[0][2] = cov3D[2];
+	c.Vrk.m[1][0] = cov3D[1]; c.Vrk.m[1][1] = cov3D[3]; c.Vrk.m[1][2] = cov3D[4];
+	c.Vrk.m[2][0] = cov3D[2]; c.Vrk.m[2][1] = cov3D[4]; c.Vrk.m[2][2] = cov3D[5];
+	c.T = m3_mul(c.W, J);
+	M3 Tt = m3_t(c.T);
+	M3 Vt = m3_t(c.Vrk);
+	M3 A = m3_mul(Tt, Vt);
+	c.cov = m3_mul(A, c.T);
+}
+
+// 64-lane sum, result valid in every lane (butterfly over DPP-free shuffles; gfx950 wave64).
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}

@@ -1,0 +1,107 @@
+// gsr_internal.h -- private buffer layouts and kernel launchers of libgsrast.
+#pragma once
+#include "gsr_common.h"
+#include <stddef.h>
+
+namespace gsr {
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// geometry buffer: [GsCam][GsRec x P]            (replaces GeometryState, rasterizer_impl.h:33-48:
+// depths/clamped/radii/means2D/cov3D/conic_opacity/rgb/point_offsets/tiles_touched/scan space = 79 B/Gaussian
+// in 9 arrays; here one 64-B record, cov3D is recomputed in backward instead of stored)
+struct GeomLayout {
+	size_t cam, recs, total;
+	explicit GeomLayout(size_t P)
+	{
+		cam = 0;
+		recs = align_up(sizeof(GsCam));
+		total = recs + align_up(sizeof(GsRec) * P);
+	}
+};
+
+// image buffer: [GsCtl][ranges uint2 x T][tile_count/cursor u32 x T][final_T f32 x T*256][n_contrib u32 x T*256]
+// (replaces ImageState, rasterizer_impl.h:50-57; per-pixel state is tile-major so that a tile's 256
+// threads read/write 1 KiB contiguous; ranges are sized per tile, not per pixel)
+struct ImgLayout {
+	size_t ctl, ranges, tile_count, final_T, n_contrib, total;
+	int gx, gy, T;
+	ImgLayout(int W, int H)
+	{
+		gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
+		gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+		T = gx * gy;
+		ctl = 0;
+		ranges = align_up(sizeof(GsCtl));
+		tile_count = ranges + align_up(sizeof(uint2) * (size_t)T);
+		final_T = tile_count + align_up(sizeof(uint32_t) * (size_t)T);
+		n_contrib = final_T + align_up(sizeof(float) * (size_t)T * GSR_TILE_PIX);
+		total = n_contrib + align_up(sizeof(uint32_t) * (size_t)T * GSR_TILE_PIX);
+	}
+};
+
+// binning buffer: [keys u64 x R][point_list u32 x R]   (replaces BinningState, rasterizer_impl.h:59-68:
+// 2x u64 keys + 2x u32 values + CUB temp = 24 B/instance + temp; here 12 B/instance)
+struct BinLayout {
+	size_t keys, point_list, total;
+	explicit BinLayout(size_t R)
+	{
+		keys = 0;
+		point_list = align_up(sizeof(uint64_t) * R);
+		total = point_list + align_up(sizeof(uint32_t) * R);
+		if (total == 0) total = 256;
+	}
+};
+
+struct FwdArgs {
+	int P, D, M, W, H;
+	const float* means3D;
+	const float* shs;
+	const float* colors_precomp;
+	const float* opacities;
+	const float* scales;
+	float scale_modifier;
+	const float* rotations;
+	const float* cov3D_precomp;
+	float tan_fovx, tan_fovy;
+	int prefiltered;
+};
+
+// --- launchers (gsr_kernels_fwd.hip) ---
+void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
+void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs,
+                           uint32_t* tile_count, GsCtl* ctl, hipStream_t s);
+void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, GsCtl* ctl, hipStream_t s);
+void launch_bin_scatter(int P, int gx, const int* radii, const GsRec* recs, const uint2* ranges,
+                        uint32_t* cursor, uint64_t* keys, hipStream_t s);
+void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
+                      hipStream_t s);
+void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
+                          const GsRec* recs, float* out_color, float* out_depth, float* out_median,
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, hipStream_t s);
+
+// --- launchers (gsr_kernels_bwd.hip) ---
+struct BwdArgs {
+	int P, D, M, W, H;
+	const float* means3D;
+	const float* shs;
+	const float* colors_precomp;
+	const float* scales;
+	float scale_modifier;
+	const float* rotations;
+	const float* cov3D_precomp;
+	float tan_fovx, tan_fovy;
+	const int* radii;
+};
+// per-Gaussian accumulator row of composite_bwd: 12 floats (48 B)
+//   0,1 dL_dmean2D.xy | 2,3,4 dL_dconic a,b,c | 5 dL_dopacity | 6,7,8 dL_dcolor | 9 dL_ddepth | 10,11 unused
+#define GSR_ACC_STRIDE 12
+void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
+                          const uint32_t* point_list, const GsRec* recs, const float* final_T,
+                          const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* acc, hipStream_t s);
+void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const float* acc,
+                           float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
+
+}  // namespace gsr

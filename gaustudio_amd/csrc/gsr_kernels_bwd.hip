@@ -1,0 +1,466 @@
+// gsr_kernels_bwd.hip -- backward kernels of libgsrast for gfx950 (MI355X, wave64).
+//
+//   composite_bwd    one workgroup per tile, back-to-front; per (wave, instance) the ten gradient
+//                    components are reduced over the 64 lanes with a 6-step DPP network and issued as
+//                    ONE atomic per component from lane 63 into a packed 48-B accumulator row
+//                    (replaces backward.cu:415-610 renderCUDA: 11-12 atomicAdd per (pixel, Gaussian))
+//   preprocess_bwd   one lane per Gaussian: dL/dconic -> dL/dcov3D, dL/dmean (3 paths), SH backward,
+//                    cov3D -> scale / raw-quaternion backward, fused in one pass
+//                    (replaces backward.cu:144-274 computeCov2DCUDA + :346-412 preprocessCUDA)
+#include "gsr_internal.h"
+
+namespace gsr {
+
+__device__ __constant__ float bSH_C0 = 0.28209479177387814f;
+__device__ __constant__ float bSH_C1 = 0.4886025119029199f;
+__device__ __constant__ float bSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                            -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                            -0.5900435899266435f};
+
+// 64-lane sum through DPP; the total is valid in lane 63 only.
+//   quad_perm xor1, xor2 -> row_half_mirror -> row_mirror (row sums in every lane of the row)
+//   -> row_bcast:15 into rows 1,3 -> row_bcast:31 into rows 2,3.
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1,3
+	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2,3
+	return v;
+}
+
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+    const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
+    const float* __restrict__ dL_dpix_opacity, float* __restrict__ acc)
+{
+	__shared__ float4 sA[256];
+	__shared__ float4 sB[256];
+	__shared__ float4 sC[256];
+	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int tx = tile % gx, ty = tile / gx;
+	const int px = tx * GSR_BLOCK_X + (tid & 15), py = ty * GSR_BLOCK_Y + (tid >> 4);
+	const bool inside = px < W && py < H;
+	const float pixfx = (float)px, pixfy = (float)py;
+	const uint2 range = ranges[tile];
+	const int total = (int)(range.y - range.x);
+
+	const float T_final = inside ? final_T[(size_t)tile * GSR_TILE_PIX + tid] : 0.f;
+	float T_ = T_final;
+	const int last_contributor = inside ? (int)n_contrib[(size_t)tile * GSR_TILE_PIX + tid] : 0;
+	float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLm = 0.f, dLo = 0.f;
+	if (inside) {
+		const size_t HW = (size_t)H * W;
+		const size_t pix_id = (size_t)W * py + px;
+		dLp0 = dL_dpix[pix_id];
+		dLp1 = dL_dpix[HW + pix_id];
+		dLp2 = dL_dpix[2 * HW + pix_id];
+		dLd = dL_dpix_depth[pix_id];
+		dLm = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
+		dLo = dL_dpix_opacity[pix_id];
+	}
+	// bg . dL_dpixel (backward.cu:584-586), loop invariant
+	float bg_dot = 0.f;
+	bg_dot = FMA(bg[0], dLp0, bg_dot);
+	bg_dot = FMA(bg[1], dLp1, bg_dot);
+	bg_dot = FMA(bg[2], dLp2, bg_dot);
+	const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
+
+	float acc_r0 = 0.f, acc_r1 = 0.f, acc_r2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+	float accum_depth_rec = 0.f, accum_op_rec = 0.f;
+	float last_alpha = 0.f, last_depth = 0.f, last_op = 0.f;
+
+	// workgroup-wide max of last_contributor: list entries at or beyond it are dead for every pixel
+	int wmax = last_contributor;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+	__shared__ int s_max[4];
+	if (lane == 0) s_max[tid >> 6] = wmax;
+	__syncthreads();
+	const int bmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+	// walk positions pos = bmax-1 ... 0, staged 256 at a time
+	for (int top = bmax; top > 0; top -= 256) {
+		const int cnt = min(256, top);
+		__syncthreads();
+		if (tid < cnt) {
+			const uint32_t id = point_list[range.x + (top - 1 - tid)];
+			const GsRec* r = recs + id;
+			sA[tid] = r->q0;
+			sB[tid] = r->q1;
+			float4 c = r->q2;
+			c.w = __int_as_float((int)id);
+			sC[tid] = c;
+		}
+		__syncthreads();
+		// entries of this batch that are dead for the whole wave
+		const int jstart = max(0, top - wmax);
+		for (int j = jstart; j < cnt; j++) {
+			const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
+			const float4 A = sA[j];
+			const float4 B = sB[j];
+			const float dx = A.x - pixfx, dy = A.y - pixfy;
+			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
+			bool live = pos < last_contributor && !(power > 0.0f || power < B.w);
+			float G = 0.f, alpha = 0.f;
+			if (live) {
+				G = gs_exp(power);
+				alpha = fminf(0.99f, B.y * G);
+				live = !(alpha < 1.0f / 255.0f);
+			}
+			if (__ballot(live) == 0ull) continue;
+			float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f, g9 = 0.f;
+			const float4 Cc = sC[j];
+			if (live) {
+				const float test_T = T_ / (1.f - alpha);
+				const float w = alpha * test_T;
+				const float one_m_la = 1.f - last_alpha;
+				float dL_dalpha = 0.0f;
+				acc_r0 = FMA(last_alpha, lc0, one_m_la * acc_r0); lc0 = Cc.x;
+				dL_dalpha = FMA(Cc.x - acc_r0, dLp0, dL_dalpha);
+				g6 = w * dLp0;
+				acc_r1 = FMA(last_alpha, lc1, one_m_la * acc_r1); lc1 = Cc.y;
+				dL_dalpha = FMA(Cc.y - acc_r1, dLp1, dL_dalpha);
+				g7 = w * dLp1;
+				acc_r2 = FMA(last_alpha, lc2, one_m_la * acc_r2); lc2 = Cc.z;
+				dL_dalpha = FMA(Cc.z - acc_r2, dLp2, dL_dalpha);
+				g8 = w * dLp2;
+				const float c_d = B.z;
+				accum_depth_rec = FMA(last_alpha, last_depth, one_m_la * accum_depth_rec);
+				last_depth = c_d;
+				dL_dalpha = FMA(c_d - accum_depth_rec, dLd, dL_dalpha);
+				g9 = w * dLd;
+				if (test_T > 0.5f && T_ < 0.5f) g9 += dLm;   // median-depth gradient (backward.cu:566-569)
+				accum_op_rec = FMA(last_alpha, last_op, one_m_la * accum_op_rec);
+				last_op = 1.f;
+				dL_dalpha = FMA(1.f - accum_op_rec, dLo, dL_dalpha);
+				g5 = w * dLo;   // extra opacity term (backward.cu:575)
+				dL_dalpha *= test_T;
+				T_ = test_T;
+				last_alpha = alpha;
+				if (bg_dot != 0.f) dL_dalpha = FMA(-T_final / (1.f - alpha), bg_dot, dL_dalpha);   // exact no-op when bg.dL == 0
+				const float con_a = -2.f * A.z, con_b = -A.w, con_c = -2.f * B.x;
+				const float dL_dG = B.y * dL_dalpha;
+				const float gdx = G * dx, gdy = G * dy;
+				const float dG_ddelx = FMA(-gdy, con_b, -gdx * con_a);
+				const float dG_ddely = FMA(-gdx, con_b, -gdy * con_c);
+				g0 = dL_dG * dG_ddelx * ddelx_dx;
+				g1 = dL_dG * dG_ddely * ddely_dy;
+				g2 = -0.5f * gdx * dx * dL_dG;
+				g3 = -0.5f * gdx * dy * dL_dG;
+				g4 = -0.5f * gdy * dy * dL_dG;
+				g5 += G * dL_dalpha;
+			}
+			g0 = wave_sum_to_lane63(g0); g1 = wave_sum_to_lane63(g1); g2 = wave_sum_to_lane63(g2);
+			g3 = wave_sum_to_lane63(g3); g4 = wave_sum_to_lane63(g4); g5 = wave_sum_to_lane63(g5);
+			g6 = wave_sum_to_lane63(g6); g7 = wave_sum_to_lane63(g7); g8 = wave_sum_to_lane63(g8);
+			g9 = wave_sum_to_lane63(g9);
+			if (lane == 63) {
+				float* row = acc + (size_t)__float_as_int(Cc.w) * GSR_ACC_STRIDE;
+				atomicAdd(row + 0, g0); atomicAdd(row + 1, g1); atomicAdd(row + 2, g2); atomicAdd(row + 3, g3);
+				atomicAdd(row + 4, g4); atomicAdd(row + 5, g5); atomicAdd(row + 6, g6); atomicAdd(row + 7, g7);
+				atomicAdd(row + 8, g8); atomicAdd(row + 9, g9);
+			}
+		}
+	}
+}
+
+void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
+                          const uint32_t* point_list, const GsRec* recs, const float* final_T,
+                          const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* acc, hipStream_t s)
+{
+	const int chunk = (il.T + 7) / 8;
+	hipLaunchKernelGGL(composite_bwd_kernel, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, bg, ranges,
+	                   point_list, recs, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
+	                   dL_dpix_opacity, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
+    int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
+    const float* __restrict__ cov3D_precomp, const GsCam* __restrict__ cam, int W, int H, float tan_fovx,
+    float tan_fovy, float h_x, float h_y, const GsRec* __restrict__ recs, const float* __restrict__ acc,
+    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+    float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	constexpr int NC = (D + 1) * (D + 1);
+	const bool vis = radii[idx] > 0;
+	float a_[GSR_ACC_STRIDE];
+	if (vis) {
+		const float4* ar = reinterpret_cast<const float4*>(acc + (size_t)idx * GSR_ACC_STRIDE);
+		const float4 v0 = ar[0], v1 = ar[1], v2 = ar[2];
+		a_[0] = v0.x; a_[1] = v0.y; a_[2] = v0.z; a_[3] = v0.w; a_[4] = v1.x; a_[5] = v1.y; a_[6] = v1.z;
+		a_[7] = v1.w; a_[8] = v2.x; a_[9] = v2.y; a_[10] = 0.f; a_[11] = 0.f;
+	} else {
+#pragma unroll
+		for (int i = 0; i < GSR_ACC_STRIDE; i++) a_[i] = 0.f;
+	}
+	// user-facing copies of the composite-stage gradients (rasterize_points.cu:209 returns them)
+	dL_dmean2D[3 * (size_t)idx] = a_[0];
+	dL_dmean2D[3 * (size_t)idx + 1] = a_[1];
+	dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+	dL_dopacity[idx] = a_[5];
+	dL_dcolor[3 * (size_t)idx] = a_[6];
+	dL_dcolor[3 * (size_t)idx + 1] = a_[7];
+	dL_dcolor[3 * (size_t)idx + 2] = a_[8];
+
+	float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	float dscale[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+	float* dsh = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : nullptr;
+	if (!vis) {
+		if (dsh)
+			for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
+	} else {
+		const float* view = cam->view;
+		const float* proj = cam->proj;
+		const float3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+		float cov3D[6];
+		if (cov3D_precomp != nullptr) {
+#pragma unroll
+			for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
+		} else {
+			const float3 sc = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+			const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+			cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);   // recomputed, bit-identical to forward
+		}
+		// ---- computeCov2DCUDA (backward.cu:144-274) ----
+		const float dLc_x = a_[2], dLc_y = a_[3], dLc_z = a_[4];
+		Cov2D c;
+		cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, c);
+		const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
+		const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0.f : 1.f;
+		const float a = c.cov.m[0][0] + 0.3f, b = c.cov.m[0][1], cc = c.cov.m[1][1] + 0.3f;
+		const float denom = FMA(-b, b, a * cc);
+		float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+		const float denom2inv = 1.0f / FMA(denom, denom, 0.0000001f);
+#define T_(i, j) c.T.m[i][j]
+#define V_(i, j) c.Vrk.m[i][j]
+#define W_(i, j) c.W.m[i][j]
+		if (denom2inv != 0) {
+			const float dmac = FMA(-a, cc, denom);
+			dL_da = denom2inv * FMA(dmac, dLc_z, FMA(2 * b * cc, dLc_y, -cc * cc * dLc_x));
+			dL_dc = denom2inv * FMA(dmac, dLc_x, FMA(2 * a * b, dLc_y, -a * a * dLc_z));
+			dL_db = denom2inv * 2 * FMA(a * b, dLc_z, FMA(-FMA(2 * b, b, denom), dLc_y, b * cc * dLc_x));
+			dcov[0] = FMA(T_(1, 0) * T_(1, 0), dL_dc, FMA(T_(0, 0) * T_(1, 0), dL_db, T_(0, 0) * T_(0, 0) * dL_da));
+			dcov[3] = FMA(T_(1, 1) * T_(1, 1), dL_dc, FMA(T_(0, 1) * T_(1, 1), dL_db, T_(0, 1) * T_(0, 1) * dL_da));
+			dcov[5] = FMA(T_(1, 2) * T_(1, 2), dL_dc, FMA(T_(0, 2) * T_(1, 2), dL_db, T_(0, 2) * T_(0, 2) * dL_da));
+			dcov[1] = FMA(2 * T_(1, 0) * T_(1, 1), dL_dc, FMA(FMA(T_(0, 1), T_(1, 0), T_(0, 0) * T_(1, 1)), dL_db, 2 * T_(0, 0) * T_(0, 1) * dL_da));
+			dcov[2] = FMA(2 * T_(1, 0) * T_(1, 2), dL_dc, FMA(FMA(T_(0, 2), T_(1, 0), T_(0, 0) * T_(1, 2)), dL_db, 2 * T_(0, 0) * T_(0, 2) * dL_da));
+			dcov[4] = FMA(2 * T_(1, 1) * T_(1, 2), dL_dc, FMA(FMA(T_(0, 2), T_(1, 1), T_(0, 1) * T_(1, 2)), dL_db, 2 * T_(0, 2) * T_(0, 1) * dL_da));
+		}
+#define TV(i, k) FMA(T_(i, 2), V_(k, 2), FMA(T_(i, 1), V_(k, 1), T_(i, 0) * V_(k, 0)))
+		const float dL_dT00 = FMA(TV(1, 0), dL_db, 2 * TV(0, 0) * dL_da);
+		const float dL_dT01 = FMA(TV(1, 1), dL_db, 2 * TV(0, 1) * dL_da);
+		const float dL_dT02 = FMA(TV(1, 2), dL_db, 2 * TV(0, 2) * dL_da);
+		const float dL_dT10 = FMA(TV(0, 0), dL_db, 2 * TV(1, 0) * dL_dc);
+		const float dL_dT11 = FMA(TV(0, 1), dL_db, 2 * TV(1, 1) * dL_dc);
+		const float dL_dT12 = FMA(TV(0, 2), dL_db, 2 * TV(1, 2) * dL_dc);
+#undef TV
+		const float dL_dJ00 = FMA(W_(0, 2), dL_dT02, FMA(W_(0, 1), dL_dT01, W_(0, 0) * dL_dT00));
+		const float dL_dJ02 = FMA(W_(2, 2), dL_dT02, FMA(W_(2, 1), dL_dT01, W_(2, 0) * dL_dT00));
+		const float dL_dJ11 = FMA(W_(1, 2), dL_dT12, FMA(W_(1, 1), dL_dT11, W_(1, 0) * dL_dT10));
+		const float dL_dJ12 = FMA(W_(2, 2), dL_dT12, FMA(W_(2, 1), dL_dT11, W_(2, 0) * dL_dT10));
+#undef T_
+#undef V_
+#undef W_
+		const float tz = 1.f / c.t.z;
+		const float tz2 = tz * tz;
+		const float tz3 = tz2 * tz;
+		const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+		const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+		const float dL_dtz = FMA((2 * h_y * c.t.y) * tz3, dL_dJ12,
+		                         FMA((2 * h_x * c.t.x) * tz3, dL_dJ02, FMA(-(h_y * tz2), dL_dJ11, -h_x * tz2 * dL_dJ00)));
+		// transformVec4x3Transpose (auxiliary.h:89-97)
+		dmean[0] = FMA(view[2], dL_dtz, FMA(view[1], dL_dty, view[0] * dL_dtx));
+		dmean[1] = FMA(view[6], dL_dtz, FMA(view[5], dL_dty, view[4] * dL_dtx));
+		dmean[2] = FMA(view[10], dL_dtz, FMA(view[9], dL_dty, view[8] * dL_dtx));
+
+		// ---- preprocessCUDA (backward.cu:346-412) ----
+		const float3 m = mean;
+		const float4 m_hom = xform4x4(m, proj);
+		const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+		const float mul1 = (FMA(proj[8], m.z, FMA(proj[4], m.y, proj[0] * m.x)) + proj[12]) * m_w * m_w;
+		const float mul2 = (FMA(proj[9], m.z, FMA(proj[5], m.y, proj[1] * m.x)) + proj[13]) * m_w * m_w;
+		const float g2x = a_[0], g2y = a_[1];
+		dmean[0] += FMA(FMA(-proj[3], mul2, proj[1] * m_w), g2y, FMA(-proj[3], mul1, proj[0] * m_w) * g2x);
+		dmean[1] += FMA(FMA(-proj[7], mul2, proj[5] * m_w), g2y, FMA(-proj[7], mul1, proj[4] * m_w) * g2x);
+		dmean[2] += FMA(FMA(-proj[11], mul2, proj[9] * m_w), g2y, FMA(-proj[11], mul1, proj[8] * m_w) * g2x);
+		const float mul3 = FMA(view[10], m.z, FMA(view[6], m.y, view[2] * m.x)) + view[14];
+		const float gd = a_[9];
+		dmean[0] += FMA(-view[3], mul3, view[2]) * gd;
+		dmean[1] += FMA(-view[7], mul3, view[6]) * gd;
+		dmean[2] += FMA(-view[11], mul3, view[10]) * gd;
+
+		if (shs != nullptr) {
+			// computeColorFromSH backward (backward.cu:20-139)
+			float sh[NC * 3];
+			const float* shp = shs + (size_t)idx * M * 3;
+#pragma unroll
+			for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+			const float3 dir_orig = {m.x - cam->campos[0], m.y - cam->campos[1], m.z - cam->campos[2]};
+			const float len = sqrtf(FMA(dir_orig.z, dir_orig.z, FMA(dir_orig.y, dir_orig.y, dir_orig.x * dir_orig.x)));
+			const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+			const uint32_t clamped = recs[idx].q3.z;
+			float dRGB[3];
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) dRGB[ch] = a_[6 + ch] * (((clamped >> ch) & 1u) ? 0.f : 1.f);
+			float dRGBdx[3] = {0.f, 0.f, 0.f}, dRGBdy[3] = {0.f, 0.f, 0.f}, dRGBdz[3] = {0.f, 0.f, 0.f};
+#define SH(k) sh[(k) * 3 + ch]
+#define DSH(k, coef) _Pragma("unroll") for (int ch = 0; ch < 3; ch++) dsh[(k) * 3 + ch] = (coef) * dRGB[ch]
+			DSH(0, bSH_C0);
+			if (D > 0) {
+				const float d1_ = -bSH_C1 * y, d2_ = bSH_C1 * z, d3_ = -bSH_C1 * x;
+				DSH(1, d1_); DSH(2, d2_); DSH(3, d3_);
+#pragma unroll
+				for (int ch = 0; ch < 3; ch++) {
+					dRGBdx[ch] = -bSH_C1 * SH(3);
+					dRGBdy[ch] = -bSH_C1 * SH(1);
+					dRGBdz[ch] = bSH_C1 * SH(2);
+				}
+				if (D > 1) {
+					const float xx = x * x, yy = y * y, zz = z * z;
+					const float xy = x * y, yz = y * z, xz = x * z;
+					const float d4_ = bSH_C2[0] * xy, d5_ = bSH_C2[1] * yz;
+					const float d6_ = bSH_C2[2] * (FMA(2.f, zz, -xx) - yy);
+					const float d7_ = bSH_C2[3] * xz, d8_ = bSH_C2[4] * (xx - yy);
+					DSH(4, d4_); DSH(5, d5_); DSH(6, d6_); DSH(7, d7_); DSH(8, d8_);
+#pragma unroll
+					for (int ch = 0; ch < 3; ch++) {
+						dRGBdx[ch] += FMA(bSH_C2[4] * 2.f * x, SH(8), FMA(bSH_C2[3] * z, SH(7), FMA(bSH_C2[2] * 2.f * -x, SH(6), bSH_C2[0] * y * SH(4))));
+						dRGBdy[ch] += FMA(bSH_C2[4] * 2.f * -y, SH(8), FMA(bSH_C2[2] * 2.f * -y, SH(6), FMA(bSH_C2[1] * z, SH(5), bSH_C2[0] * x * SH(4))));
+						dRGBdz[ch] += FMA(bSH_C2[3] * x, SH(7), FMA(bSH_C2[2] * 2.f * 2.f * z, SH(6), bSH_C2[1] * y * SH(5)));
+					}
+					if (D > 2) {
+						const float d9_ = bSH_C3[0] * y * FMA(3.f, xx, -yy);
+						const float d10_ = bSH_C3[1] * xy * z;
+						const float d11_ = bSH_C3[2] * y * (FMA(4.f, zz, -xx) - yy);
+						const float d12_ = bSH_C3[3] * z * FMA(-3.f, yy, FMA(-3.f, xx, 2.f * zz));
+						const float d13_ = bSH_C3[4] * x * (FMA(4.f, zz, -xx) - yy);
+						const float d14_ = bSH_C3[5] * z * (xx - yy);
+						const float d15_ = bSH_C3[6] * x * FMA(-3.f, yy, xx);
+						DSH(9, d9_); DSH(10, d10_); DSH(11, d11_); DSH(12, d12_); DSH(13, d13_); DSH(14, d14_); DSH(15, d15_);
+#pragma unroll
+						for (int ch = 0; ch < 3; ch++) {
+							dRGBdx[ch] += FMA(bSH_C3[6] * SH(15) * 3.f, xx - yy,
+							              FMA(bSH_C3[5] * SH(14) * 2.f, xz,
+							              FMA(bSH_C3[4] * SH(13), FMA(4.f, zz, -3.f * xx) - yy,
+							              FMA(bSH_C3[3] * SH(12) * -3.f * 2.f, xz,
+							              FMA(bSH_C3[2] * SH(11) * -2.f, xy,
+							              FMA(bSH_C3[1] * SH(10), yz, bSH_C3[0] * SH(9) * 3.f * 2.f * xy))))));
+							dRGBdy[ch] += FMA(bSH_C3[6] * SH(15) * -3.f * 2.f, xy,
+							              FMA(bSH_C3[5] * SH(14) * -2.f, yz,
+							              FMA(bSH_C3[4] * SH(13) * -2.f, xy,
+							              FMA(bSH_C3[3] * SH(12) * -3.f * 2.f, yz,
+							              FMA(bSH_C3[2] * SH(11), FMA(4.f, zz, -3.f * yy) - xx,
+							              FMA(bSH_C3[1] * SH(10), xz, bSH_C3[0] * SH(9) * 3.f * (xx - yy)))))));
+							dRGBdz[ch] += FMA(bSH_C3[5] * SH(14), xx - yy,
+							              FMA(bSH_C3[4] * SH(13) * 4.f * 2.f, xz,
+							              FMA(bSH_C3[3] * SH(12) * 3.f, FMA(2.f, zz, -xx) - yy,
+							              FMA(bSH_C3[2] * SH(11) * 4.f * 2.f, yz, bSH_C3[1] * SH(10) * xy))));
+						}
+					}
+				}
+			}
+#undef SH
+#undef DSH
+			for (int i = NC * 3; i < M * 3; i++) dsh[i] = 0.f;   // coefficients above the active degree
+			const float ddx = FMA(dRGBdx[2], dRGB[2], FMA(dRGBdx[1], dRGB[1], dRGBdx[0] * dRGB[0]));
+			const float ddy = FMA(dRGBdy[2], dRGB[2], FMA(dRGBdy[1], dRGB[1], dRGBdy[0] * dRGB[0]));
+			const float ddz = FMA(dRGBdz[2], dRGB[2], FMA(dRGBdz[1], dRGB[1], dRGBdz[0] * dRGB[0]));
+			// dnormvdv (auxiliary.h:107-117)
+			const float3 v = dir_orig;
+			const float sum2 = FMA(v.z, v.z, FMA(v.y, v.y, v.x * v.x));
+			const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+			dmean[0] += (FMA(-(v.z * v.x), ddz, FMA(-(v.y * v.x), ddy, FMA(-v.x, v.x, sum2) * ddx))) * invsum32;
+			dmean[1] += (FMA(-(v.z * v.y), ddz, FMA(FMA(-v.y, v.y, sum2), ddy, (-v.x * v.y) * ddx))) * invsum32;
+			dmean[2] += (FMA(FMA(-v.z, v.z, sum2), ddz, FMA(-(v.y * v.z), ddy, (-v.x * v.z) * ddx))) * invsum32;
+		}
+
+		if (scales != nullptr) {
+			// computeCov3D backward (backward.cu:278-341)
+			const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+			const float r = q.x, x = q.y, y = q.z, z = q.w;
+			const M3 R = quat_to_R(q);
+			const float s[3] = {scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
+			                    scale_modifier * scales[3 * idx + 2]};
+			M3 S;
+#pragma unroll
+			for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+				for (int ri = 0; ri < 3; ri++) S.m[ci][ri] = 0.f;
+			S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+			const M3 Mm = m3_mul(S, R);
+			M3 dSig;
+			dSig.m[0][0] = dcov[0]; dSig.m[0][1] = 0.5f * dcov[1]; dSig.m[0][2] = 0.5f * dcov[2];
+			dSig.m[1][0] = 0.5f * dcov[1]; dSig.m[1][1] = dcov[3]; dSig.m[1][2] = 0.5f * dcov[4];
+			dSig.m[2][0] = 0.5f * dcov[2]; dSig.m[2][1] = 0.5f * dcov[4]; dSig.m[2][2] = dcov[5];
+			M3 M2;
+#pragma unroll
+			for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+				for (int ri = 0; ri < 3; ri++) M2.m[ci][ri] = 2.0f * Mm.m[ci][ri];
+			const M3 dL_dM = m3_mul(M2, dSig);
+			const M3 Rt = m3_t(R);
+			M3 dMt = m3_t(dL_dM);
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+				dscale[i] = FMA(Rt.m[i][2], dMt.m[i][2], FMA(Rt.m[i][1], dMt.m[i][1], Rt.m[i][0] * dMt.m[i][0]));
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+#pragma unroll
+				for (int j = 0; j < 3; j++) dMt.m[i][j] *= s[i];
+#define D_(i, j) dMt.m[i][j]
+			dq[0] = FMA(2 * x, D_(1, 2) - D_(2, 1), FMA(2 * y, D_(2, 0) - D_(0, 2), 2 * z * (D_(0, 1) - D_(1, 0))));
+			dq[1] = FMA(-4 * x, D_(2, 2) + D_(1, 1), FMA(2 * r, D_(1, 2) - D_(2, 1), FMA(2 * z, D_(2, 0) + D_(0, 2), 2 * y * (D_(1, 0) + D_(0, 1)))));
+			dq[2] = FMA(-4 * y, D_(2, 2) + D_(0, 0), FMA(2 * z, D_(1, 2) + D_(2, 1), FMA(2 * r, D_(2, 0) - D_(0, 2), 2 * x * (D_(1, 0) + D_(0, 1)))));
+			dq[3] = FMA(-4 * z, D_(1, 1) + D_(0, 0), FMA(2 * y, D_(1, 2) + D_(2, 1), FMA(2 * x, D_(2, 0) + D_(0, 2), 2 * r * (D_(0, 1) - D_(1, 0)))));
+#undef D_
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] = dmean[i];
+#pragma unroll
+	for (int i = 0; i < 6; i++) dL_dcov[6 * (size_t)idx + i] = dcov[i];
+#pragma unroll
+	for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
+	*reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+}
+
+void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const float* acc,
+                           float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s)
+{
+	const float h_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:391-392
+	const float h_x = a.W / (2.0f * a.tan_fovx);
+	dim3 grid((a.P + 255) / 256), block(256);
+#define GSR_LAUNCH_PB(DEG)                                                                                         \
+	hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, a.scales, \
+	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
+	                   h_y, recs, acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
+	                   dL_drot)
+	const int D = a.shs ? a.D : 0;
+	switch (D) {
+		case 0: GSR_LAUNCH_PB(0); break;
+		case 1: GSR_LAUNCH_PB(1); break;
+		case 2: GSR_LAUNCH_PB(2); break;
+		default: GSR_LAUNCH_PB(3); break;
+	}
+#undef GSR_LAUNCH_PB
+}
+
+}  // namespace gsr

@@ -1,0 +1,499 @@
+// gsr_kernels_fwd.hip -- forward kernels of libgsrast for gfx950 (MI355X, wave64).
+//
+//   preprocess_fwd   one lane per Gaussian: cull, project, cov3D, EWA cov2D, conic, radius, tile rect,
+//                    SH->RGB; writes one 64-B record per visible Gaussian and counts instances per tile
+//                    (replaces forward.cu:155-256 preprocessCUDA + the tiles_touched scan input)
+//   tile_scan        exclusive scan of the per-tile counts -> per-tile [start,end) ranges, R
+//                    (replaces cub InclusiveSum over P + identifyTileRanges, rasterizer_impl.cu:280,116-138)
+//   bin_scatter      emits (depth bits<<32 | id) keys straight into each tile's segment
+//                    (replaces duplicateWithKeys, rasterizer_impl.cu:70-111)
+//   tile_sort        one workgroup per tile sorts its segment in LDS by (depth, id)
+//                    (replaces the global 45..47-bit cub::DeviceRadixSort, rasterizer_impl.cu:306-311)
+//   composite_fwd    one workgroup (4 waves) per 16x16 tile, front-to-back alpha compositing
+//                    (replaces forward.cu:261-397 renderCUDA)
+#include "gsr_internal.h"
+
+namespace gsr {
+
+__device__ __constant__ float kSH_C0 = 0.28209479177387814f;
+__device__ __constant__ float kSH_C1 = 0.4886025119029199f;
+__device__ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                            -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                            -0.5900435899266435f};
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ view,
+                                                           unsigned char* __restrict__ present)
+{
+	int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	float3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+	float3 pv = xform4x3(p, view);
+	present[idx] = !(pv.z <= 0.2f);   // auxiliary.h:154 (lateral test is commented out in the reference)
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s)
+{
+	if (P <= 0) return;
+	hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile-rect walkers.  A lane whose rect is small walks it alone; rects with more than
+// GSR_COOP_TILES tiles are walked by the whole wave (64 tiles per step) so that one screen-filling
+// Gaussian does not serialise 63 idle lanes behind thousands of atomics.
+#define GSR_COOP_TILES 32
+
+template <typename F>
+__device__ __forceinline__ void for_each_tile(bool active, int rminx, int rminy, int rmaxx, int rmaxy,
+                                              uint32_t pay0, uint32_t pay1, F&& f)
+{
+	// f(x, y, p0, p1): p0/p1 are the OWNING lane's payload (shuffled in the cooperative path; the
+	// shuffles sit outside the divergent tile loop so that the source lane is always active).
+	const int w = rmaxx - rminx, h = rmaxy - rminy;
+	const int n = active ? w * h : 0;
+	const bool big = n > GSR_COOP_TILES;
+	if (n > 0 && !big) {
+		for (int y = rminy; y < rmaxy; y++)
+			for (int x = rminx; x < rmaxx; x++) f(x, y, pay0, pay1);
+	}
+	unsigned long long m = __ballot(big);
+	const int lane = threadIdx.x & 63;
+	while (m) {
+		const int src = __ffsll((long long)m) - 1;
+		m &= m - 1;
+		const int sx = __shfl(rminx, src, 64), sy = __shfl(rminy, src, 64);
+		const int sw = __shfl(w, src, 64), sn = __shfl(n, src, 64);
+		const uint32_t p0 = (uint32_t)__shfl((int)pay0, src, 64), p1 = (uint32_t)__shfl((int)pay1, src, 64);
+		for (int t = lane; t < sn; t += 64) f(sx + t % sw, sy + t / sw, p0, p1);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
+    int P, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    const GsCam* __restrict__ cam, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
+    int gx, int gy, int prefiltered, int sh_vec4, int* __restrict__ radii, GsRec* __restrict__ recs,
+    uint32_t* __restrict__ tile_count, GsCtl* __restrict__ ctl)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	bool vis = false;
+	int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+	if (idx < P) {
+		int my_radius_i = 0;
+		do {
+			const float* view = cam->view;
+			const float* proj = cam->proj;
+			const float3 p_orig = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+			// in_frustum (auxiliary.h:139-164)
+			const float4 p_hom = xform4x4(p_orig, proj);
+			const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+			const float p_proj_x = p_hom.x * p_w, p_proj_y = p_hom.y * p_w;
+			const float3 p_view = xform4x3(p_orig, view);
+			if (p_view.z <= 0.2f) {
+				if (prefiltered) ctl->err_prefiltered = 1;
+				break;
+			}
+			float cov3D[6];
+			if (cov3D_precomp != nullptr) {
+#pragma unroll
+				for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
+			} else {
+				const float3 sc = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+				const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+				cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
+			}
+			Cov2D c;
+			cov2d_common(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, c);
+			const float cov_x = c.cov.m[0][0] + 0.3f;
+			const float cov_y = c.cov.m[0][1];
+			const float cov_z = c.cov.m[1][1] + 0.3f;
+			const float det = FMA(-cov_y, cov_y, cov_x * cov_z);
+			if (det == 0.0f) break;
+			const float det_inv = 1.f / det;
+			const float conic_x = cov_z * det_inv, conic_y = -cov_y * det_inv, conic_z = cov_x * det_inv;
+			const float mid = 0.5f * (cov_x + cov_z);
+			const float disc = sqrtf(fmaxf(0.1f, FMA(mid, mid, -det)));
+			const float lambda1 = mid + disc, lambda2 = mid - disc;
+			const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+			// ndc2Pix in double (auxiliary.h:41-44)
+			const float pix_x = (float)((((double)p_proj_x + 1.0) * (double)W - 1.0) * 0.5);
+			const float pix_y = (float)((((double)p_proj_y + 1.0) * (double)H - 1.0) * 0.5);
+			// getRect (auxiliary.h:46-56)
+			const int mr = (int)my_radius;
+			rminx = min(gx, max(0, (int)((pix_x - mr) / GSR_BLOCK_X)));
+			rminy = min(gy, max(0, (int)((pix_y - mr) / GSR_BLOCK_Y)));
+			rmaxx = min(gx, max(0, (int)((pix_x + mr + GSR_BLOCK_X - 1) / GSR_BLOCK_X)));
+			rmaxy = min(gy, max(0, (int)((pix_y + mr + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y)));
+			if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
+
+			float rgb[3];
+			uint32_t clamped = 0;
+			if (colors_precomp == nullptr) {
+				// computeColorFromSH (forward.cu:20-71)
+				constexpr int NC = (D + 1) * (D + 1);
+				float sh[NC * 3];
+				const float* shp = shs + (size_t)idx * M * 3;
+				if (sh_vec4 && (NC * 3) % 4 == 0) {
+#pragma unroll
+					for (int i = 0; i < NC * 3 / 4; i++) {
+						const float4 v = reinterpret_cast<const float4*>(shp)[i];
+						sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+					}
+				} else {
+#pragma unroll
+					for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+				}
+				float3 dir = {p_orig.x - cam->campos[0], p_orig.y - cam->campos[1], p_orig.z - cam->campos[2]};
+				const float len = sqrtf(FMA(dir.z, dir.z, FMA(dir.y, dir.y, dir.x * dir.x)));
+				dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+				const float x = dir.x, y = dir.y, z = dir.z;
+#pragma unroll
+				for (int ch = 0; ch < 3; ch++) {
+#define SH(k) sh[(k) * 3 + ch]
+					float r = kSH_C0 * SH(0);
+					if (D > 0) {
+						r = FMA(-(kSH_C1 * y), SH(1), r);
+						r = FMA(kSH_C1 * z, SH(2), r);
+						r = FMA(-(kSH_C1 * x), SH(3), r);
+						if (D > 1) {
+							const float xx = x * x, yy = y * y, zz = z * z;
+							const float xy = x * y, yz = y * z, xz = x * z;
+							r = FMA(kSH_C2[0] * xy, SH(4), r);
+							r = FMA(kSH_C2[1] * yz, SH(5), r);
+							r = FMA(kSH_C2[2] * (FMA(2.0f, zz, -xx) - yy), SH(6), r);
+							r = FMA(kSH_C2[3] * xz, SH(7), r);
+							r = FMA(kSH_C2[4] * (xx - yy), SH(8), r);
+							if (D > 2) {
+								r = FMA(kSH_C3[0] * y * FMA(3.0f, xx, -yy), SH(9), r);
+								r = FMA(kSH_C3[1] * xy * z, SH(10), r);
+								r = FMA(kSH_C3[2] * y * (FMA(4.0f, zz, -xx) - yy), SH(11), r);
+								r = FMA(kSH_C3[3] * z * FMA(-3.0f, yy, FMA(-3.0f, xx, 2.0f * zz)), SH(12), r);
+								r = FMA(kSH_C3[4] * x * (FMA(4.0f, zz, -xx) - yy), SH(13), r);
+								r = FMA(kSH_C3[5] * z * (xx - yy), SH(14), r);
+								r = FMA(kSH_C3[6] * x * FMA(-3.0f, yy, xx), SH(15), r);
+							}
+						}
+					}
+#undef SH
+					r += 0.5f;
+					if (r < 0) clamped |= 1u << ch;
+					rgb[ch] = fmaxf(r, 0.0f);
+				}
+			} else {
+				rgb[0] = colors_precomp[3 * (size_t)idx];
+				rgb[1] = colors_precomp[3 * (size_t)idx + 1];
+				rgb[2] = colors_precomp[3 * (size_t)idx + 2];
+			}
+			const float op = opacities[idx];
+			// pcut: power < pcut  ==>  op*exp(power) < 1/255 with a 1e-3 margin, so skipping the pair is
+			// bit-identical to evaluating it and failing `alpha < 1/255` (forward.cu:346).  Clamped to the
+			// domain of gs_exp.  op <= 0 -> +inf (always skipped); NaN -> -80 (never skipped by pcut).
+			const float pcut = fmaxf(-__logf(255.0f * op) - 0.001f, -80.0f);
+			my_radius_i = mr;
+			vis = true;
+			GsRec rec;
+			rec.q0 = make_float4(pix_x, pix_y, -0.5f * conic_x, -conic_y);
+			rec.q1 = make_float4(-0.5f * conic_z, op, p_view.z, pcut);
+			rec.q2 = make_float4(rgb[0], rgb[1], rgb[2], __int_as_float(mr));
+			rec.q3 = make_uint4((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16),
+			                    clamped, (uint32_t)((rmaxy - rminy) * (rmaxx - rminx)));
+			recs[idx] = rec;
+		} while (0);
+		radii[idx] = my_radius_i;
+	}
+	for_each_tile(vis, rminx, rminy, rmaxx, rmaxy, 0u, 0u,
+	              [&](int x, int y, uint32_t, uint32_t) { atomicAdd(&tile_count[y * gx + x], 1u); });
+}
+
+void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs,
+                           uint32_t* tile_count, GsCtl* ctl, hipStream_t s)
+{
+	const float focal_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:225-226
+	const float focal_x = a.W / (2.0f * a.tan_fovx);
+	const int sh_vec4 = (a.shs != nullptr && ((uintptr_t)a.shs % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0;
+	dim3 grid((a.P + 255) / 256), block(256);
+#define GSR_LAUNCH_PRE(DEG)                                                                                        \
+	hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.scales,               \
+	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.cov3D_precomp, a.colors_precomp, cam,   \
+	                   a.W, a.H, a.tan_fovx, a.tan_fovy, focal_x, focal_y, il.gx, il.gy, a.prefiltered, sh_vec4,     \
+	                   radii, recs, tile_count, ctl)
+	const int D = a.colors_precomp ? 0 : a.D;
+	switch (D) {
+		case 0: GSR_LAUNCH_PRE(0); break;
+		case 1: GSR_LAUNCH_PRE(1); break;
+		case 2: GSR_LAUNCH_PRE(2); break;
+		default: GSR_LAUNCH_PRE(3); break;
+	}
+#undef GSR_LAUNCH_PRE
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan over T tile counts by one 1024-thread workgroup; also resets the counters so
+// that bin_scatter can reuse them as per-tile cursors.
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __restrict__ tile_count,
+                                                         uint2* __restrict__ ranges, GsCtl* __restrict__ ctl)
+{
+	__shared__ uint32_t s_wave[16];
+	__shared__ uint32_t s_max[16];
+	const int tid = threadIdx.x;
+	const int chunk = (T + 1023) / 1024;
+	const int b = tid * chunk, e = min(T, b + chunk);
+	uint32_t sum = 0, mx = 0;
+	for (int i = b; i < e; i++) {
+		const uint32_t c = tile_count[i];
+		sum += c;
+		mx = max(mx, c);
+	}
+	// inclusive scan across the wave, then across the 16 waves
+	uint32_t incl = sum;
+	const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t v = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += v;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+	if (lane == 63) s_wave[wv] = incl;
+	if (lane == 0) s_max[wv] = mx;
+	__syncthreads();
+	uint32_t base = 0, total = 0, gmax = 0;
+	for (int w = 0; w < 16; w++) {
+		if (w < wv) base += s_wave[w];
+		total += s_wave[w];
+		gmax = max(gmax, s_max[w]);
+	}
+	uint32_t run = base + incl - sum;
+	for (int i = b; i < e; i++) {
+		const uint32_t c = tile_count[i];
+		ranges[i] = make_uint2(run, run + c);
+		run += c;
+		tile_count[i] = 0;
+	}
+	if (tid == 0) {
+		ctl->num_rendered = total;
+		ctl->max_tile_count = gmax;
+	}
+}
+
+void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, GsCtl* ctl, hipStream_t s)
+{
+	hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_count, ranges, ctl);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const int* __restrict__ radii,
+                                                          const GsRec* __restrict__ recs,
+                                                          const uint2* __restrict__ ranges,
+                                                          uint32_t* __restrict__ cursor,
+                                                          uint64_t* __restrict__ keys)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	bool vis = false;
+	int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+	uint32_t dbits = 0;
+	if (idx < P && radii[idx] > 0) {
+		vis = true;
+		const uint4 q3 = recs[idx].q3;
+		rminx = q3.x & 0xffff; rminy = q3.x >> 16;
+		rmaxx = q3.y & 0xffff; rmaxy = q3.y >> 16;
+		dbits = (uint32_t)__float_as_int(recs[idx].q1.z);
+	}
+	for_each_tile(vis, rminx, rminy, rmaxx, rmaxy, dbits, (uint32_t)idx, [&](int x, int y, uint32_t d, uint32_t id) {
+		// key = | depth bits | id |: within a tile the order is (depth, id) exactly as the stable
+		// radix sort of rasterizer_impl.cu:98-109,306-311 produces (depth > 0.2 so bits order as uint)
+		const int tile = y * gx + x;
+		const uint32_t pos = ranges[tile].x + atomicAdd(&cursor[tile], 1u);
+		keys[pos] = ((uint64_t)d << 32) | id;
+	});
+}
+
+void launch_bin_scatter(int P, int gx, const int* radii, const GsRec* recs, const uint2* ranges, uint32_t* cursor,
+                        uint64_t* keys, hipStream_t s)
+{
+	hipLaunchKernelGGL(bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, radii, recs, ranges,
+	                   cursor, keys);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-tile sort.  Normalised bitonic network (every comparator ascending), so that virtual +inf
+// padding beyond n never moves and arbitrary n needs no padding storage.
+//   MODE 0: n <= cap (dynamic LDS of cap keys)      MODE 1: any n, in place in global memory.
+template <int MODE>
+__global__ __launch_bounds__(256) void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ point_list, uint32_t lo, uint32_t hi)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
+	const uint2 range = ranges[blockIdx.x];
+	const uint32_t n = range.y - range.x;
+	if (n <= lo || n > hi) return;   // handled by another launch (or empty)
+	const uint32_t tid = threadIdx.x;
+	uint64_t* g = keys + range.x;
+	uint64_t* a = MODE == 0 ? s : g;
+	if (MODE == 0) {
+		for (uint32_t i = tid; i < n; i += 256) s[i] = g[i];
+	}
+	__syncthreads();
+	uint32_t npad = 2;
+	while (npad < n) npad <<= 1;
+	const uint32_t half = npad >> 1;
+	for (uint32_t k = 2; k <= npad; k <<= 1) {
+		// first step of the merge: i <-> (block end - offset)
+		const uint32_t hk = k >> 1;
+		for (uint32_t t = tid; t < half; t += 256) {
+			const uint32_t blk = t / hk, off = t % hk;
+			const uint32_t i = blk * k + off, p = blk * k + (k - 1 - off);
+			if (p < n) {
+				const uint64_t x = a[i], y = a[p];
+				if (x > y) { a[i] = y; a[p] = x; }
+			}
+		}
+		__syncthreads();
+		for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+			for (uint32_t t = tid; t < half; t += 256) {
+				const uint32_t i = ((t / j) * (j << 1)) + (t % j), p = i + j;
+				if (p < n) {
+					const uint64_t x = a[i], y = a[p];
+					if (x > y) { a[i] = y; a[p] = x; }
+				}
+			}
+			__syncthreads();
+		}
+	}
+	for (uint32_t i = tid; i < n; i += 256) point_list[range.x + i] = (uint32_t)a[i];
+}
+
+void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
+                      hipStream_t s)
+{
+	if (max_tile_count == 0) return;
+	// small: <= 4096 keys (32 KiB LDS, several workgroups per CU); large: <= 16384 (128 KiB); huge: global
+	const uint32_t CAP_S = 4096, CAP_L = 16384;
+	{
+		const uint32_t cap = max_tile_count < CAP_S ? max(256u, max_tile_count) : CAP_S;
+		hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(T), dim3(256), cap * sizeof(uint64_t), s, ranges, keys,
+		                   point_list, 0u, CAP_S);
+	}
+	if (max_tile_count > CAP_S) {
+		static bool attr_set = false;
+		if (!attr_set) {
+			(void)hipFuncSetAttribute((const void*)tile_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                          CAP_L * sizeof(uint64_t));
+			attr_set = true;
+		}
+		hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(T), dim3(256), CAP_L * sizeof(uint64_t), s, ranges, keys,
+		                   point_list, CAP_S, CAP_L);
+	}
+	if (max_tile_count > CAP_L)
+		hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(T), dim3(256), 0, s, ranges, keys, point_list, CAP_L,
+		                   0xffffffffu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// composite_fwd: 256 threads = 4 wave64; wave w owns the 16x4 pixel strip rows 4w..4w+3 of the tile.
+// Instances are staged 256 at a time through LDS as three float4 planes; the inner loop reads them
+// with wave-uniform (broadcast) ds_read_b128.  Per-lane early termination (`done`), the wave leaves
+// the inner loop when all its lanes are done, the workgroup leaves when all four waves are.
+// XCD-aware tile order: workgroup b runs on XCD b%8 (observed placement, speed only); each XCD is
+// given a contiguous band of tiles so that neighbouring tiles, which share Gaussians, gather the
+// same records from the same 4 MiB L2.
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
+    int T, int chunk, int gx, int W, int H, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
+    float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+{
+	__shared__ float4 sA[256];
+	__shared__ float4 sB[256];
+	__shared__ float4 sC[256];
+	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+	const int tid = threadIdx.x;
+	const int tx = tile % gx, ty = tile / gx;
+	const int px = tx * GSR_BLOCK_X + (tid & 15), py = ty * GSR_BLOCK_Y + (tid >> 4);
+	const bool inside = px < W && py < H;
+	const float pixfx = (float)px, pixfy = (float)py;
+	const uint2 range = ranges[tile];
+	const int total = (int)(range.y - range.x);
+	bool done = !inside;
+	float T_ = 1.0f;
+	uint32_t last_contributor = 0;
+	float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dacc = 0.f;
+	float median_D = 15.0f, median_weight = 0.f, median_id = 0.f;
+
+	for (int base = 0; base < total; base += 256) {
+		if (__syncthreads_and(done)) break;
+		const int cnt = min(256, total - base);
+		if (tid < cnt) {
+			const uint32_t id = point_list[range.x + base + tid];
+			const GsRec* r = recs + id;
+			sA[tid] = r->q0;
+			sB[tid] = r->q1;
+			float4 c = r->q2;
+			c.w = __int_as_float((int)id);
+			sC[tid] = c;
+		}
+		__syncthreads();
+		for (int j = 0; !done && j < cnt; j++) {
+			const float4 A = sA[j];
+			const float4 B = sB[j];
+			const float dx = A.x - pixfx, dy = A.y - pixfy;
+			// power = -0.5(a dx^2 + c dy^2) - b dx dy with pre-scaled conic (forward.cu:338)
+			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
+			if (power > 0.0f || power < B.w) continue;
+			const float alpha = fminf(0.99f, B.y * gs_exp(power));
+			if (alpha < 1.0f / 255.0f) continue;
+			const float test_T = T_ * (1 - alpha);
+			if (test_T < 0.0001f) {
+				done = true;
+				continue;
+			}
+			const float4 Cc = sC[j];
+			const float w = alpha * T_;
+			C0 = FMA(Cc.x, w, C0);
+			C1 = FMA(Cc.y, w, C1);
+			C2 = FMA(Cc.z, w, C2);
+			Dacc = FMA(B.z, w, Dacc);
+			if (T_ > 0.5f && test_T < 0.5f) {
+				median_D = B.z;
+				median_weight = w;
+				median_id = (float)__float_as_int(Cc.w);
+			}
+			T_ = test_T;
+			last_contributor = (uint32_t)(base + j + 1);
+		}
+	}
+	final_T[(size_t)tile * GSR_TILE_PIX + tid] = T_;
+	n_contrib[(size_t)tile * GSR_TILE_PIX + tid] = last_contributor;
+	if (inside) {
+		const size_t HW = (size_t)H * W;
+		const size_t pix_id = (size_t)W * py + px;
+		out_color[pix_id] = C0;
+		out_color[HW + pix_id] = C1;
+		out_color[2 * HW + pix_id] = C2;
+		out_depth[pix_id] = Dacc;
+		out_median[pix_id] = median_D;
+		out_median[HW + pix_id] = median_weight;
+		out_median[2 * HW + pix_id] = median_id;
+		out_opacity[pix_id] = 1 - T_;
+	}
+}
+
+void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
+                          const GsRec* recs, float* out_color, float* out_depth, float* out_median,
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, hipStream_t s)
+{
+	const int chunk = (il.T + 7) / 8;
+	hipLaunchKernelGGL(composite_fwd_kernel, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges,
+	                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib);
+}
+
+}  // namespace gsr

@@ -1,0 +1,126 @@
+"""Host-side mirror of the reference's operator interface
+($RAST/gaustudio_diff_gaussian_rasterization/__init__.py): the 12-field settings tuple (:160-172),
+the nn.Module front door (:174-223) and the autograd Function (:44-158), so that
+gaustudio/renderers/base.py:7,23-49 works against the MI355X op unchanged.
+
+Everything numeric happens in gaustudio_amd._C -> libgsrast.so (hand-written HIP, gfx950).
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    # field order is part of the contract (positional construction works in the reference)
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _to_cpu_snapshot(values):
+    """Debug mode keeps a host copy of every argument so a failing call can be replayed
+    (reference: cpu_deep_copy_tuple, __init__.py:17-19)."""
+    return tuple(v.detach().cpu().clone() if isinstance(v, torch.Tensor) else v for v in values)
+
+
+def _run_guarded(fn, args, debug, dump_name, banner):
+    if not debug:
+        return fn(*args)
+    snapshot = _to_cpu_snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(snapshot, dump_name)
+        print(banner)
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        # argument order of _C.rasterize_gaussians (rasterize_points.h:18-38)
+        call = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        (num_rendered, color, depth, median_depth, final_opacity, radii, geom_buf, binning_buf,
+         img_buf) = _run_guarded(
+            _C.rasterize_gaussians, call, rs.debug, "snapshot_fw.dump",
+            "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf,
+                              binning_buf, img_buf)
+        return color, radii, depth, median_depth, final_opacity
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_median_depth, grad_final_opacity):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf,
+         img_buf) = ctx.saved_tensors
+        # argument order of _C.rasterize_gaussians_backward (rasterize_points.h:40-65)
+        call = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth,
+                grad_median_depth, grad_final_opacity, sh, rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered,
+                binning_buf, img_buf, rs.debug)
+        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations) = _run_guarded(
+            _C.rasterize_gaussians_backward, call, rs.debug, "snapshot_bw.dump",
+            "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+        # back to the input order of forward(); the settings tuple gets no gradient
+        return (g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3D, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+def _absent():
+    # the reference's "not provided" marker: an empty CPU float tensor whose data_ptr is null
+    return torch.Tensor([])
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: Gaussians passing the near-plane test for this camera (__init__.py:179-188)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        have_sh, have_col = shs is not None, colors_precomp is not None
+        if have_sh == have_col:
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        have_sr_any = scales is not None or rotations is not None
+        have_sr_all = scales is not None and rotations is not None
+        have_cov = cov3D_precomp is not None
+        if (not have_sr_all and not have_cov) or (have_sr_any and have_cov):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(
+            means3D, means2D,
+            shs if have_sh else _absent(),
+            colors_precomp if have_col else _absent(),
+            opacities,
+            scales if scales is not None else _absent(),
+            rotations if rotations is not None else _absent(),
+            cov3D_precomp if have_cov else _absent(),
+            self.raster_settings)

@@ -1,0 +1,164 @@
+/*
+ * gsrast.h -- C ABI of libgsrast.so, the MI355X-native (gfx950) differentiable 3D-Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the reference's native layer
+ *   $RAST = submodules/gaustudio-diff-gaussian-rasterization   (in GAP-LAB-CUHK-SZ/gaustudio)
+ *   $RAST/cuda_rasterizer/rasterizer.h:20-92   class CudaRasterizer::Rasterizer { markVisible, forward, backward }
+ * Each entry point below replaces one of those static methods: same argument meaning and order, plain
+ * pointers and sizes, plus an explicit HIP stream (the reference launches on the legacy default stream).
+ * The torch extension `_C` (gaustudio_amd/csrc/torch_binding.cpp) is a thin adapter over these, replacing
+ * $RAST/rasterize_points.cu:35-231 / ext.cpp:15-19.
+ *
+ * Conventions shared with the reference:
+ *   - all tensors float32, row-major, device memory of the current HIP device;
+ *   - an absent optional input is a NULL pointer (forward.cu:205,241; backward.cu:406,410);
+ *   - viewmatrix / projmatrix are float[16] holding the column-major 4x4 (i.e. the transposed
+ *     torch tensors gaustudio's Camera builds, datasets/__init__.py:154-159);
+ *   - outputs are CHW planes (forward.cu:387-395).
+ * Differences, all deliberate:
+ *   - `background`, `viewmatrix`, `projmatrix`, `cam_pos` may live in HOST or DEVICE memory
+ *     (gaustudio's renderers pass a CPU `bg`, renderers/vanilla_renderer.py:23);
+ *   - the three opaque buffers are obtained through C callbacks instead of std::function
+ *     (rasterizer.h:38-40); their internal layout is private to this library;
+ *   - gsr_backward takes uninitialised OUTPUT pointers plus one scratch buffer; the reference wanted
+ *     ten pre-zeroed tensors of which two (dL_dconic, dL_ddepth) were scratch (rasterize_points.cu:160-169);
+ *   - errors are return codes + gsr_last_error() instead of C++ exceptions.
+ */
+#ifndef GSRAST_H_INCLUDED
+#define GSRAST_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_ERR_HIP (-1)         /* a HIP runtime call or kernel failed; see gsr_last_error() */
+#define GSR_ERR_ARG (-2)         /* invalid argument (e.g. neither SH nor colours; rasterizer_impl.cu:245-248) */
+#define GSR_ERR_PREFILTERED (-3) /* a point was culled although `prefiltered` is set (auxiliary.h:156-160) */
+#define GSR_ERR_ALLOC (-4)       /* an allocator callback returned NULL */
+
+/* Replaces std::function<char*(size_t)> (rasterizer.h:38-40): must return device memory of at
+ * least `bytes` bytes, 256-byte aligned, that stays valid until the matching backward has run. */
+typedef char* (*gsr_alloc_fn)(void* ctx, size_t bytes);
+
+/* ABI version of this header (bumped on any signature change). */
+int gsr_abi_version(void);
+
+/* Message of the last error on the calling thread ("" if none). */
+const char* gsr_last_error(void);
+
+/* Replaces Rasterizer::markVisible (rasterizer.h:24-29; rasterizer_impl.cu:141-153).
+ * present[i] = 1 iff Gaussian i passes the near-plane test p_view.z > 0.2 (auxiliary.h:154). */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     unsigned char* present, void* stream);
+
+/* Replaces Rasterizer::forward (rasterizer.h:31-59; rasterizer_impl.cu:198-343).
+ * Returns num_rendered (>= 0, number of Gaussian x tile instances) or a negative GSR_ERR_*.
+ * D = active SH degree, M = SH coefficients per Gaussian as stored (row stride of `shs`).
+ * Exactly one of {shs, colors_precomp} and one of {scales+rotations, cov3D_precomp} must be non-NULL.
+ * out_color[3,H,W], out_depth[1,H,W], out_median_depth[3,H,W], out_opacity[1,H,W], radii[P] are
+ * fully overwritten (no pre-zeroing needed).  Blocks the host once to read num_rendered back
+ * (as rasterizer_impl.cu:283-284 does). */
+int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx,
+                gsr_alloc_fn binning_alloc, void* binning_ctx,
+                gsr_alloc_fn image_alloc, void* image_ctx,
+                int P, int D, int M,
+                const float* background,
+                int width, int height,
+                const float* means3D,
+                const float* shs,
+                const float* colors_precomp,
+                const float* opacities,
+                const float* scales,
+                float scale_modifier,
+                const float* rotations,
+                const float* cov3D_precomp,
+                const float* viewmatrix,
+                const float* projmatrix,
+                const float* cam_pos,
+                float tan_fovx, float tan_fovy,
+                int prefiltered,
+                float* out_color,
+                float* out_depth,
+                float* out_median_depth,
+                float* out_opacity,
+                int* radii,
+                int debug,
+                void* stream);
+
+/* Bytes of device scratch gsr_backward needs for P Gaussians. */
+size_t gsr_backward_scratch_bytes(int P);
+
+/* Replaces Rasterizer::backward (rasterizer.h:61-91; rasterizer_impl.cu:347-452).
+ * R = num_rendered returned by the matching gsr_forward; geom/binning/image buffers are the ones its
+ * allocators returned, unmodified.  Outputs (all fully overwritten, rows of culled Gaussians = 0):
+ *   dL_dmean2D[P,3] (xy used, already scaled by 0.5*W / 0.5*H, backward.cu:493-494,598-599),
+ *   dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3] (may be NULL if M==0),
+ *   dL_dscale[P,3], dL_drot[P,4].
+ * Only channel 0 of dL_dpix_median_depth[3,H,W] is read (backward.cu:481-482). */
+int gsr_backward(int P, int D, int M, int R,
+                 const float* background,
+                 int width, int height,
+                 const float* means3D,
+                 const float* shs,
+                 const float* colors_precomp,
+                 const float* scales,
+                 float scale_modifier,
+                 const float* rotations,
+                 const float* cov3D_precomp,
+                 const float* viewmatrix,
+                 const float* projmatrix,
+                 const float* campos,
+                 float tan_fovx, float tan_fovy,
+                 const int* radii,
+                 const char* geom_buffer,
+                 const char* binning_buffer,
+                 const char* image_buffer,
+                 const float* dL_dpix,
+                 const float* dL_dpix_depth,
+                 const float* dL_dpix_median_depth,
+                 const float* dL_dpix_final_opacity,
+                 float* dL_dmean2D,
+                 float* dL_dopacity,
+                 float* dL_dcolor,
+                 float* dL_dmean3D,
+                 float* dL_dcov3D,
+                 float* dL_dsh,
+                 float* dL_dscale,
+                 float* dL_drot,
+                 char* scratch,
+                 int debug,
+                 void* stream);
+
+/* ---- introspection of the opaque buffers (tests, debugging).  The reference exposes the same state
+ * only implicitly through GeometryState/BinningState/ImageState (rasterizer_impl.h:33-64).
+ * Any output pointer may be NULL.  All outputs are device memory. ---- */
+
+/* means2D[P,2], depths[P], conic_opacity[P,4], rgb[P,3], clamped[P,3] (0/1 bytes), tiles_touched[P].
+ * Rows of culled Gaussians (radii==0) are written as zeros. */
+int gsr_inspect_geometry(const char* geom_buffer, int P, const int* radii, float* means2D, float* depths,
+                         float* conic_opacity, float* rgb, unsigned char* clamped,
+                         uint32_t* tiles_touched, void* stream);
+
+/* point_list[R] (Gaussian ids, tile-major, depth-sorted), ranges[T,2] ([start,end) per tile). */
+int gsr_inspect_binning(const char* binning_buffer, const char* image_buffer, int R, int width, int height,
+                        uint32_t* point_list, uint32_t* ranges, void* stream);
+
+/* final_T[H,W], n_contrib[H,W] in pixel-major order (forward.cu:385-386). */
+int gsr_inspect_image(const char* image_buffer, int width, int height, float* final_T,
+                      uint32_t* n_contrib, void* stream);
+
+/* Per-stage GPU time of the last gsr_forward / gsr_backward on this thread when profiling was
+ * enabled with gsr_set_profiling(1): milliseconds for {preprocess, scan, scatter, sort, composite}
+ * (forward) or {composite_bwd, preprocess_bwd} (backward).  Profiling adds event records only. */
+void gsr_set_profiling(int enable);
+int gsr_last_forward_ms(float ms[5]);
+int gsr_last_backward_ms(float ms[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRAST_H_INCLUDED */

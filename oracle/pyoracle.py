@@ -151,13 +151,25 @@ def backward(st, grad_color, grad_depth, grad_median, grad_opacity, tile_step=1,
                         _p(st["conic_opacity"]), _p(st["features"]), _p(st["depths"]), _p(st["final_T"]),
                         _p(st["n_contrib"]), _p(g_color), _p(g_depth), _p(g_median), _p(g_op), _p(acc),
                         _p(accabs), int(tile_step))
-    a32 = acc.astype(np.float32)
+    out = finish_backward(st, acc.astype(np.float32))
+    out["acc"] = acc
+    out["accabs"] = accabs
+    return out
+
+
+def finish_backward(st, a32):
+    """Per-Gaussian half of the backward (computeCov2DCUDA + preprocessCUDA, backward.cu:144-274,346-412)
+    from composite-stage sums a32[P,10] (component order of gsr_oracle.c) given in float32."""
+    L = lib()
+    inp = st["_inputs"]
+    P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
+    a32 = np.ascontiguousarray(a32, dtype=np.float32)
     dL_dmean2D = np.zeros((P, 3), np.float32); dL_dmean2D[:, :2] = a32[:, 0:2]
     dL_dconic = np.zeros((P, 4), np.float32); dL_dconic[:, 0] = a32[:, 2]; dL_dconic[:, 1] = a32[:, 3]; dL_dconic[:, 3] = a32[:, 4]
     dL_dopacity = np.ascontiguousarray(a32[:, 5:6])
     dL_dcolor = np.ascontiguousarray(a32[:, 6:9])
     dL_ddepth = np.ascontiguousarray(a32[:, 9])
-    out = dict(acc=acc, accabs=accabs, dL_dmeans2D=dL_dmean2D, dL_dconic=dL_dconic, dL_dopacity=dL_dopacity,
+    out = dict(dL_dmeans2D=dL_dmean2D, dL_dconic=dL_dconic, dL_dopacity=dL_dopacity,
                dL_dcolors=dL_dcolor, dL_ddepths=dL_ddepth)
     out["dL_dmeans3D"] = np.zeros((P, 3), np.float32)
     out["dL_dcov3D"] = np.zeros((P, 6), np.float32)

@@ -1,0 +1,157 @@
+"""-m gpu: forward parity of the HIP path (through the C ABI) against the CPU oracle -- BIT-EXACT.
+
+The oracle (oracle/gsr_oracle.c) restates $RAST/cuda_rasterizer/forward.cu + rasterizer_impl.cu with a
+pinned FMA contraction and an explicit exp(); the HIP kernels implement the same arithmetic, so every
+float of every output and intermediate must be identical (tolerance: 0 ulp; the north-star tolerance
+of 1e-5 abs on RGB/depth applies to the comparison with the reference binary, tests/test_gpu_ref.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from gaustudio_amd import scenes
+
+from util import compare_forward_exact, hip_forward, oracle_forward, scene_kwargs, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(oracle, P, W, H, D, use_sh=True, use_cov=False, seed=0, scale_modifier=1.0, sigma_px=1.5, bg=None):
+    cam = scenes.make_camera(W, H)
+    sc = scenes.make_scene(P, cam, seed=seed, sigma_px_median=sigma_px)
+    kw = scene_kwargs(sc, use_sh, use_cov)
+    os_ = oracle_forward(oracle, sc, cam, D, kw, scale_modifier, bg)
+    hs = hip_forward(sc, cam, D, kw, scale_modifier, bg)
+    compare_forward_exact(hs, os_)
+    return hs, os_
+
+
+@pytest.mark.parametrize("D", [0, 1, 2, 3])
+def test_c1_10k_400x400(oracle, D):
+    """BASELINE config C1 (10k Gaussians, 400x400), every SH degree."""
+    hs, os_ = _run(oracle, 10000, 400, 400, D)
+    assert hs["num_rendered"] > 10000
+
+
+@pytest.mark.parametrize("W,H", [(401, 399), (16, 16), (17, 33), (1, 1), (640, 8)])
+def test_ragged_image_sizes(oracle, W, H):
+    """Partial last tile row/column (1080 = 67.5 tiles in C3) and degenerate images."""
+    _run(oracle, 3000, W, H, 3, seed=5, sigma_px=2.5)
+
+
+def test_precomputed_colors_and_cov(oracle):
+    _run(oracle, 5000, 320, 240, 0, use_sh=False, use_cov=False, seed=2)
+    _run(oracle, 5000, 320, 240, 3, use_sh=True, use_cov=True, seed=3)
+    _run(oracle, 5000, 320, 240, 0, use_sh=False, use_cov=True, seed=4)
+
+
+def test_scale_modifier_and_white_bg(oracle):
+    # out_color is NOT blended with bg in this fork, so white bg must not change the image
+    a, _ = _run(oracle, 4000, 256, 256, 2, seed=7, scale_modifier=1.7)
+    b, _ = _run(oracle, 4000, 256, 256, 2, seed=7, scale_modifier=1.7, bg=torch.ones(3))
+    assert torch.equal(a["color"], b["color"])
+
+
+def test_large_footprints_cooperative_binning(oracle):
+    """Screen-filling Gaussians exercise the wave-cooperative tile walk (> 32 tiles per Gaussian)."""
+    hs, os_ = _run(oracle, 600, 512, 384, 1, seed=11, sigma_px=60.0)
+    assert int(to_np(hs["tiles_touched"]).max()) > 32
+
+
+@pytest.mark.parametrize("P,lo,hi", [(2500, 256, 4096), (12000, 4096, 16384), (100000, 16384, 1 << 30)])
+def test_long_tile_lists_lds_and_global_sort(oracle, P, lo, hi):
+    """Per-tile lists in each regime of tile_sort: <= 4096 keys (small LDS), <= 16384 (128 KiB LDS),
+    beyond (in-place global fallback)."""
+    cam = scenes.make_camera(48, 32)
+    sc = scenes.make_scene(P, cam, seed=13, sigma_px_median=6.0)
+    kw = scene_kwargs(sc, True, False)
+    os_ = oracle_forward(oracle, sc, cam, 0, kw)
+    r = os_["ranges"]
+    assert lo < int((r[:, 1] - r[:, 0]).max()) <= hi
+    hs = hip_forward(sc, cam, 0, kw)
+    compare_forward_exact(hs, os_)
+
+
+def test_depth_ties_resolve_by_id(oracle):
+    """Equal depths inside a tile must order by ascending Gaussian id."""
+    cam = scenes.make_camera(64, 64)
+    sc = scenes.make_scene(2000, cam, seed=17, sigma_px_median=4.0)
+    means = sc.means3D.clone()
+    z = torch.round(means[:, 2])          # only ~18 distinct depths
+    means[:, 0] *= z / means[:, 2]
+    means[:, 1] *= z / means[:, 2]
+    means[:, 2] = z
+    sc = sc._replace(means3D=means.contiguous())
+    kw = scene_kwargs(sc, True, False)
+    os_ = oracle_forward(oracle, sc, cam, 3, kw)
+    d = os_["depths"][os_["radii"] > 0]
+    assert len(np.unique(d)) < 40
+    hs = hip_forward(sc, cam, 3, kw)
+    compare_forward_exact(hs, os_)
+
+
+def test_all_culled_and_empty(oracle):
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(100, 60)
+    sc = scenes.make_scene(500, cam, seed=1)
+    sc = sc._replace(means3D=(sc.means3D * torch.tensor([1.0, 1.0, -1.0])).contiguous())   # behind the camera
+    kw = scene_kwargs(sc, True, False)
+    os_ = oracle_forward(oracle, sc, cam, 3, kw)
+    assert os_["num_rendered"] == 0
+    hs = hip_forward(sc, cam, 3, kw)
+    assert hs["num_rendered"] == 0 and int(hs["radii"].abs().sum()) == 0
+    for k in ("color", "depth", "median", "opacity"):
+        assert np.array_equal(to_np(hs[k]), os_[k]), k
+    # P == 0 (rasterize_points.cu:84): zero images, rendered = 0, empty buffers
+    e = torch.Tensor([])
+    dev = "cuda"
+    out = _C.rasterize_gaussians(torch.zeros(3), torch.zeros(0, 3, device=dev), e, torch.zeros(0, 1, device=dev),
+                                 torch.zeros(0, 3, device=dev), torch.zeros(0, 4, device=dev), 1.0, e,
+                                 cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.tanfovx, cam.tanfovy, cam.height,
+                                 cam.width, torch.zeros(0, 16, 3, device=dev), 3, cam.campos.to(dev), False, False)
+    assert out[0] == 0 and out[1].shape == (3, 60, 100) and float(out[1].abs().sum()) == 0.0
+    assert float(out[3][0].min()) == 15.0 and out[5].numel() == 0
+
+
+def test_mark_visible(oracle):
+    from gaustudio_amd import _C
+    cam = scenes.look_at_camera(64, 64, (3.0, 1.0, -6.0), (0.0, 0.0, 0.0))
+    sc = scenes.make_ball_scene(5000, radius=8.0, seed=3)
+    ref = oracle.mark_visible(sc.means3D.numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy())
+    got = _C.mark_visible(sc.means3D.cuda(), cam.viewmatrix.cuda(), cam.projmatrix.cuda())
+    assert got.dtype == torch.bool and np.array_equal(to_np(got), ref)
+    assert 0 < ref.sum() < ref.size
+    got2 = _C.mark_visible(sc.means3D.cuda(), cam.viewmatrix, cam.projmatrix)   # host-side matrices accepted
+    assert torch.equal(got, got2)
+
+
+def test_prefiltered_violation_raises():
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(64, 64)
+    sc = scenes.make_scene(100, cam, seed=1)
+    sc = sc._replace(means3D=(sc.means3D * torch.tensor([1.0, 1.0, -1.0])).contiguous())
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        hip_forward(sc, cam, 0, scene_kwargs(sc, True, False), prefiltered=True)
+
+
+def test_inward_ring_camera_rotated_view(oracle):
+    """Non-identity view matrices (C4-style ring cameras looking at a ball of Gaussians)."""
+    sc = scenes.make_ball_scene(20000, radius=3.0, seed=5, sigma=0.03)
+    for cam in scenes.ring_cameras(3, 320, 208, radius=8.0):
+        kw = scene_kwargs(sc, True, False)
+        os_ = oracle_forward(oracle, sc, cam, 3, kw)
+        hs = hip_forward(sc, cam, 3, kw)
+        compare_forward_exact(hs, os_)
+        assert os_["num_rendered"] > 1000
+
+
+def test_forward_is_deterministic():
+    """Two runs are bit-identical although bin_scatter fills tile segments with atomics: the per-tile
+    sort key (depth, id) is unique."""
+    cam = scenes.make_camera(800, 800)
+    sc = scenes.make_scene(300000, cam, seed=21)
+    kw = scene_kwargs(sc, True, False)
+    a = hip_forward(sc, cam, 3, kw)
+    b = hip_forward(sc, cam, 3, kw)
+    for k in ("color", "depth", "median", "opacity", "radii", "point_list", "final_T", "n_contrib"):
+        assert torch.equal(a[k], b[k]), k
