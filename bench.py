@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native Gaussian rasterizer.
+
+Metric (BASELINE.json): Mpixels/s forward+backward at 1 M Gaussians, 1920x1080 (config C3), per-kernel
+fraction of the HBM roofline, 1 -> 8 GPU scaling.  A "step" = one forward + one backward of the
+operator over one camera per GPU (through GaussianRasterizer / the autograd Function, i.e. the path
+gaustudio/renderers/base.py takes), inputs resident in HBM; for N > 1 each rank renders its own camera
+of the replicated scene and the step ends with ONE RCCL all-reduce of the flat per-Gaussian gradient
+buffer (gaustudio_amd/parallel.py).  value = N * H * W / step_time.
+
+    python bench.py                                  # N=1, C3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant north-star kernel (composite_fwd):
+algorithmic bytes R*44 + T*8 + H*W*32 (+ H*W*8 training aux) over its mean duration,
+measured with HIP events on the launch stream during the timed steps.  `cpu_baseline` is the CPU
+oracle (a C restatement of the reference kernels -- the reference itself has no CPU renderer) timed on
+the host cores on a bounded sample of the same frame.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (P, W, H, SH degree, description)
+    "C1": (10_000, 400, 400, 0, "C1: 10k synthetic Gaussians, 400x400, SH degree 0, fwd+bwd"),
+    "C2": (300_000, 800, 800, 3, "C2: 300k synthetic Gaussians (lego stand-in), 800x800, SH degree 3, fwd+bwd"),
+    "C3": (1_000_000, 1920, 1080, 3,
+           "C3: 1M synthetic Gaussians, 1920x1080, SH degree 3, fwd+bwd (colour+depth+median+opacity consumed)"),
+}
+
+
+def rank_camera(scenes, W, H, rank, world):
+    """Rank r looks down +z from the origin, yawed by 3 degrees per rank around the scene's axis so every
+    rank renders a different view of the same (replicated) Gaussians with the same amount of work."""
+    a = math.radians(3.0) * (rank - (world - 1) / 2.0)
+    R = np.array([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+    return scenes.make_camera(W, H, R=R)
+
+
+def cpu_baseline(sc, cam, D, grads, budget_s=20.0):
+    """Times the CPU oracle (fwd+bwd) on every `tile_step`-th tile of the same frame; per-Gaussian
+    stages run in full.  tile_step is chosen from a pilot so that the run takes roughly budget_s."""
+    from oracle import pyoracle as po   # test infrastructure, used here ONLY as the timed CPU baseline
+    po.build()
+    threads = po.num_threads()
+    kw = dict(sh_degree=D, shs=sc.shs.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
+    args = (sc.means3D.numpy(), sc.opacities.numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
+            cam.campos.numpy(), cam.width, cam.height, cam.tanfovx, cam.tanfovy)
+    g = [t.numpy() for t in grads]
+
+    def run(step):
+        t0 = time.perf_counter()
+        st = po.forward(*args, tile_step=step, **kw)
+        po.backward(st, *g, tile_step=step, want_abs=False)
+        return time.perf_counter() - t0
+
+    pilot_step = 32
+    t_pilot = run(pilot_step)
+    step = 1
+    while step < pilot_step and t_pilot * pilot_step / step > budget_s:
+        step *= 2
+    t = run(step) if step != pilot_step else t_pilot
+    T = ((cam.width + 15) // 16) * ((cam.height + 15) // 16)
+    tiles = len(range(0, T, step))
+    pixels = cam.width * cam.height * tiles / T
+    return {"value": round(pixels / t / 1e6, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "seconds": round(t, 2),
+            "sample": f"CPU restatement of the reference kernels (oracle/gsr_oracle.c, OpenMP x{threads}): fwd+bwd on "
+                      f"every {step}th 16x16 tile of the same frame ({tiles}/{T} tiles), per-Gaussian stages in full"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--fwd-only", action="store_true", help="time the no_grad forward only (inference paths)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", type=float, default=None,
+                    help="measured HBM bytes per composite_fwd launch from a rocprofv3 --pmc pass (profiles/)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gaustudio_amd import _C, parallel, scenes
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    P, W, H, D, desc = WORKLOADS[a.workload]
+    cam0 = scenes.make_camera(W, H)
+    sc = scenes.make_scene(P, cam0, seed=0)                 # identical on every rank (replicated parameters)
+    cam = rank_camera(scenes, W, H, rank, world)
+    grads_cpu = scenes.make_output_grads(cam, seed=1)
+
+    params = {k: getattr(sc, k).to(dev).requires_grad_(not a.fwd_only)
+              for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    means2D = torch.zeros_like(params["means3D"], requires_grad=not a.fwd_only)
+    grads = [g.to(dev) for g in grads_cpu]
+    rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=dev), 1.0,
+                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), D, cam.campos.to(dev),
+                                       False, False)
+    rasterizer = GaussianRasterizer(rs)
+    bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()))
+    state = {}
+
+    def step():
+        if a.fwd_only:
+            with torch.no_grad():
+                out = rasterizer(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
+                                 shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
+            state["out"] = out
+            return
+        for p in params.values():
+            p.grad = None
+        means2D.grad = None
+        color, radii, depth, median, opac = rasterizer(
+            means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], shs=params["shs"],
+            scales=params["scales"], rotations=params["rotations"])
+        torch.autograd.backward([color, depth, median, opac], grads)
+        parallel.allreduce_gaussian_grads(bucket)          # one flat all-reduce (no-op collective at N=1)
+        state["out"] = (color, radii, depth, median, opac)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    _C.set_profiling(True)                                   # HIP events on the launch stream, no host syncs
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    fwd_ms = _C.last_forward_ms()
+    bwd_ms = _C.last_backward_ms()
+    _C.set_profiling(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # instance count R of this rank's view (drives every composite-stage byte count)
+    with torch.no_grad():
+        R = _C.rasterize_gaussians(rs.bg, params["means3D"], torch.Tensor([]), params["opacities"], params["scales"],
+                                   params["rotations"], 1.0, torch.Tensor([]), rs.viewmatrix, rs.projmatrix,
+                                   rs.tanfovx, rs.tanfovy, H, W, params["shs"], D, rs.campos, False, False)[0]
+        vis = int((state["out"][1] > 0).sum().item())
+
+    if rank == 0:
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        ms_per_step = dt / a.steps * 1e3
+        value = world * H * W / (dt / a.steps) / 1e6
+        comp_ms = fwd_ms["composite"] if fwd_ms else None
+        alg_bytes = R * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8)
+        roof = None
+        if comp_ms:
+            achieved = alg_bytes / (comp_ms * 1e-3) / 1e9
+            roof = {"kernel": "composite_fwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": a.traffic,
+                    "algorithmic_bytes": alg_bytes, "avg_ms": round(comp_ms, 4),
+                    "note": "composite is VALU-bound (256 pixel evaluations per staged 48-B record), see DESIGN.md s5"}
+        line = {
+            "metric": "Mpixels/s fwd+bwd @1M Gaussians 1920x1080" if a.workload == "C3" and not a.fwd_only
+                      else f"Mpixels/s {'fwd' if a.fwd_only else 'fwd+bwd'} @{a.workload}",
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "gaussians": P, "visible": vis, "width": W, "height": H, "sh_degree": D,
+                       "num_rendered": R, "tiles": T, "views_per_step": world,
+                       "parallelism": f"one camera per GPU x{world}, 1 flat RCCL all-reduce of "
+                                      f"{0 if bucket is None else bucket.nbytes} B/rank" if world > 1 else "single GPU"},
+            "stage_ms": {"forward": fwd_ms, "backward": bwd_ms},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sc, cam, D, grads_cpu)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -256,12 +256,22 @@ def set_profiling(enable):
 
 
 def last_forward_ms():
+    """Mean per-stage GPU milliseconds over the forward calls since set_profiling(True) (HIP events
+    recorded on the launch stream); None if nothing was recorded."""
     a = (ctypes.c_float * 5)()
-    ok = lib().gsr_last_forward_ms(a)
-    return dict(zip(("preprocess", "scan", "scatter", "sort", "composite"), list(a))) if ok else None
+    n = lib().gsr_last_forward_ms(a)
+    if not n:
+        return None
+    d = dict(zip(("preprocess", "scan", "scatter", "sort", "composite"), list(a)))
+    d["calls"] = n
+    return d
 
 
 def last_backward_ms():
     a = (ctypes.c_float * 2)()
-    ok = lib().gsr_last_backward_ms(a)
-    return dict(zip(("composite_bwd", "preprocess_bwd"), list(a))) if ok else None
+    n = lib().gsr_last_backward_ms(a)
+    if not n:
+        return None
+    d = dict(zip(("composite_bwd", "preprocess_bwd"), list(a)))
+    d["calls"] = n
+    return d

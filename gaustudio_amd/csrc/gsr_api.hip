@@ -5,17 +5,64 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 using namespace gsr;
 
 namespace {
 
 thread_local std::string g_err;
-thread_local bool g_prof = false;
-thread_local float g_fwd_ms[5] = {0, 0, 0, 0, 0};
-thread_local float g_bwd_ms[2] = {0, 0};
-thread_local int g_fwd_valid = 0, g_bwd_valid = 0;
+// ---- per-stage profiling: HIP events recorded on the launch stream, resolved lazily ----
+struct ProfSet {
+	hipEvent_t ev[6];
+	int n = 0;
+};
+struct ProfLog {
+	std::vector<ProfSet*> sets;   // pool, reused across resets
+	size_t used = 0;
+	ProfSet* next()
+	{
+		if (used == sets.size()) {
+			ProfSet* p = new ProfSet;
+			for (auto& e : p->ev) (void)hipEventCreate(&e);
+			sets.push_back(p);
+		}
+		ProfSet* p = sets[used++];
+		p->n = 0;
+		return p;
+	}
+	// mean stage times over every recorded call; returns the number of calls
+	int mean(float* out, int k)
+	{
+		for (int i = 0; i < k; i++) out[i] = 0.f;
+		if (used == 0) return 0;
+		int calls = 0;
+		for (size_t c = 0; c < used; c++) {
+			ProfSet* p = sets[c];
+			if (p->n < 2) continue;
+			if (hipEventSynchronize(p->ev[p->n - 1]) != hipSuccess) continue;
+			for (int i = 0; i < k && i + 1 < p->n; i++) {
+				float ms = 0.f;
+				(void)hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
+				out[i] += ms;
+			}
+			calls++;
+		}
+		for (int i = 0; i < k && calls; i++) out[i] /= (float)calls;
+		return calls;
+	}
+};
+// process-wide (autograd runs backward on its own thread); guarded by g_prof_mu
+std::mutex g_prof_mu;
+bool g_prof = false;
+ProfLog g_fwd_log, g_bwd_log;
+ProfSet* prof_next(ProfLog& log)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	return g_prof ? log.next() : nullptr;
+}
 
 int fail(int code, const char* what, const char* file, int line, hipError_t e = hipSuccess)
 {
@@ -74,29 +121,12 @@ uint32_t* pinned_words()
 }
 
 struct Timer {
-	hipEvent_t ev[8];
-	int n = 0;
-	bool on;
+	ProfSet* set;
 	hipStream_t s;
-	Timer(bool enable, hipStream_t st) : on(enable), s(st)
-	{
-		if (on)
-			for (auto& e : ev) (void)hipEventCreate(&e);
-	}
+	Timer(ProfSet* p, hipStream_t st) : set(p), s(st) {}
 	void mark()
 	{
-		if (on && n < 8) (void)hipEventRecord(ev[n++], s);
-	}
-	void collect(float* out, int k)
-	{
-		if (!on) return;
-		(void)hipEventSynchronize(ev[n - 1]);
-		for (int i = 0; i < k && i + 1 < n; i++) (void)hipEventElapsedTime(&out[i], ev[i], ev[i + 1]);
-	}
-	~Timer()
-	{
-		if (on)
-			for (auto& e : ev) (void)hipEventDestroy(e);
+		if (set && set->n < 6) (void)hipEventRecord(set->ev[set->n++], s);
 	}
 };
 
@@ -156,17 +186,23 @@ int gsr_abi_version(void) { return 1; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
-void gsr_set_profiling(int enable) { g_prof = enable != 0; }
+void gsr_set_profiling(int enable)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	g_prof = enable != 0;
+	g_fwd_log.used = 0;
+	g_bwd_log.used = 0;
+}
 
 int gsr_last_forward_ms(float ms[5])
 {
-	for (int i = 0; i < 5; i++) ms[i] = g_fwd_ms[i];
-	return g_fwd_valid;
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	return g_fwd_log.mean(ms, 5);
 }
 int gsr_last_backward_ms(float ms[2])
 {
-	for (int i = 0; i < 2; i++) ms[i] = g_bwd_ms[i];
-	return g_bwd_valid;
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	return g_bwd_log.mean(ms, 2);
 }
 
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -201,7 +237,6 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 {
 	hipStream_t s = (hipStream_t)stream;
 	g_err.clear();
-	g_fwd_valid = 0;
 	if (width <= 0 || height <= 0) return fail(GSR_ERR_ARG, "gsr_forward: bad image size", __FILE__, __LINE__);
 	if (!out_color || !out_depth || !out_median_depth || !out_opacity)
 		return fail(GSR_ERR_ARG, "gsr_forward: NULL output", __FILE__, __LINE__);
@@ -239,7 +274,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	float* final_T = reinterpret_cast<float*>(img + il.final_T);
 	uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + il.n_contrib);
 
-	Timer tm(g_prof, s);
+	Timer tm(prof_next(g_fwd_log), s);
 	// camera block + control words + tile counters
 	HIP_TRY(stage_floats(cam->view, viewmatrix, 16, s));
 	HIP_TRY(stage_floats(cam->proj, projmatrix, 16, s));
@@ -292,10 +327,6 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	                     out_opacity, final_T, n_contrib, s);
 	STAGE_CHECK("composite_fwd", debug, s);
 	tm.mark();
-	if (g_prof) {
-		tm.collect(g_fwd_ms, 5);
-		g_fwd_valid = 1;
-	}
 	return (int)R;
 }
 
@@ -316,7 +347,6 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 {
 	hipStream_t s = (hipStream_t)stream;
 	g_err.clear();
-	g_bwd_valid = 0;
 	(void)viewmatrix; (void)projmatrix; (void)campos;   // the device copies made by gsr_forward are used
 	if (P <= 0) return GSR_OK;   // rasterize_points.cu:171
 	if (!geom_buffer || !image_buffer || !binning_buffer || !scratch || !radii || !means3D)
@@ -344,7 +374,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 	// the reference reads the backward's own `background` argument (backward.cu:584-587), which the
 	// forward never dereferences.
 	float* bg_dev = reinterpret_cast<float*>(scratch + align_up(sizeof(float) * GSR_ACC_STRIDE * (size_t)P));
-	Timer tm(g_prof, s);
+	Timer tm(prof_next(g_bwd_log), s);
 	HIP_TRY(hipMemsetAsync(acc, 0, sizeof(float) * GSR_ACC_STRIDE * (size_t)P, s));
 	HIP_TRY(stage_floats(bg_dev, background, 3, s));
 
@@ -365,10 +395,6 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 	                      dL_dscale, dL_drot, s);
 	STAGE_CHECK("preprocess_bwd", debug, s);
 	tm.mark();
-	if (g_prof) {
-		tm.collect(g_bwd_ms, 2);
-		g_bwd_valid = 1;
-	}
 	return GSR_OK;
 }
 

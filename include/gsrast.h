@@ -151,9 +151,11 @@ int gsr_inspect_binning(const char* binning_buffer, const char* image_buffer, in
 int gsr_inspect_image(const char* image_buffer, int width, int height, float* final_T,
                       uint32_t* n_contrib, void* stream);
 
-/* Per-stage GPU time of the last gsr_forward / gsr_backward on this thread when profiling was
- * enabled with gsr_set_profiling(1): milliseconds for {preprocess, scan, scatter, sort, composite}
- * (forward) or {composite_bwd, preprocess_bwd} (backward).  Profiling adds event records only. */
+/* Per-stage GPU time, averaged over every gsr_forward / gsr_backward call made on this thread since
+ * gsr_set_profiling(1): milliseconds for {preprocess, scan(+readback), scatter, sort, composite} (forward)
+ * or {composite_bwd, preprocess_bwd} (backward), measured with HIP events recorded on the launch stream.
+ * Recording costs one event per stage and no synchronisation; the getters synchronise on the last
+ * recorded event and return the number of calls averaged (0 = nothing recorded). */
 void gsr_set_profiling(int enable);
 int gsr_last_forward_ms(float ms[5]);
 int gsr_last_backward_ms(float ms[2]);
