@@ -35,9 +35,9 @@ def lib():
         L = ctypes.CDLL(_LIB_PATH)
         L.gsr_last_error.restype = ctypes.c_char_p
         L.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
-        L.gsr_backward_scratch_bytes.argtypes = [ctypes.c_int]
+        L.gsr_backward_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.gsr_abi_version.restype = ctypes.c_int
-        if L.gsr_abi_version() != 1:
+        if L.gsr_abi_version() != 2:
             raise ImportError("libgsrast.so ABI version mismatch")
         _lib = L
     return _lib
@@ -169,7 +169,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dscales = torch.empty((P, 3), **fo)
         dL_drotations = torch.empty((P, 4), **fo)
         if P != 0:
-            scratch = torch.empty(L.gsr_backward_scratch_bytes(ctypes.c_int(P)), dtype=torch.uint8, device=dev)
+            scratch = torch.empty(L.gsr_backward_scratch_bytes(ctypes.c_int(P), ctypes.c_int(int(R))), dtype=torch.uint8,
+                                  device=dev)
             rc = L.gsr_backward(ctypes.c_int(P), ctypes.c_int(int(degree)), ctypes.c_int(M), ctypes.c_int(int(R)),
                                 _ptr(background), ctypes.c_int(W), ctypes.c_int(H), _ptr(means3D), _ptr(sh),
                                 _ptr(colors), _ptr(scales), ctypes.c_float(scale_modifier), _ptr(rotations),

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(256) void inspect_image_kernel(int gx, int W, int H
                                                             float* final_T, uint32_t* n_contrib)
 {
 	const int tile = blockIdx.x, tid = threadIdx.x;
-	const int px = (tile % gx) * GSR_BLOCK_X + (tid & 15), py = (tile / gx) * GSR_BLOCK_Y + (tid >> 4);
+	int lx, ly;
+	gs_pixel_of_thread(tid, lx, ly);
+	const int px = (tile % gx) * GSR_BLOCK_X + lx, py = (tile / gx) * GSR_BLOCK_Y + ly;
 	if (px >= W || py >= H) return;
 	const size_t pix = (size_t)W * py + px;
 	if (final_T) final_T[pix] = tT[(size_t)tile * GSR_TILE_PIX + tid];
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void inspect_image_kernel(int gx, int W, int H
 
 extern "C" {
 
-int gsr_abi_version(void) { return 1; }
+int gsr_abi_version(void) { return 2; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -289,7 +291,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.prefiltered = prefiltered;
 
 	tm.mark();
-	launch_preprocess_fwd(a, cam, il, radii, recs, tile_count, ctl, s);
+	launch_preprocess_fwd(a, cam, il, radii, recs, reinterpret_cast<uint32_t*>(geom + gl.tiles_touched), tile_count, ctl, s);
 	STAGE_CHECK("preprocess_fwd", debug, s);
 	tm.mark();
 	launch_tile_scan(il.T, tile_count, ranges, ctl, s);
@@ -330,9 +332,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	return (int)R;
 }
 
-size_t gsr_backward_scratch_bytes(int P)
+size_t gsr_backward_scratch_bytes(int P, int R)
 {
-	return align_up(sizeof(float) * GSR_ACC_STRIDE * (size_t)(P > 0 ? P : 1)) + 256;
+	return BwdLayout((size_t)(P > 0 ? P : 0), (size_t)(R > 0 ? R : 0)).total;
 }
 
 int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -368,15 +370,20 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 	const float* final_T = reinterpret_cast<const float*>(image_buffer + il.final_T);
 	const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + il.n_contrib);
 	const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + bl.point_list);
-	float* acc = reinterpret_cast<float*>(scratch);
+	const uint32_t* tiles_touched = reinterpret_cast<const uint32_t*>(geom_buffer + gl.tiles_touched);
+	const BwdLayout wl((size_t)P, (size_t)(R > 0 ? R : 0));
+	uint32_t* goff = reinterpret_cast<uint32_t*>(scratch + wl.goff);
+	uint32_t* bsums = reinterpret_cast<uint32_t*>(scratch + wl.bsums);
+	float* bg_dev = reinterpret_cast<float*>(scratch + wl.bg);
+	float* rows = reinterpret_cast<float*>(scratch + wl.rows);
 
-	// scratch layout = [acc rows P x 12 floats][bg 4 floats].  The background is re-staged here because
-	// the reference reads the backward's own `background` argument (backward.cu:584-587), which the
-	// forward never dereferences.
-	float* bg_dev = reinterpret_cast<float*>(scratch + align_up(sizeof(float) * GSR_ACC_STRIDE * (size_t)P));
+	// The background is re-staged here because the reference reads the backward's own `background`
+	// argument (backward.cu:584-587), which the forward never dereferences.
 	Timer tm(prof_next(g_bwd_log), s);
-	HIP_TRY(hipMemsetAsync(acc, 0, sizeof(float) * GSR_ACC_STRIDE * (size_t)P, s));
 	HIP_TRY(stage_floats(bg_dev, background, 3, s));
+	HIP_TRY(hipMemsetAsync(rows, 0, sizeof(float) * GSR_ROW_STRIDE * (size_t)(R > 0 ? R : 1), s));
+	launch_gaussian_scan(P, tiles_touched, goff, bsums, s);
+	STAGE_CHECK("gaussian_scan", debug, s);
 
 	BwdArgs a;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
@@ -386,12 +393,12 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 
 	tm.mark();
 	if (R > 0) {
-		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, final_T, n_contrib, dL_dpix,
-		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, acc, s);
+		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, goff, final_T, n_contrib, dL_dpix,
+		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, s);
 		STAGE_CHECK("composite_bwd", debug, s);
 	}
 	tm.mark();
-	launch_preprocess_bwd(a, cam, recs, acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+	launch_preprocess_bwd(a, cam, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
 	                      dL_dscale, dL_drot, s);
 	STAGE_CHECK("preprocess_bwd", debug, s);
 	tm.mark();
@@ -411,6 +418,23 @@ int gsr_inspect_geometry(const char* geom_buffer, int P, const int* radii, float
 	                   reinterpret_cast<const GsRec*>(geom_buffer + gl.recs), means2D, depths, conic_opacity, rgb,
 	                   clamped, tiles_touched);
 	STAGE_CHECK("inspect_geometry", 0, s);
+	return GSR_OK;
+}
+
+int gsr_inspect_backward_sums(const char* geom_buffer, const char* scratch, int P, int R, const int* radii,
+                               float* sums, void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	if (P <= 0) return GSR_OK;
+	if (!geom_buffer || !scratch || !radii || !sums)
+		return fail(GSR_ERR_ARG, "gsr_inspect_backward_sums: NULL argument", __FILE__, __LINE__);
+	const GeomLayout gl((size_t)P);
+	const BwdLayout wl((size_t)P, (size_t)(R > 0 ? R : 0));
+	launch_inspect_sums(P, radii, reinterpret_cast<const GsRec*>(geom_buffer + gl.recs),
+	                    reinterpret_cast<const uint32_t*>(scratch + wl.goff),
+	                    reinterpret_cast<const float*>(scratch + wl.rows), sums, s);
+	STAGE_CHECK("inspect_backward_sums", 0, s);
 	return GSR_OK;
 }
 

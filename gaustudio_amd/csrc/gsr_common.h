@@ -175,6 +175,55 @@ __device__ __forceinline__ void cov2d_common(const float3 mean, float fx, float 
 	c.cov = m3_mul(A, c.T);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Thread -> pixel mapping of the compositing kernels: 256 threads = 4 wave64 per 16x16 tile, wave w
+// owns the 8x8 pixel block (w&1, w>>1); lane l is pixel (l&7, l>>3) of that block.  Square blocks
+// make the per-wave culling below tightest for the (mostly round) splat footprints.
+// The tile-major per-pixel state (final_T, n_contrib) is indexed by the thread id.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gs_pixel_of_thread(int tid, int& lx, int& ly)
+{
+	const int w = tid >> 6, l = tid & 63;
+	lx = ((w & 1) << 3) + (l & 7);
+	ly = ((w >> 1) << 3) + (l >> 3);
+}
+
+// Conservative wave-level cull.  Returns false only if NO pixel centre (x,y) in the closed box
+// [bx0,bx1] x [by0,by1] can pass the per-pixel test `0 >= power >= pcut`, where
+//   power(d) = ha*dx^2 + nb*dx*dy + hc*dy^2,  d = centre - pixel   (ha,nb,hc,pcut from the record).
+// For a negative-definite form the maximum over the box lies on the edges nearest to the centre
+// (power decreases along every ray from the centre); it is found in closed form per near edge.
+// A slack of 0.05 + 1e-5*|terms| in `power` covers every rounding difference to the per-pixel
+// evaluation, so culling a (wave, Gaussian) pair is exactly equivalent to evaluating its 64 pixels
+// and rejecting each: results stay bit-identical, only work is removed.
+__device__ __forceinline__ bool gs_box_may_touch(const float4 A, const float4 B, float bx0, float by0, float bx1,
+                                                 float by1)
+{
+	const float ha = A.z, nb = A.w, hc = B.x, pcut = B.w;
+	if (!(pcut <= 0.f)) return false;            // opacity < 1/255: no pixel can reach alpha >= 1/255
+	const float X0 = A.x - bx1, X1 = A.x - bx0;  // range of dx over the box
+	const float Y0 = A.y - by1, Y1 = A.y - by0;
+	const float xn = fminf(fmaxf(0.f, X0), X1);  // point of the range nearest to 0
+	const float yn = fminf(fmaxf(0.f, Y0), Y1);
+	if (xn == 0.f && yn == 0.f) return true;     // centre inside the box
+	if (!(ha < 0.f && hc < 0.f && 4.f * ha * hc - nb * nb > 0.f)) return true;   // not negative definite: keep
+	float best = -3.0e38f;
+	float mag = 0.f;
+	if (xn != 0.f) {
+		const float dy = fminf(fmaxf(-0.5f * nb * xn * __builtin_amdgcn_rcpf(hc), Y0), Y1);
+		const float t0 = ha * xn * xn, t1 = (hc * dy + nb * xn) * dy;
+		best = t0 + t1;
+		mag = fabsf(t0) + fabsf(hc * dy * dy) + fabsf(nb * xn * dy);
+	}
+	if (yn != 0.f) {
+		const float dx = fminf(fmaxf(-0.5f * nb * yn * __builtin_amdgcn_rcpf(ha), X0), X1);
+		const float t0 = hc * yn * yn, t1 = (ha * dx + nb * yn) * dx;
+		best = fmaxf(best, t0 + t1);
+		mag = fmaxf(mag, fabsf(t0) + fabsf(ha * dx * dx) + fabsf(nb * yn * dx));
+	}
+	return best >= pcut - (0.05f + 1e-5f * mag);
+}
+
 // 64-lane sum, result valid in every lane (butterfly over DPP-free shuffles; gfx950 wave64).
 __device__ __forceinline__ float wave_sum(float v)
 {

@@ -7,16 +7,17 @@ namespace gsr {
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-// geometry buffer: [GsCam][GsRec x P]            (replaces GeometryState, rasterizer_impl.h:33-48:
+// geometry buffer: [GsCam][GsRec x P][tiles_touched u32 x P]   (replaces GeometryState, rasterizer_impl.h:33-48:
 // depths/clamped/radii/means2D/cov3D/conic_opacity/rgb/point_offsets/tiles_touched/scan space = 79 B/Gaussian
 // in 9 arrays; here one 64-B record, cov3D is recomputed in backward instead of stored)
 struct GeomLayout {
-	size_t cam, recs, total;
+	size_t cam, recs, tiles_touched, total;
 	explicit GeomLayout(size_t P)
 	{
 		cam = 0;
 		recs = align_up(sizeof(GsCam));
-		total = recs + align_up(sizeof(GsRec) * P);
+		tiles_touched = recs + align_up(sizeof(GsRec) * P);          // compact u32[P] (0 for culled), for the backward's scan
+		total = tiles_touched + align_up(sizeof(uint32_t) * P);
 	}
 };
 
@@ -70,7 +71,7 @@ struct FwdArgs {
 // --- launchers (gsr_kernels_fwd.hip) ---
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
 void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs,
-                           uint32_t* tile_count, GsCtl* ctl, hipStream_t s);
+                           uint32_t* tiles_touched, uint32_t* tile_count, GsCtl* ctl, hipStream_t s);
 void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, GsCtl* ctl, hipStream_t s);
 void launch_bin_scatter(int P, int gx, const int* radii, const GsRec* recs, const uint2* ranges,
                         uint32_t* cursor, uint64_t* keys, hipStream_t s);
@@ -93,15 +94,38 @@ struct BwdArgs {
 	float tan_fovx, tan_fovy;
 	const int* radii;
 };
-// per-Gaussian accumulator row of composite_bwd: 12 floats (48 B)
-//   0,1 dL_dmean2D.xy | 2,3,4 dL_dconic a,b,c | 5 dL_dopacity | 6,7,8 dL_dcolor | 9 dL_ddepth | 10,11 unused
-#define GSR_ACC_STRIDE 12
+// Backward data flow (no global atomics): composite_bwd leaves ONE 48-B row of partial sums per
+// (tile, Gaussian) instance, stored in GAUSSIAN-MAJOR order: row index = goff[g] + k, where goff is
+// the exclusive scan of tiles_touched over Gaussians and k the raster index of the tile inside the
+// Gaussian's tile rect.  preprocess_bwd then adds the rows of each Gaussian in ascending k -- a
+// contiguous read and a fixed summation order.
+//   row: 0,1 dL_dmean2D.xy | 2,3,4 dL_dconic a,b,c | 5 dL_dopacity | 6,7,8 dL_dcolor | 9 dL_ddepth | 10,11 unused
+#define GSR_ROW_STRIDE 12
+// scratch: [goff u32 x (P+1)][block sums u32 x (nb+1)][bg f32 x 4][rows f32 x R*12]
+#define GSR_SCAN_BLOCK 2048
+struct BwdLayout {
+	size_t goff, bsums, bg, rows, total;
+	size_t nb;
+	BwdLayout(size_t P, size_t R)
+	{
+		nb = (P + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
+		goff = 0;
+		bsums = align_up(sizeof(uint32_t) * (P + 1));
+		bg = bsums + align_up(sizeof(uint32_t) * (nb + 1));
+		rows = bg + 256;
+		total = rows + align_up(sizeof(float) * GSR_ROW_STRIDE * (R > 0 ? R : 1));
+	}
+};
+void launch_gaussian_scan(int P, const uint32_t* tiles_touched, uint32_t* goff, uint32_t* bsums, hipStream_t s);
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
-                          const uint32_t* point_list, const GsRec* recs, const float* final_T,
+                          const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* acc, hipStream_t s);
-void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const float* acc,
-                           float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
+                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, hipStream_t s);
+void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
+                           const float* rows, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                           float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                           hipStream_t s);
+void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint32_t* goff, const float* rows,
+                         float* sums10, hipStream_t s);
 
 }  // namespace gsr

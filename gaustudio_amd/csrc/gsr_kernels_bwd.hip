@@ -2,7 +2,8 @@
 //
 //   composite_bwd    one workgroup per tile, back-to-front; per (wave, instance) the ten gradient
 //                    components are reduced over the 64 lanes with a 6-step DPP network and issued as
-//                    ONE atomic per component from lane 63 into a packed 48-B accumulator row
+//                    ONE LDS atomic per component; the four waves of a tile meet in LDS and each
+//                    (tile, Gaussian) instance leaves one plain-stored 48-B row -- no global atomics
 //                    (replaces backward.cu:415-610 renderCUDA: 11-12 atomicAdd per (pixel, Gaussian))
 //   preprocess_bwd   one lane per Gaussian: dL/dconic -> dL/dcov3D, dL/dmean (3 paths), SH backward,
 //                    cov3D -> scale / raw-quaternion backward, fused in one pass
@@ -19,40 +20,190 @@ __device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
                                             0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                             -0.5900435899266435f};
 
-// 64-lane sum through DPP; the total is valid in lane 63 only.
-//   quad_perm xor1, xor2 -> row_half_mirror -> row_mirror (row sums in every lane of the row)
-//   -> row_bcast:15 into rows 1,3 -> row_bcast:31 into rows 2,3.
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+// Cross-lane reduction of the per-pixel gradient contributions of one (wave, Gaussian) pair.
+// Every VALU instruction of a wave64 costs 4 cycles on gfx950, so the reduction is built to need as
+// few instructions as possible:
+//   row_sum16   4 fused v_add_f32_dpp: sum over each 16-lane row, valid in every lane of the row;
+//   rows4_sum   takes the row sums of FOUR different quantities and returns, in the lanes of row r,
+//               the 64-lane total of quantity r -- 3 lane-swap instructions (v_permlane16_swap x2,
+//               v_permlane32_swap) + 3 adds instead of 4 x 2 masked row_bcast steps.
+// One lane per row then issues ONE ds_add_f32 for four quantities at once.
+__device__ __forceinline__ float row_sum16(float v)
 {
 	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
 	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
 	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
 	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1,3
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2,3
 	return v;
 }
+__device__ __forceinline__ float rows4_sum(float a, float b, float c, float d)
+{
+	// permlane16_swap(X, Y): X.row1 <-> Y.row0, X.row3 <-> Y.row2
+	const auto ab = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+	const float x = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);   // rows: a0+a1, b0+b1, a2+a3, b2+b3
+	const auto cd = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+	const float y = __uint_as_float(cd[0]) + __uint_as_float(cd[1]);   // rows: c0+c1, d0+d1, c2+c3, d2+d3
+	// permlane32_swap(X, Y): X.rows23 <-> Y.rows01
+	const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+	return __uint_as_float(xy[0]) + __uint_as_float(xy[1]);            // rows: sum a, sum b, sum c, sum d
+}
+
+// Sum of the per-instance rows of Gaussian idx in ascending tile order (fixed order: the result does
+// not depend on scheduling).  Used by preprocess_bwd and by the test-only inspection kernel.
+__device__ __forceinline__ void gs_sum_rows(bool vis, int idx, const GsRec* __restrict__ recs,
+                                            const uint32_t* __restrict__ goff, const float* __restrict__ rows,
+                                            float* a_)
+{
+#pragma unroll
+	for (int i = 0; i < GSR_ROW_STRIDE; i++) a_[i] = 0.f;
+	if (!vis) return;
+	const uint32_t b = goff[idx], e = goff[idx + 1];
+	for (uint32_t r = b; r < e; r++) {
+		const float4* ar = reinterpret_cast<const float4*>(rows + (size_t)r * GSR_ROW_STRIDE);
+		const float4 v0 = ar[0], v1 = ar[1], v2 = ar[2];
+		a_[0] += v0.x; a_[1] += v0.y; a_[2] += v0.z; a_[3] += v0.w; a_[4] += v1.x; a_[5] += v1.y;
+		a_[6] += v1.z; a_[7] += v1.w; a_[8] += v2.x; a_[9] += v2.y;
+	}
+}
+
+// ---- exclusive scan of tiles_touched over Gaussians -> goff[P+1] (goff[P] = R) ----
+// pass 1: block totals; pass 2: one workgroup scans the totals; pass 3: block-local scan + offset.
+__global__ __launch_bounds__(256) void gscan_block_sums_kernel(int P, const uint32_t* __restrict__ v,
+                                                              uint32_t* __restrict__ bsums)
+{
+	__shared__ uint32_t s_w[4];
+	const int base = blockIdx.x * GSR_SCAN_BLOCK;
+	uint32_t sum = 0;
+	for (int i = threadIdx.x; i < GSR_SCAN_BLOCK; i += 256) {
+		const int g = base + i;
+		if (g < P) sum += v[g];
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) bsums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(1024) void gscan_top_kernel(int nb, uint32_t* __restrict__ bsums)
+{
+	__shared__ uint32_t s_wave[16];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int chunk = (nb + 1023) / 1024;
+	const int b = tid * chunk, e = min(nb, b + chunk);
+	uint32_t sum = 0;
+	for (int i = b; i < e; i++) sum += bsums[i];
+	uint32_t incl = sum;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+		if (lane >= o) incl += t;
+	}
+	if (lane == 63) s_wave[wv] = incl;
+	__syncthreads();
+	uint32_t basev = 0, total = 0;
+	for (int w = 0; w < 16; w++) {
+		if (w < wv) basev += s_wave[w];
+		total += s_wave[w];
+	}
+	uint32_t run = basev + incl - sum;
+	for (int i = b; i < e; i++) {
+		const uint32_t c = bsums[i];
+		bsums[i] = run;
+		run += c;
+	}
+	if (tid == 0) bsums[nb] = total;
+}
+
+__global__ __launch_bounds__(256) void gscan_apply_kernel(int P, const uint32_t* __restrict__ v,
+                                                          const uint32_t* __restrict__ bsums,
+                                                          uint32_t* __restrict__ goff)
+{
+	// each thread owns 8 consecutive elements of the 2048-element block
+	__shared__ uint32_t s_w[4];
+	const int base = blockIdx.x * GSR_SCAN_BLOCK + threadIdx.x * 8;
+	uint32_t x[8];
+	uint32_t sum = 0;
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		x[i] = (base + i < P) ? v[base + i] : 0u;
+		sum += x[i];
+	}
+	uint32_t incl = sum;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+		if (lane >= o) incl += t;
+	}
+	if (lane == 63) s_w[wv] = incl;
+	__syncthreads();
+	uint32_t run = bsums[blockIdx.x] + incl - sum;
+	for (int w = 0; w < wv; w++) run += s_w[w];
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		if (base + i < P) goff[base + i] = run;
+		run += x[i];
+	}
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) goff[P] = bsums[gridDim.x];
+}
+
+void launch_gaussian_scan(int P, const uint32_t* tiles_touched, uint32_t* goff, uint32_t* bsums, hipStream_t s)
+{
+	const int nb = (P + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
+	hipLaunchKernelGGL(gscan_block_sums_kernel, dim3(nb), dim3(256), 0, s, P, tiles_touched, bsums);
+	hipLaunchKernelGGL(gscan_top_kernel, dim3(1), dim3(1024), 0, s, nb, bsums);
+	hipLaunchKernelGGL(gscan_apply_kernel, dim3(nb), dim3(256), 0, s, P, tiles_touched, bsums, goff);
+}
+
+__global__ __launch_bounds__(256) void inspect_sums_kernel(int P, const int* __restrict__ radii,
+                                                           const GsRec* __restrict__ recs,
+                                                           const uint32_t* __restrict__ goff,
+                                                           const float* __restrict__ rows, float* __restrict__ out)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	float a_[GSR_ROW_STRIDE];
+	gs_sum_rows(radii[idx] > 0, idx, recs, goff, rows, a_);
+#pragma unroll
+	for (int i = 0; i < 10; i++) out[10 * (size_t)idx + i] = a_[i];
+}
+
+void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint32_t* goff, const float* rows,
+                         float* sums10, hipStream_t s)
+{
+	hipLaunchKernelGGL(inspect_sums_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, recs, goff, rows, sums10);
+}
+
+#define GSR_SG_STRIDE 11
 
 __global__ __launch_bounds__(256) void composite_bwd_kernel(
     int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
-    const float* __restrict__ dL_dpix_opacity, float* __restrict__ acc)
+    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows)
 {
 	__shared__ float4 sA[256];
 	__shared__ float4 sB[256];
 	__shared__ float4 sC[256];
+	// per-instance partial sums of the staged batch, 10 floats per row, row stride 11 words (odd: the
+	// flush's one-row-per-thread reads are bank-conflict free)
+	__shared__ float sG[256 * GSR_SG_STRIDE];
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int tx = tile % gx, ty = tile / gx;
-	const int px = tx * GSR_BLOCK_X + (tid & 15), py = ty * GSR_BLOCK_Y + (tid >> 4);
+	int lx, ly;
+	gs_pixel_of_thread(tid, lx, ly);
+	const int px = tx * GSR_BLOCK_X + lx, py = ty * GSR_BLOCK_Y + ly;
 	const bool inside = px < W && py < H;
 	const float pixfx = (float)px, pixfy = (float)py;
+	const float bx0 = (float)(tx * GSR_BLOCK_X + (((tid >> 6) & 1) << 3));
+	const float by0 = (float)(ty * GSR_BLOCK_Y + (((tid >> 6) >> 1) << 3));
+	const float bx1 = fminf(bx0 + 7.f, (float)(W - 1)), by1 = fminf(by0 + 7.f, (float)(H - 1));
 	const uint2 range = ranges[tile];
-	const int total = (int)(range.y - range.x);
 
 	const float T_final = inside ? final_T[(size_t)tile * GSR_TILE_PIX + tid] : 0.f;
 	float T_ = T_final;
@@ -75,9 +226,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
 	bg_dot = FMA(bg[2], dLp2, bg_dot);
 	const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
 
-	float acc_r0 = 0.f, acc_r1 = 0.f, acc_r2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-	float accum_depth_rec = 0.f, accum_op_rec = 0.f;
-	float last_alpha = 0.f, last_depth = 0.f, last_op = 0.f;
+	// The reference carries five back-to-front recurrences accum_rec[ch] (3 colours, depth, opacity;
+	// backward.cu:541-573) but dL_dalpha only needs their dot product with this pixel's upstream
+	// gradients, and the recurrence is linear: we carry that one scalar, S = <accum_rec, dL_dpixel>.
+	float S = 0.f, last_cd = 0.f, last_alpha = 0.f;
 
 	// workgroup-wide max of last_contributor: list entries at or beyond it are dead for every pixel
 	int wmax = last_contributor;
@@ -91,6 +243,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
 	// walk positions pos = bmax-1 ... 0, staged 256 at a time
 	for (int top = bmax; top > 0; top -= 256) {
 		const int cnt = min(256, top);
+		uint32_t my_row = 0;
 		__syncthreads();
 		if (tid < cnt) {
 			const uint32_t id = point_list[range.x + (top - 1 - tid)];
@@ -100,11 +253,25 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
 			float4 c = r->q2;
 			c.w = __int_as_float((int)id);
 			sC[tid] = c;
+			// Gaussian-major row of this (tile, Gaussian) instance: goff[g] + raster index of the tile
+			// inside the Gaussian's tile rect (same 64-B record, no extra sector)
+			const uint4 q3 = r->q3;
+			const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
+			my_row = goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx));
 		}
+#pragma unroll
+		for (int k = 0; k < 10; k++) sG[tid * GSR_SG_STRIDE + k] = 0.f;
 		__syncthreads();
-		// entries of this batch that are dead for the whole wave
-		const int jstart = max(0, top - wmax);
-		for (int j = jstart; j < cnt; j++) {
+		// per-wave cull of the staged batch, 64 instances per ballot (see composite_fwd); entries at or
+		// beyond the wave's largest n_contrib are dead for every pixel of the wave
+		for (int sub = 0; sub < cnt; sub += 64) {
+		const int jl = sub + lane;
+		bool hit = false;
+		if (jl < cnt && top - 1 - jl < wmax) hit = gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
+		unsigned long long m = __ballot(hit);
+		while (m) {
+			const int j = sub + __ffsll((long long)m) - 1;
+			m &= m - 1;
 			const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
 			const float4 A = sA[j];
 			const float4 B = sB[j];
@@ -121,68 +288,83 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
 			float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f, g9 = 0.f;
 			const float4 Cc = sC[j];
 			if (live) {
-				const float test_T = T_ / (1.f - alpha);
-				const float w = alpha * test_T;
-				const float one_m_la = 1.f - last_alpha;
-				float dL_dalpha = 0.0f;
-				acc_r0 = FMA(last_alpha, lc0, one_m_la * acc_r0); lc0 = Cc.x;
-				dL_dalpha = FMA(Cc.x - acc_r0, dLp0, dL_dalpha);
+				// 1/(1-alpha) once, by v_rcp_f32 (1 ulp) instead of two IEEE divisions (backward.cu:536,587): the
+				// backward is tolerance-checked (its sums are order-dependent in the reference as well)
+				const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
+				const float test_T = T_ * rinv;
+				const float w = alpha * test_T;   // dchannel_dcolor = dpixel_depth_ddepth = dpixel_opacity_dopacity
+				// <colour of this Gaussian, dL_dpixel> over the 5 blended channels (rgb, depth, opacity == 1)
+				const float cd = FMA(Cc.x, dLp0, FMA(Cc.y, dLp1, FMA(Cc.z, dLp2, FMA(B.z, dLd, dLo))));
+				S = FMA(last_alpha, last_cd - S, S);
+				last_cd = cd;
+				float dL_dalpha = (cd - S) * test_T;
 				g6 = w * dLp0;
-				acc_r1 = FMA(last_alpha, lc1, one_m_la * acc_r1); lc1 = Cc.y;
-				dL_dalpha = FMA(Cc.y - acc_r1, dLp1, dL_dalpha);
 				g7 = w * dLp1;
-				acc_r2 = FMA(last_alpha, lc2, one_m_la * acc_r2); lc2 = Cc.z;
-				dL_dalpha = FMA(Cc.z - acc_r2, dLp2, dL_dalpha);
 				g8 = w * dLp2;
-				const float c_d = B.z;
-				accum_depth_rec = FMA(last_alpha, last_depth, one_m_la * accum_depth_rec);
-				last_depth = c_d;
-				dL_dalpha = FMA(c_d - accum_depth_rec, dLd, dL_dalpha);
 				g9 = w * dLd;
 				if (test_T > 0.5f && T_ < 0.5f) g9 += dLm;   // median-depth gradient (backward.cu:566-569)
-				accum_op_rec = FMA(last_alpha, last_op, one_m_la * accum_op_rec);
-				last_op = 1.f;
-				dL_dalpha = FMA(1.f - accum_op_rec, dLo, dL_dalpha);
-				g5 = w * dLo;   // extra opacity term (backward.cu:575)
-				dL_dalpha *= test_T;
+				g5 = w * dLo;                                // extra opacity term (backward.cu:575)
 				T_ = test_T;
 				last_alpha = alpha;
-				if (bg_dot != 0.f) dL_dalpha = FMA(-T_final / (1.f - alpha), bg_dot, dL_dalpha);   // exact no-op when bg.dL == 0
-				const float con_a = -2.f * A.z, con_b = -A.w, con_c = -2.f * B.x;
+				if (bg_dot != 0.f) dL_dalpha = FMA(-T_final * rinv, bg_dot, dL_dalpha);   // exact no-op when bg.dL == 0
+				// conic = (-2*A.z, -A.w, -2*B.x):  dG_ddelx = -gdx*a - gdy*b,  dG_ddely = -gdy*c - gdx*b
 				const float dL_dG = B.y * dL_dalpha;
 				const float gdx = G * dx, gdy = G * dy;
-				const float dG_ddelx = FMA(-gdy, con_b, -gdx * con_a);
-				const float dG_ddely = FMA(-gdx, con_b, -gdy * con_c);
+				const float dG_ddelx = FMA(gdy, A.w, 2.f * (A.z * gdx));
+				const float dG_ddely = FMA(gdx, A.w, 2.f * (B.x * gdy));
 				g0 = dL_dG * dG_ddelx * ddelx_dx;
 				g1 = dL_dG * dG_ddely * ddely_dy;
-				g2 = -0.5f * gdx * dx * dL_dG;
-				g3 = -0.5f * gdx * dy * dL_dG;
-				g4 = -0.5f * gdy * dy * dL_dG;
-				g5 += G * dL_dalpha;
+				const float hgx = (-0.5f * dL_dG) * gdx, hgy = (-0.5f * dL_dG) * gdy;
+				g2 = hgx * dx;
+				g3 = hgx * dy;
+				g4 = hgy * dy;
+				g5 = FMA(G, dL_dalpha, g5);
 			}
-			g0 = wave_sum_to_lane63(g0); g1 = wave_sum_to_lane63(g1); g2 = wave_sum_to_lane63(g2);
-			g3 = wave_sum_to_lane63(g3); g4 = wave_sum_to_lane63(g4); g5 = wave_sum_to_lane63(g5);
-			g6 = wave_sum_to_lane63(g6); g7 = wave_sum_to_lane63(g7); g8 = wave_sum_to_lane63(g8);
-			g9 = wave_sum_to_lane63(g9);
-			if (lane == 63) {
-				float* row = acc + (size_t)__float_as_int(Cc.w) * GSR_ACC_STRIDE;
-				atomicAdd(row + 0, g0); atomicAdd(row + 1, g1); atomicAdd(row + 2, g2); atomicAdd(row + 3, g3);
-				atomicAdd(row + 4, g4); atomicAdd(row + 5, g5); atomicAdd(row + 6, g6); atomicAdd(row + 7, g7);
-				atomicAdd(row + 8, g8); atomicAdd(row + 9, g9);
+			g0 = row_sum16(g0); g1 = row_sum16(g1); g2 = row_sum16(g2); g3 = row_sum16(g3); g4 = row_sum16(g4);
+			g5 = row_sum16(g5); g6 = row_sum16(g6); g7 = row_sum16(g7); g8 = row_sum16(g8); g9 = row_sum16(g9);
+			const float t0 = rows4_sum(g0, g1, g2, g3);   // row r holds component r
+			const float t1 = rows4_sum(g4, g5, g6, g7);   // row r holds component 4+r
+			const float t2 = rows4_sum(g8, g9, 0.f, 0.f); // rows 0,1 hold components 8,9
+			if ((lane & 15) == 0) {
+				// LDS float atomics (ds_add_f32), one lane per row = four components per instruction: the four
+				// waves of the tile meet here; global memory sees one row per (tile, instance) in the flush
+				float* row = sG + j * GSR_SG_STRIDE + (lane >> 4);
+				atomicAdd(row, t0);
+				atomicAdd(row + 4, t1);
+				if (lane < 32) atomicAdd(row + 8, t2);
+			}
+		}
+		}
+		// flush: one thread per staged instance stores its 48-B row (plain stores, no global atomics);
+		// rows nobody touched stay at the zero the host memset left
+		__syncthreads();
+		if (tid < cnt) {
+			float v[12];
+			bool any = false;
+#pragma unroll
+			for (int k = 0; k < 10; k++) {
+				v[k] = sG[tid * GSR_SG_STRIDE + k];
+				any = any || v[k] != 0.f;
+			}
+			if (any) {
+				float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row * GSR_ROW_STRIDE);
+				dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+				dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+				dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
 			}
 		}
 	}
 }
 
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
-                          const uint32_t* point_list, const GsRec* recs, const float* final_T,
+                          const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* acc, hipStream_t s)
+                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
 	hipLaunchKernelGGL(composite_bwd_kernel, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, bg, ranges,
-	                   point_list, recs, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
-	                   dL_dpix_opacity, acc);
+	                   point_list, recs, goff, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
+	                   dL_dpix_opacity, rows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -191,7 +373,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
     const float* __restrict__ cov3D_precomp, const GsCam* __restrict__ cam, int W, int H, float tan_fovx,
-    float tan_fovy, float h_x, float h_y, const GsRec* __restrict__ recs, const float* __restrict__ acc,
+    float tan_fovy, float h_x, float h_y, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
+    const float* __restrict__ rows,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
@@ -200,16 +383,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 	if (idx >= P) return;
 	constexpr int NC = (D + 1) * (D + 1);
 	const bool vis = radii[idx] > 0;
-	float a_[GSR_ACC_STRIDE];
-	if (vis) {
-		const float4* ar = reinterpret_cast<const float4*>(acc + (size_t)idx * GSR_ACC_STRIDE);
-		const float4 v0 = ar[0], v1 = ar[1], v2 = ar[2];
-		a_[0] = v0.x; a_[1] = v0.y; a_[2] = v0.z; a_[3] = v0.w; a_[4] = v1.x; a_[5] = v1.y; a_[6] = v1.z;
-		a_[7] = v1.w; a_[8] = v2.x; a_[9] = v2.y; a_[10] = 0.f; a_[11] = 0.f;
-	} else {
-#pragma unroll
-		for (int i = 0; i < GSR_ACC_STRIDE; i++) a_[i] = 0.f;
-	}
+	float a_[GSR_ROW_STRIDE];
+	gs_sum_rows(vis, idx, recs, goff, rows, a_);
 	// user-facing copies of the composite-stage gradients (rasterize_points.cu:209 returns them)
 	dL_dmean2D[3 * (size_t)idx] = a_[0];
 	dL_dmean2D[3 * (size_t)idx + 1] = a_[1];
@@ -441,9 +616,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 	*reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
 }
 
-void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const float* acc,
-                           float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s)
+void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
+                           const float* rows, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                           float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                           hipStream_t s)
 {
 	const float h_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:391-392
 	const float h_x = a.W / (2.0f * a.tan_fovx);
@@ -451,7 +627,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 #define GSR_LAUNCH_PB(DEG)                                                                                         \
 	hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, a.scales, \
 	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
-	                   h_y, recs, acc, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
+	                   h_y, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
 	                   dL_drot)
 	const int D = a.shs ? a.D : 0;
 	switch (D) {

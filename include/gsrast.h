@@ -89,8 +89,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx,
                 int debug,
                 void* stream);
 
-/* Bytes of device scratch gsr_backward needs for P Gaussians. */
-size_t gsr_backward_scratch_bytes(int P);
+/* Bytes of device scratch gsr_backward needs for P Gaussians and R = num_rendered instances
+ * (4 B per Gaussian + 48 B per instance: the per-instance partial-gradient rows that replace the
+ * reference's float atomics, backward.cu:559-607). */
+size_t gsr_backward_scratch_bytes(int P, int R);
 
 /* Replaces Rasterizer::backward (rasterizer.h:61-91; rasterizer_impl.cu:347-452).
  * R = num_rendered returned by the matching gsr_forward; geom/binning/image buffers are the ones its
@@ -142,6 +144,13 @@ int gsr_backward(int P, int D, int M, int R,
 int gsr_inspect_geometry(const char* geom_buffer, int P, const int* radii, float* means2D, float* depths,
                          float* conic_opacity, float* rgb, unsigned char* clamped,
                          uint32_t* tiles_touched, void* stream);
+
+/* After gsr_backward: sums[P,10] = the per-Gaussian totals of the compositing stage that feed the
+ * per-Gaussian stage, in the order {dL_dmean2D.x, .y, dL_dconic a, b, c, dL_dopacity, dL_dcolor r, g, b,
+ * dL_ddepth} (what the reference accumulates with atomicAdd, backward.cu:559-607), recomputed from
+ * the scratch rows with the same fixed summation order gsr_backward used. */
+int gsr_inspect_backward_sums(const char* geom_buffer, const char* scratch, int P, int R, const int* radii,
+                               float* sums, void* stream);
 
 /* point_list[R] (Gaussian ids, tile-major, depth-sorted), ranges[T,2] ([start,end) per tile). */
 int gsr_inspect_binning(const char* binning_buffer, const char* image_buffer, int R, int width, int height,

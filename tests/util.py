@@ -117,7 +117,7 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
                dL_dcolors=torch.full((P, 3), float("nan"), **fo), dL_dmeans3D=torch.full((P, 3), float("nan"), **fo),
                dL_dcov3D=torch.full((P, 6), float("nan"), **fo), dL_dsh=torch.full((P, M, 3), float("nan"), **fo),
                dL_dscales=torch.full((P, 3), float("nan"), **fo), dL_drotations=torch.full((P, 4), float("nan"), **fo))
-    nscratch = L.gsr_backward_scratch_bytes(ctypes.c_int(P))
+    nscratch = L.gsr_backward_scratch_bytes(ctypes.c_int(P), ctypes.c_int(hs["num_rendered"]))
     scratch = torch.full((nscratch,), 0xAB, dtype=torch.uint8, device=dev)   # poison: the library must zero it
     means = sc.means3D.to(dev); shs = g("shs"); col = g("colors_precomp"); scl = g("scales"); rot = g("rotations")
     cov = g("cov3D_precomp")
@@ -133,7 +133,11 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
                         ctypes.c_int(bool(debug)), _C._stream(dev))
     if rc < 0:
         raise _C._err(L, rc)
+    acc = torch.empty((P, 10), **fo)
+    rc = L.gsr_inspect_backward_sums(p(hs["geom"]), p(scratch), ctypes.c_int(P), ctypes.c_int(hs["num_rendered"]),
+                                     p(hs["radii"]), p(acc), _C._stream(dev))
+    if rc < 0:
+        raise _C._err(L, rc)
     torch.cuda.synchronize()
-    acc = scratch[:P * 48].view(torch.float32).view(P, 12)[:, :10].clone()
     out["acc"] = acc
     return out
