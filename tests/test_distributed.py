@@ -1,0 +1,95 @@
+"""CPU (-m "not gpu"): the N > 1 path -- one camera per rank, replicated Gaussians, ONE flat all-reduce of the
+per-Gaussian gradients (gaustudio_amd/parallel.py) -- with the gloo backend and world_size 2.
+Per-view gradients come from the CPU oracle here (there is no GPU); on the MI355X node the same code runs
+over RCCL with gradients from the HIP kernels (bench.py --gpus N).  The invariant checked is the one the
+north star states: all-reduced gradients == gradients accumulated over the views on one device."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gaustudio_amd import parallel, scenes
+
+KEYS = ("means3D", "shs", "opacities", "scales", "rotations")
+ORC = dict(means3D="dL_dmeans3D", shs="dL_dsh", opacities="dL_dopacity", scales="dL_dscales", rotations="dL_drotations")
+
+
+def _view_grads(sc, cam):
+    from oracle import pyoracle as po
+    st = po.forward(sc.means3D.numpy(), sc.opacities.numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
+                    cam.campos.numpy(), cam.width, cam.height, cam.tanfovx, cam.tanfovy, sh_degree=3,
+                    shs=sc.shs.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy())
+    g = scenes.make_output_grads(cam, seed=5)
+    bw = po.backward(st, *[t.numpy() for t in g], want_abs=False)
+    return {k: torch.from_numpy(bw[ORC[k]].reshape(getattr(sc, k).shape).copy()) for k in KEYS}
+
+
+def _scene_and_cams(n):
+    sc = scenes.make_ball_scene(1500, radius=3.0, seed=4, sigma=0.06)
+    return sc, scenes.ring_cameras(n, 96, 64, radius=8.0)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc, cams = _scene_and_cams(world)
+        params = [getattr(sc, k).clone().requires_grad_(True) for k in KEYS]
+        bucket = parallel.FlatGradBucket(params)
+        mine = parallel.shard_views(cams)
+        assert len(mine) == 1
+
+        def render(cam):
+            for p, k in zip(params, KEYS):
+                gk = _view_grads(sc, cam)[k]
+                p.grad = gk if p.grad is None else p.grad + gk
+
+        parallel.render_views_and_reduce(render, mine, bucket)
+        assert bucket.nbytes == sum(p.numel() for p in params) * 4 == 1500 * 59 * 4
+        for p, v in zip(params, bucket.views()):
+            assert p.grad.data_ptr() == v.data_ptr()          # grads live in the flat buffer after the reduce
+        torch.save([p.grad.clone() for p in params], os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_allreduced_grads_equal_single_device_accumulation(tmp_path, oracle):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sc, cams = _scene_and_cams(world)
+    per_view = [_view_grads(sc, c) for c in cams]
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for i, k in enumerate(KEYS):
+        want = per_view[0][k] + per_view[1][k]                # accumulating both views on one device
+        assert torch.equal(r0[i], r1[i]), k                   # every rank holds the same reduced gradient
+        assert torch.allclose(r0[i], want, rtol=0, atol=1e-6 * float(want.abs().max())), k
+        assert float(want.abs().max()) > 0
+
+
+def test_bucket_roundtrip_and_view_sharding_without_process_group():
+    ps = [torch.randn(5, 3, requires_grad=True), torch.randn(5, 16, 3, requires_grad=True), torch.randn(5, 1, requires_grad=True)]
+    b = parallel.FlatGradBucket(ps)
+    ps[0].grad = torch.ones(5, 3)
+    ps[2].grad = torch.full((5, 1), 2.0)
+    assert parallel.allreduce_gaussian_grads(b) is None        # world_size 1: packing only, no collective
+    assert b.flat.numel() == 15 + 240 + 5
+    assert float(b.flat[:15].sum()) == 15.0 and float(b.flat[15:255].abs().sum()) == 0.0 and float(b.flat[255:].sum()) == 10.0
+    assert ps[1].grad is not None and float(ps[1].grad.abs().sum()) == 0.0
+    assert parallel.shard_views(list(range(8)), rank=3, world_size=8) == [3]
+    assert parallel.shard_views(list(range(8)), rank=1, world_size=4) == [1, 5]
+    with pytest.raises(ValueError):
+        parallel.FlatGradBucket([])
