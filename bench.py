@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="time the no_grad forward only (inference paths)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None,
-                    help="measured HBM bytes per composite_fwd launch from a rocprofv3 --pmc pass (profiles/)")
+                    help="measured HBM bytes per composite_fwd launch from a rocprofv3 --pmc pass; default: the "
+                         "committed measurement in profiles/r*_traffic.json for this workload, else null")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,11 +179,19 @@ def main():
         value = world * H * W / (dt / a.steps) / 1e6
         comp_ms = fwd_ms["composite"] if fwd_ms else None
         alg_bytes = R * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8)
+        traffic = a.traffic
+        if traffic is None:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+                t = json.load(open(f))
+                if t.get("workload") == a.workload and "composite_fwd" in t:
+                    traffic = t["composite_fwd"]["traffic_bytes"]      # PMC counters cannot be read in-process
+                    break
         roof = None
         if comp_ms:
             achieved = alg_bytes / (comp_ms * 1e-3) / 1e9
             roof = {"kernel": "composite_fwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": a.traffic,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                     "algorithmic_bytes": alg_bytes, "avg_ms": round(comp_ms, 4),
                     "note": "composite is VALU-bound (256 pixel evaluations per staged 48-B record), see DESIGN.md s5"}
         line = {

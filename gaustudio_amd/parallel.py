@@ -60,11 +60,12 @@ class FlatGradBucket:
 def allreduce_gaussian_grads(bucket: FlatGradBucket, group: Optional[dist.ProcessGroup] = None,
                              async_op: bool = False):
     """SUM-all-reduces the packed gradients across ranks in one collective and re-attaches them.
-    With world_size 1 (or no process group) this is a no-op apart from the packing."""
+    With world_size 1 (or no process group) there is nothing to exchange: gradients stay where autograd
+    put them and nothing is copied."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return None
     bucket.pack()
-    work = None
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     if work is None or not async_op:
         bucket.unpack()
     return work

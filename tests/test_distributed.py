@@ -85,7 +85,10 @@ def test_bucket_roundtrip_and_view_sharding_without_process_group():
     b = parallel.FlatGradBucket(ps)
     ps[0].grad = torch.ones(5, 3)
     ps[2].grad = torch.full((5, 1), 2.0)
-    assert parallel.allreduce_gaussian_grads(b) is None        # world_size 1: packing only, no collective
+    assert parallel.allreduce_gaussian_grads(b) is None        # world_size 1: nothing to exchange, nothing copied
+    assert float(b.flat.abs().sum()) == 0.0 and ps[1].grad is None
+    b.pack()
+    b.unpack()
     assert b.flat.numel() == 15 + 240 + 5
     assert float(b.flat[:15].sum()) == 15.0 and float(b.flat[15:255].abs().sum()) == 0.0 and float(b.flat[255:].sum()) == 10.0
     assert ps[1].grad is not None and float(ps[1].grad.abs().sum()) == 0.0
