@@ -265,7 +265,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	const ImgLayout il(width, height);
 	if (il.gx > 65535 || il.gy > 65535) return fail(GSR_ERR_ARG, "gsr_forward: image too large", __FILE__, __LINE__);
 	char* geom = geometry_alloc(geometry_ctx, gl.total);
-	char* img = image_alloc(image_ctx, il.total);
+	// the per-chunk tile histogram of the atomics-free binning lives behind the image state proper
+	const bool lds_bin = bin_lds_path_ok(il.T);
+	const size_t hm_off = il.total;
+	char* img = image_alloc(image_ctx, il.total + (lds_bin ? align_up(bin_hist_bytes(P, il.T)) : 0));
 	if (!geom || !img) return fail(GSR_ERR_ALLOC, "gsr_forward: allocator returned NULL", __FILE__, __LINE__);
 
 	GsCam* cam = reinterpret_cast<GsCam*>(geom + gl.cam);
@@ -291,9 +294,15 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.prefiltered = prefiltered;
 
 	tm.mark();
-	launch_preprocess_fwd(a, cam, il, radii, recs, reinterpret_cast<uint32_t*>(geom + gl.tiles_touched), tile_count, ctl, s);
+	uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + gl.tiles_touched);
+	uint32_t* Hm = reinterpret_cast<uint32_t*>(img + hm_off);
+	launch_preprocess_fwd(a, cam, il, radii, recs, tiles_touched, lds_bin ? nullptr : tile_count, ctl, s);
 	STAGE_CHECK("preprocess_fwd", debug, s);
 	tm.mark();
+	if (lds_bin) {
+		launch_bin_hist(P, il.gx, il.T, tiles_touched, recs, Hm, tile_count, s);
+		STAGE_CHECK("bin_hist", debug, s);
+	}
 	launch_tile_scan(il.T, tile_count, ranges, ctl, s);
 	STAGE_CHECK("tile_scan", debug, s);
 
@@ -316,7 +325,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 
 	tm.mark();
 	if (R > 0) {
-		launch_bin_scatter(P, il.gx, radii, recs, ranges, tile_count, keys, s);
+		if (lds_bin)
+			launch_bin_scatter2(P, il.gx, il.T, tiles_touched, recs, Hm, ranges, keys, s);
+		else
+			launch_bin_scatter(P, il.gx, radii, recs, ranges, tile_count, keys, s);
 		STAGE_CHECK("bin_scatter", debug, s);
 	}
 	tm.mark();

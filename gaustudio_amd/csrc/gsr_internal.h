@@ -75,6 +75,14 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, GsCtl* ctl, hipStream_t s);
 void launch_bin_scatter(int P, int gx, const int* radii, const GsRec* recs, const uint2* ranges,
                         uint32_t* cursor, uint64_t* keys, hipStream_t s);
+// binning without global atomics (default when the tile grid fits an LDS histogram)
+int bin_chunks(int P);
+size_t bin_hist_bytes(int P, int T);
+bool bin_lds_path_ok(int T);
+void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
+                     uint32_t* tile_count, hipStream_t s);
+void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
+                         const uint2* ranges, uint64_t* keys, hipStream_t s);
 void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                       hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,

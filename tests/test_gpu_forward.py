@@ -155,3 +155,10 @@ def test_forward_is_deterministic():
     b = hip_forward(sc, cam, 3, kw)
     for k in ("color", "depth", "median", "opacity", "radii", "point_list", "final_T", "n_contrib"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("W,H,path", [(3840, 2160, "lds-histogram binning with a 127 KiB histogram (C5 resolution)"),
+                                      (5120, 2880, "fallback: device-atomic binning, tile grid too large for LDS")])
+def test_large_tile_grids_both_binning_paths(oracle, W, H, path):
+    hs, os_ = _run(oracle, 30000, W, H, 1, seed=23, sigma_px=4.0)
+    assert hs["num_rendered"] > 30000
