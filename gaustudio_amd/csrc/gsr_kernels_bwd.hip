@@ -23,10 +23,9 @@ __device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
 // Cross-lane reduction of the per-pixel gradient contributions of one (wave, Gaussian) pair.
 // Every VALU instruction of a wave64 costs 4 cycles on gfx950, so the reduction is built to need as
 // few instructions as possible:
-//   row_sum16   4 fused v_add_f32_dpp: sum over each 16-lane row, valid in every lane of the row;
-//   rows4_sum   takes the row sums of FOUR different quantities and returns, in the lanes of row r,
-//               the 64-lane total of quantity r -- 3 lane-swap instructions (v_permlane16_swap x2,
-//               v_permlane32_swap) + 3 adds instead of 4 x 2 masked row_bcast steps.
+//   row_sum16      4 fused v_add_f32_dpp: sum over each 16-lane row, valid in every lane of the row;
+//   half/row_swap  v_permlane32_swap / v_permlane16_swap + add: fold the two halves / the row pairs of TWO
+//                  quantities into one register (see below).
 // One lane per row then issues ONE ds_add_f32 for four quantities at once.
 __device__ __forceinline__ float row_sum16(float v)
 {
@@ -36,16 +35,22 @@ __device__ __forceinline__ float row_sum16(float v)
 	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
 	return v;
 }
-__device__ __forceinline__ float rows4_sum(float a, float b, float c, float d)
+// half_swap_sum(a, b): lanes 0-31 get a[l] + a[l+32], lanes 32-63 get b[l-32] + b[l]   (1 swap + 1 add for
+// two quantities); row_swap_sum(p, q): rows (0,1,2,3) get p.r0+p.r1, q.r0+q.r1, p.r2+p.r3, q.r2+q.r3.
+// Doing these "transposing" cross-row steps FIRST shrinks ten per-lane quantities to three registers
+// (each 16-lane row carrying a different quantity) before the four within-row DPP steps, so the whole
+// 64-lane reduction of ten quantities costs 8 swaps + 8 adds + 12 DPP adds instead of 60 DPP adds.
+__device__ __forceinline__ float half_swap_sum(float a, float b)
 {
-	// permlane16_swap(X, Y): X.row1 <-> Y.row0, X.row3 <-> Y.row2
-	const auto ab = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-	const float x = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);   // rows: a0+a1, b0+b1, a2+a3, b2+b3
-	const auto cd = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(d), false, false);
-	const float y = __uint_as_float(cd[0]) + __uint_as_float(cd[1]);   // rows: c0+c1, d0+d1, c2+c3, d2+d3
-	// permlane32_swap(X, Y): X.rows23 <-> Y.rows01
-	const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-	return __uint_as_float(xy[0]) + __uint_as_float(xy[1]);            // rows: sum a, sum b, sum c, sum d
+	// v_permlane32_swap(X, Y): X.rows23 <-> Y.rows01
+	const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+	return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float row_swap_sum(float p, float q)
+{
+	// v_permlane16_swap(X, Y): X.row1 <-> Y.row0, X.row3 <-> Y.row2
+	const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+	return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
 // Sum of the per-instance rows of Gaussian idx in ascending tile order (fixed order: the result does
@@ -177,180 +182,229 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 
 #define GSR_SG_STRIDE 11
 
-__global__ __launch_bounds__(256) void composite_bwd_kernel(
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// gs_exp on two values at once (same arithmetic as gs_common.h gs_exp; arguments far below -80 give
+// garbage that callers mask)
+__device__ __forceinline__ v2f gs_exp2(v2f p)
+{
+	const v2f LOG2E = {0x1.715476p+0f, 0x1.715476p+0f};
+	const v2f MAGIC = {12582912.0f, 12582912.0f};
+	const v2f tm = vfma(p, LOG2E, MAGIC);
+	const v2f nf = tm - MAGIC;
+	const v2f f = vfma(p, LOG2E, -nf);
+	v2f y = {0x1.5c08e6p-10f, 0x1.5c08e6p-10f};
+	y = vfma(y, f, v2f{0x1.3d0c52p-7f, 0x1.3d0c52p-7f});
+	y = vfma(y, f, v2f{0x1.c6b6e4p-5f, 0x1.c6b6e4p-5f});
+	y = vfma(y, f, v2f{0x1.ebf918p-3f, 0x1.ebf918p-3f});
+	y = vfma(y, f, v2f{0x1.62e428p-1f, 0x1.62e428p-1f});
+	y = vfma(y, f, v2f{0x1.000002p+0f, 0x1.000002p+0f});
+	const v2i r = __builtin_bit_cast(v2i, y) + (__builtin_bit_cast(v2i, tm) << 23);
+	return __builtin_bit_cast(v2f, r);
+}
+
+// composite_bwd: ONE workgroup of 2 wave64 per 16x16 tile; wave w owns the 8-wide, 16-tall half tile
+// (columns 8w..8w+7) and every lane owns TWO pixels of it, (x, y) and (x, y+8).  The cross-lane reduction
+// of the ten gradient components costs ~85 VALU instructions per (wave, instance) regardless of how many
+// pixels feed it, which was more than the per-pixel math of one pixel per lane; with two pixels per lane it
+// is paid once per 128 pixel evaluations (the culling box grows from 8x8 to 8x16, a smaller loss).
+// Pixel state comes from the forward's tile-major arrays: index = (forward wave)*64 + (forward lane).
+#define GSR_BWD_THREADS 128
+#define GSR_BWD_BATCH 128
+__global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
     int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
     const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows)
 {
-	__shared__ float4 sA[256];
-	__shared__ float4 sB[256];
-	__shared__ float4 sC[256];
+	__shared__ float4 sA[GSR_BWD_BATCH];
+	__shared__ float4 sB[GSR_BWD_BATCH];
+	__shared__ float4 sC[GSR_BWD_BATCH];
 	// per-instance partial sums of the staged batch, 10 floats per row, row stride 11 words (odd: the
 	// flush's one-row-per-thread reads are bank-conflict free)
-	__shared__ float sG[256 * GSR_SG_STRIDE];
+	__shared__ float sG[GSR_BWD_BATCH * GSR_SG_STRIDE];
+	__shared__ int s_max[2];
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
-	const int lane = tid & 63;
+	const int lane = tid & 63, wv = tid >> 6;
 	const int tx = tile % gx, ty = tile / gx;
-	int lx, ly;
-	gs_pixel_of_thread(tid, lx, ly);
-	const int px = tx * GSR_BLOCK_X + lx, py = ty * GSR_BLOCK_Y + ly;
-	const bool inside = px < W && py < H;
-	const float pixfx = (float)px, pixfy = (float)py;
-	const float bx0 = (float)(tx * GSR_BLOCK_X + (((tid >> 6) & 1) << 3));
-	const float by0 = (float)(ty * GSR_BLOCK_Y + (((tid >> 6) >> 1) << 3));
-	const float bx1 = fminf(bx0 + 7.f, (float)(W - 1)), by1 = fminf(by0 + 7.f, (float)(H - 1));
+	const int px = tx * GSR_BLOCK_X + (wv << 3) + (lane & 7);
+	const int pyk[2] = {ty * GSR_BLOCK_Y + (lane >> 3), ty * GSR_BLOCK_Y + (lane >> 3) + 8};
+	const float pixfx = (float)px;
+	const v2f pixfy = {(float)pyk[0], (float)pyk[1]};
+	const float bx0 = (float)(tx * GSR_BLOCK_X + (wv << 3)), by0 = (float)(ty * GSR_BLOCK_Y);
+	const float bx1 = fminf(bx0 + 7.f, (float)(W - 1)), by1 = fminf(by0 + 15.f, (float)(H - 1));
 	const uint2 range = ranges[tile];
 
-	const float T_final = inside ? final_T[(size_t)tile * GSR_TILE_PIX + tid] : 0.f;
-	float T_ = T_final;
-	const int last_contributor = inside ? (int)n_contrib[(size_t)tile * GSR_TILE_PIX + tid] : 0;
-	float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLm = 0.f, dLo = 0.f;
-	if (inside) {
-		const size_t HW = (size_t)H * W;
-		const size_t pix_id = (size_t)W * py + px;
-		dLp0 = dL_dpix[pix_id];
-		dLp1 = dL_dpix[HW + pix_id];
-		dLp2 = dL_dpix[2 * HW + pix_id];
-		dLd = dL_dpix_depth[pix_id];
-		dLm = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
-		dLo = dL_dpix_opacity[pix_id];
+	v2f T_final, T_, dLp0, dLp1, dLp2, dLd, dLm, dLo, bg_dot;
+	v2i last_contributor;
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const bool inside = px < W && pyk[k] < H;
+		const size_t sidx = (size_t)tile * GSR_TILE_PIX + (size_t)((2 * k + wv) * 64 + lane);   // forward's thread id
+		T_final[k] = inside ? final_T[sidx] : 0.f;
+		last_contributor[k] = inside ? (int)n_contrib[sidx] : 0;
+		dLp0[k] = dLp1[k] = dLp2[k] = dLd[k] = dLm[k] = dLo[k] = 0.f;
+		if (inside) {
+			const size_t HW = (size_t)H * W;
+			const size_t pix_id = (size_t)W * pyk[k] + px;
+			dLp0[k] = dL_dpix[pix_id];
+			dLp1[k] = dL_dpix[HW + pix_id];
+			dLp2[k] = dL_dpix[2 * HW + pix_id];
+			dLd[k] = dL_dpix_depth[pix_id];
+			dLm[k] = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
+			dLo[k] = dL_dpix_opacity[pix_id];
+		}
+		// bg . dL_dpixel (backward.cu:584-586), loop invariant
+		bg_dot[k] = FMA(bg[2], dLp2[k], FMA(bg[1], dLp1[k], FMA(bg[0], dLp0[k], 0.f)));
 	}
-	// bg . dL_dpixel (backward.cu:584-586), loop invariant
-	float bg_dot = 0.f;
-	bg_dot = FMA(bg[0], dLp0, bg_dot);
-	bg_dot = FMA(bg[1], dLp1, bg_dot);
-	bg_dot = FMA(bg[2], dLp2, bg_dot);
-	const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
+	T_ = T_final;
+	const bool any_bg = bg_dot.x != 0.f || bg_dot.y != 0.f;
 
 	// The reference carries five back-to-front recurrences accum_rec[ch] (3 colours, depth, opacity;
 	// backward.cu:541-573) but dL_dalpha only needs their dot product with this pixel's upstream
 	// gradients, and the recurrence is linear: we carry that one scalar, S = <accum_rec, dL_dpixel>.
-	float S = 0.f, last_cd = 0.f, last_alpha = 0.f;
+	v2f S = {0.f, 0.f}, last_cd = {0.f, 0.f}, last_alpha = {0.f, 0.f};
 
-	// workgroup-wide max of last_contributor: list entries at or beyond it are dead for every pixel
-	int wmax = last_contributor;
+	// wave / workgroup max of last_contributor: list entries at or beyond it are dead for every pixel
+	int wmax = max(last_contributor.x, last_contributor.y);
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
-	__shared__ int s_max[4];
-	if (lane == 0) s_max[tid >> 6] = wmax;
+	if (lane == 0) s_max[wv] = wmax;
 	__syncthreads();
-	const int bmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+	const int bmax = max(s_max[0], s_max[1]);
 
-	// walk positions pos = bmax-1 ... 0, staged 256 at a time
-	for (int top = bmax; top > 0; top -= 256) {
-		const int cnt = min(256, top);
-		uint32_t my_row = 0;
+	// walk positions pos = bmax-1 ... 0, staged GSR_BWD_BATCH at a time (one instance per thread: a small
+	// batch keeps the workgroup at 12 KiB of LDS so that 13 of them -- 26 waves -- fit a CU)
+	for (int top = bmax; top > 0; top -= GSR_BWD_BATCH) {
+		const int cnt = min(GSR_BWD_BATCH, top);
+		uint32_t my_row[GSR_BWD_BATCH / GSR_BWD_THREADS] = {0u};
 		__syncthreads();
-		if (tid < cnt) {
-			const uint32_t id = point_list[range.x + (top - 1 - tid)];
-			const GsRec* r = recs + id;
-			sA[tid] = r->q0;
-			sB[tid] = r->q1;
-			float4 c = r->q2;
-			c.w = __int_as_float((int)id);
-			sC[tid] = c;
-			// Gaussian-major row of this (tile, Gaussian) instance: goff[g] + raster index of the tile
-			// inside the Gaussian's tile rect (same 64-B record, no extra sector)
-			const uint4 q3 = r->q3;
-			const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
-			my_row = goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx));
-		}
 #pragma unroll
-		for (int k = 0; k < 10; k++) sG[tid * GSR_SG_STRIDE + k] = 0.f;
-		__syncthreads();
-		// per-wave cull of the staged batch, 64 instances per ballot (see composite_fwd); entries at or
-		// beyond the wave's largest n_contrib are dead for every pixel of the wave
-		for (int sub = 0; sub < cnt; sub += 64) {
-		const int jl = sub + lane;
-		bool hit = false;
-		if (jl < cnt && top - 1 - jl < wmax) hit = gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
-		unsigned long long m = __ballot(hit);
-		while (m) {
-			const int j = sub + __ffsll((long long)m) - 1;
-			m &= m - 1;
-			const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
-			const float4 A = sA[j];
-			const float4 B = sB[j];
-			const float dx = A.x - pixfx, dy = A.y - pixfy;
-			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
-			bool live = pos < last_contributor && !(power > 0.0f || power < B.w);
-			float G = 0.f, alpha = 0.f;
-			if (live) {
-				G = gs_exp(power);
-				alpha = fminf(0.99f, B.y * G);
-				live = !(alpha < 1.0f / 255.0f);
+		for (int h = 0; h < GSR_BWD_BATCH / GSR_BWD_THREADS; h++) {
+			const int st = tid + h * GSR_BWD_THREADS;
+			if (st < cnt) {
+				const uint32_t id = point_list[range.x + (top - 1 - st)];
+				const GsRec* r = recs + id;
+				sA[st] = r->q0;
+				sB[st] = r->q1;
+				float4 c = r->q2;
+				c.w = __int_as_float((int)id);
+				sC[st] = c;
+				// Gaussian-major row of this (tile, Gaussian) instance: goff[g] + raster index of the tile
+				// inside the Gaussian's tile rect (same 64-B record, no extra sector)
+				const uint4 q3 = r->q3;
+				const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
+				my_row[h] = goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx));
 			}
-			if (__ballot(live) == 0ull) continue;
-			float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f, g9 = 0.f;
-			const float4 Cc = sC[j];
-			if (live) {
+#pragma unroll
+			for (int k = 0; k < 10; k++) sG[st * GSR_SG_STRIDE + k] = 0.f;
+		}
+		__syncthreads();
+		// per-wave cull of the staged batch, 64 instances per ballot (see composite_fwd)
+		for (int sub = 0; sub < cnt; sub += 64) {
+			const int jl = sub + lane;
+			bool hit = false;
+			if (jl < cnt && top - 1 - jl < wmax) hit = gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
+			unsigned long long m = __ballot(hit);
+			while (m) {
+				const int j = sub + __ffsll((long long)m) - 1;
+				m &= m - 1;
+				const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
+				const float4 A = sA[j];
+				const float4 B = sB[j];
+				const float4 Cc = sC[j];
+				// Both pixels of the lane are evaluated together as 2-vectors so that the arithmetic maps onto
+				// packed FP32 instructions (v_pk_fma/mul/add_f32: two results per 4-cycle VALU slot), and the
+				// body is straight-line: dead pixels are masked by zeroing their weights (w, qa), not by
+				// branching -- in a hit block about half of the pixels are live, a branch would never be skipped.
+				const float dx = A.x - pixfx;
+				const v2f dy = v2f{A.y, A.y} - pixfy;
+				const float ax = (A.z * dx) * dx, bxd = A.w * dx;
+				const v2f power = vfma(v2f{bxd, bxd}, dy, vfma(B.x * dy, dy, v2f{ax, ax}));
+				const v2f G = gs_exp2(power);
+				const v2f alpha = v2f{fminf(0.99f, B.y * G.x), fminf(0.99f, B.y * G.y)};
+				const v2i live = (v2i{pos, pos} < last_contributor) & (power <= 0.0f) & (power >= B.w) &
+				                 ~(alpha < (1.0f / 255.0f));
+				if (__ballot((live.x | live.y) != 0) == 0ull) continue;
 				// 1/(1-alpha) once, by v_rcp_f32 (1 ulp) instead of two IEEE divisions (backward.cu:536,587): the
 				// backward is tolerance-checked (its sums are order-dependent in the reference as well)
-				const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
-				const float test_T = T_ * rinv;
-				const float w = alpha * test_T;   // dchannel_dcolor = dpixel_depth_ddepth = dpixel_opacity_dopacity
+				const v2f om = 1.f - alpha;
+				const v2f rinv = v2f{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+				const v2f test_T = T_ * rinv;
+				const v2f w = live ? alpha * test_T : v2f{0.f, 0.f};   // dchannel_dcolor = dpixel_depth_ddepth = ...
 				// <colour of this Gaussian, dL_dpixel> over the 5 blended channels (rgb, depth, opacity == 1)
-				const float cd = FMA(Cc.x, dLp0, FMA(Cc.y, dLp1, FMA(Cc.z, dLp2, FMA(B.z, dLd, dLo))));
-				S = FMA(last_alpha, last_cd - S, S);
-				last_cd = cd;
-				float dL_dalpha = (cd - S) * test_T;
-				g6 = w * dLp0;
-				g7 = w * dLp1;
-				g8 = w * dLp2;
-				g9 = w * dLd;
-				if (test_T > 0.5f && T_ < 0.5f) g9 += dLm;   // median-depth gradient (backward.cu:566-569)
-				g5 = w * dLo;                                // extra opacity term (backward.cu:575)
-				T_ = test_T;
-				last_alpha = alpha;
-				if (bg_dot != 0.f) dL_dalpha = FMA(-T_final * rinv, bg_dot, dL_dalpha);   // exact no-op when bg.dL == 0
-				// conic = (-2*A.z, -A.w, -2*B.x):  dG_ddelx = -gdx*a - gdy*b,  dG_ddely = -gdy*c - gdx*b
-				const float dL_dG = B.y * dL_dalpha;
-				const float gdx = G * dx, gdy = G * dy;
-				const float dG_ddelx = FMA(gdy, A.w, 2.f * (A.z * gdx));
-				const float dG_ddely = FMA(gdx, A.w, 2.f * (B.x * gdy));
-				g0 = dL_dG * dG_ddelx * ddelx_dx;
-				g1 = dL_dG * dG_ddely * ddely_dy;
-				const float hgx = (-0.5f * dL_dG) * gdx, hgy = (-0.5f * dL_dG) * gdy;
-				g2 = hgx * dx;
-				g3 = hgx * dy;
-				g4 = hgy * dy;
-				g5 = FMA(G, dL_dalpha, g5);
+				const v2f cd = vfma(v2f{Cc.x, Cc.x}, dLp0, vfma(v2f{Cc.y, Cc.y}, dLp1,
+				                    vfma(v2f{Cc.z, Cc.z}, dLp2, vfma(v2f{B.z, B.z}, dLd, dLo))));
+				const v2f Sn = vfma(last_alpha, last_cd - S, S);
+				v2f dL_dalpha = (cd - Sn) * test_T;
+				if (any_bg) dL_dalpha = vfma(-(T_final * rinv), bg_dot, dL_dalpha);   // backward.cu:584-587
+				const v2f qa = live ? G * dL_dalpha : v2f{0.f, 0.f};                  // dL_dG * G / opacity
+				const v2i med = live & (test_T > 0.5f) & (T_ < 0.5f);                 // median-depth gradient (backward.cu:566-569)
+				const v2f g6v = w * dLp0, g7v = w * dLp1, g8v = w * dLp2;
+				const v2f g9v = vfma(w, dLd, med ? dLm : v2f{0.f, 0.f});
+				const v2f g5v = vfma(w, dLo, qa);                                     // backward.cu:575 + :607
+				// moments of qa over the pixels; the conic / opacity factors are applied once per instance in the flush
+				const v2f qx = qa * dx, qy = qa * dy;
+				const v2f m20 = qx * dx, m11 = qx * dy, m02 = qy * dy;
+				S = live ? Sn : S;
+				last_cd = live ? cd : last_cd;
+				T_ = live ? test_T : T_;
+				last_alpha = live ? alpha : last_alpha;
+				// ten per-lane quantities (two pixels each) -> three registers whose 16-lane rows carry different
+				// quantities -> within-row sums.  Row r of s0 / s1 / s2 holds component {0,2,1,3}[r] / 4+{0,2,1,3}[r] /
+				// {8,-,9,-}[r].
+				const float r0 = half_swap_sum(qx.x + qx.y, qy.x + qy.y);      // [M10 | M01]
+				const float r1 = half_swap_sum(m20.x + m20.y, m11.x + m11.y);  // [M20 | M11]
+				const float r2 = half_swap_sum(m02.x + m02.y, g5v.x + g5v.y);  // [M02 | g5 ]
+				const float r3 = half_swap_sum(g6v.x + g6v.y, g7v.x + g7v.y);  // [g6  | g7 ]
+				const float r4 = half_swap_sum(g8v.x + g8v.y, g9v.x + g9v.y);  // [g8  | g9 ]
+				const float s0 = row_sum16(row_swap_sum(r0, r1));
+				const float s1 = row_sum16(row_swap_sum(r2, r3));
+				const float s2 = row_sum16(row_swap_sum(r4, 0.f));
+				if ((lane & 15) == 0) {
+					// LDS float atomics (ds_add_f32), one lane per row = four components per instruction: the two
+					// waves of the tile meet here; global memory sees one row per (tile, instance) in the flush
+					const int row = lane >> 4;
+					float* dst = sG + j * GSR_SG_STRIDE + (((row & 1) << 1) | (row >> 1));
+					atomicAdd(dst, s0);
+					atomicAdd(dst + 4, s1);
+					if ((row & 1) == 0) atomicAdd(dst + 8, s2);
+				}
 			}
-			g0 = row_sum16(g0); g1 = row_sum16(g1); g2 = row_sum16(g2); g3 = row_sum16(g3); g4 = row_sum16(g4);
-			g5 = row_sum16(g5); g6 = row_sum16(g6); g7 = row_sum16(g7); g8 = row_sum16(g8); g9 = row_sum16(g9);
-			const float t0 = rows4_sum(g0, g1, g2, g3);   // row r holds component r
-			const float t1 = rows4_sum(g4, g5, g6, g7);   // row r holds component 4+r
-			const float t2 = rows4_sum(g8, g9, 0.f, 0.f); // rows 0,1 hold components 8,9
-			if ((lane & 15) == 0) {
-				// LDS float atomics (ds_add_f32), one lane per row = four components per instruction: the four
-				// waves of the tile meet here; global memory sees one row per (tile, instance) in the flush
-				float* row = sG + j * GSR_SG_STRIDE + (lane >> 4);
-				atomicAdd(row, t0);
-				atomicAdd(row + 4, t1);
-				if (lane < 32) atomicAdd(row + 8, t2);
-			}
-		}
 		}
 		// flush: one thread per staged instance stores its 48-B row (plain stores, no global atomics);
 		// rows nobody touched stay at the zero the host memset left
 		__syncthreads();
-		if (tid < cnt) {
-			float v[12];
-			bool any = false;
 #pragma unroll
-			for (int k = 0; k < 10; k++) {
-				v[k] = sG[tid * GSR_SG_STRIDE + k];
-				any = any || v[k] != 0.f;
-			}
-			if (any) {
-				float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row * GSR_ROW_STRIDE);
-				dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-				dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-				dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
+		for (int h = 0; h < GSR_BWD_BATCH / GSR_BWD_THREADS; h++) {
+			const int st = tid + h * GSR_BWD_THREADS;
+			if (st < cnt) {
+				float v[10];
+				bool any = false;
+#pragma unroll
+				for (int k = 0; k < 10; k++) {
+					v[k] = sG[st * GSR_SG_STRIDE + k];
+					any = any || v[k] != 0.f;
+				}
+				if (any) {
+					// moments -> gradients (once per (tile, Gaussian)): with q = G*dL_dalpha summed over pixels,
+					//   dL_dmean2D.x = -0.5W * op * (a*M10 + b*M01)      (backward.cu:593-599)
+					//   dL_dconic    = -0.5 * op * (M20, M11, M02)       (backward.cu:602-604)
+					// where conic (a, b, c) = (-2*q0.z, -q0.w, -2*q1.x), op = q1.y
+					const float4 A = sA[st], B = sB[st];
+					const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x, op = B.y;
+					const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[4];
+					const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
+					float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row[h] * GSR_ROW_STRIDE);
+					dst[0] = make_float4(-(op * FMA(cb, M01, ca * M10)) * ddelx_dx, -(op * FMA(cb, M10, cc * M01)) * ddely_dy,
+					                     -0.5f * op * M20, -0.5f * op * M11);
+					dst[1] = make_float4(-0.5f * op * M02, v[5], v[6], v[7]);
+					dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
+				}
 			}
 		}
 	}
@@ -362,7 +416,7 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
-	hipLaunchKernelGGL(composite_bwd_kernel, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, bg, ranges,
+	hipLaunchKernelGGL(composite_bwd_kernel, dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg, ranges,
 	                   point_list, recs, goff, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
 	                   dL_dpix_opacity, rows);
 }
