@@ -182,28 +182,6 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 
 #define GSR_SG_STRIDE 11
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef int v2i __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-// gs_exp on two values at once (same arithmetic as gs_common.h gs_exp; arguments far below -80 give
-// garbage that callers mask)
-__device__ __forceinline__ v2f gs_exp2(v2f p)
-{
-	const v2f LOG2E = {0x1.715476p+0f, 0x1.715476p+0f};
-	const v2f MAGIC = {12582912.0f, 12582912.0f};
-	const v2f tm = vfma(p, LOG2E, MAGIC);
-	const v2f nf = tm - MAGIC;
-	const v2f f = vfma(p, LOG2E, -nf);
-	v2f y = {0x1.5c08e6p-10f, 0x1.5c08e6p-10f};
-	y = vfma(y, f, v2f{0x1.3d0c52p-7f, 0x1.3d0c52p-7f});
-	y = vfma(y, f, v2f{0x1.c6b6e4p-5f, 0x1.c6b6e4p-5f});
-	y = vfma(y, f, v2f{0x1.ebf918p-3f, 0x1.ebf918p-3f});
-	y = vfma(y, f, v2f{0x1.62e428p-1f, 0x1.62e428p-1f});
-	y = vfma(y, f, v2f{0x1.000002p+0f, 0x1.000002p+0f});
-	const v2i r = __builtin_bit_cast(v2i, y) + (__builtin_bit_cast(v2i, tm) << 23);
-	return __builtin_bit_cast(v2f, r);
-}
-
 // composite_bwd: ONE workgroup of 2 wave64 per 16x16 tile; wave w owns the 8-wide, 16-tall half tile
 // (columns 8w..8w+7) and every lane owns TWO pixels of it, (x, y) and (x, y+8).  The cross-lane reduction
 // of the ten gradient components costs ~85 VALU instructions per (wave, instance) regardless of how many
