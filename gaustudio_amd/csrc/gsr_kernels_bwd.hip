@@ -40,6 +40,16 @@ __device__ __forceinline__ float row_sum16(float v)
 // Doing these "transposing" cross-row steps FIRST shrinks ten per-lane quantities to three registers
 // (each 16-lane row carrying a different quantity) before the four within-row DPP steps, so the whole
 // 64-lane reduction of ten quantities costs 8 swaps + 8 adds + 12 DPP adds instead of 60 DPP adds.
+// three independent row sums, interleaved step by step: a DPP read needs two wait states after the VALU
+// write of its source, which the other two chains fill (no s_nop)
+#define GSR_DPP_ADD(v, ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ void row_sum16x3(float& a, float& b, float& c)
+{
+	GSR_DPP_ADD(a, 0xB1); GSR_DPP_ADD(b, 0xB1); GSR_DPP_ADD(c, 0xB1);      // quad_perm [1,0,3,2]
+	GSR_DPP_ADD(a, 0x4E); GSR_DPP_ADD(b, 0x4E); GSR_DPP_ADD(c, 0x4E);      // quad_perm [2,3,0,1]
+	GSR_DPP_ADD(a, 0x141); GSR_DPP_ADD(b, 0x141); GSR_DPP_ADD(c, 0x141);   // row_half_mirror
+	GSR_DPP_ADD(a, 0x140); GSR_DPP_ADD(b, 0x140); GSR_DPP_ADD(c, 0x140);   // row_mirror
+}
 __device__ __forceinline__ float half_swap_sum(float a, float b)
 {
 	// v_permlane32_swap(X, Y): X.rows23 <-> Y.rows01
@@ -305,33 +315,40 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				const v2f power = vfma(v2f{bxd, bxd}, dy, vfma(B.x * dy, dy, v2f{ax, ax}));
 				const v2f G = gs_exp2(power);
 				const v2f alpha = v2f{fminf(0.99f, B.y * G.x), fminf(0.99f, B.y * G.y)};
-				const v2i live = (v2i{pos, pos} < last_contributor) & (power <= 0.0f) & (power >= B.w) &
-				                 ~(alpha < (1.0f / 255.0f));
-				if (__ballot((live.x | live.y) != 0) == 0ull) continue;
+				// per-pixel predicates stay scalar bools (SGPR lane masks): a select is then ONE v_cndmask
+				const bool live0 = pos < last_contributor.x && power.x <= 0.0f && power.x >= B.w && !(alpha.x < 1.0f / 255.0f);
+				const bool live1 = pos < last_contributor.y && power.y <= 0.0f && power.y >= B.w && !(alpha.y < 1.0f / 255.0f);
+				if (__ballot(live0 || live1) == 0ull) continue;
+#define SEL2(c0, c1, a, b) v2f{(c0) ? (a).x : (b).x, (c1) ? (a).y : (b).y}
+				const v2f zero2 = {0.f, 0.f};
 				// 1/(1-alpha) once, by v_rcp_f32 (1 ulp) instead of two IEEE divisions (backward.cu:536,587): the
 				// backward is tolerance-checked (its sums are order-dependent in the reference as well)
 				const v2f om = 1.f - alpha;
 				const v2f rinv = v2f{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
 				const v2f test_T = T_ * rinv;
-				const v2f w = live ? alpha * test_T : v2f{0.f, 0.f};   // dchannel_dcolor = dpixel_depth_ddepth = ...
+				const v2f aT = alpha * test_T;
+				const v2f w = SEL2(live0, live1, aT, zero2);   // dchannel_dcolor = dpixel_depth_ddepth = ...
 				// <colour of this Gaussian, dL_dpixel> over the 5 blended channels (rgb, depth, opacity == 1)
 				const v2f cd = vfma(v2f{Cc.x, Cc.x}, dLp0, vfma(v2f{Cc.y, Cc.y}, dLp1,
 				                    vfma(v2f{Cc.z, Cc.z}, dLp2, vfma(v2f{B.z, B.z}, dLd, dLo))));
 				const v2f Sn = vfma(last_alpha, last_cd - S, S);
 				v2f dL_dalpha = (cd - Sn) * test_T;
 				if (any_bg) dL_dalpha = vfma(-(T_final * rinv), bg_dot, dL_dalpha);   // backward.cu:584-587
-				const v2f qa = live ? G * dL_dalpha : v2f{0.f, 0.f};                  // dL_dG * G / opacity
-				const v2i med = live & (test_T > 0.5f) & (T_ < 0.5f);                 // median-depth gradient (backward.cu:566-569)
+				const v2f gq = G * dL_dalpha;
+				const v2f qa = SEL2(live0, live1, gq, zero2);                         // dL_dG * G / opacity
+				// median-depth gradient (backward.cu:566-569)
+				const bool med0 = live0 && test_T.x > 0.5f && T_.x < 0.5f, med1 = live1 && test_T.y > 0.5f && T_.y < 0.5f;
 				const v2f g6v = w * dLp0, g7v = w * dLp1, g8v = w * dLp2;
-				const v2f g9v = vfma(w, dLd, med ? dLm : v2f{0.f, 0.f});
+				const v2f g9v = vfma(w, dLd, SEL2(med0, med1, dLm, zero2));
 				const v2f g5v = vfma(w, dLo, qa);                                     // backward.cu:575 + :607
 				// moments of qa over the pixels; the conic / opacity factors are applied once per instance in the flush
 				const v2f qx = qa * dx, qy = qa * dy;
 				const v2f m20 = qx * dx, m11 = qx * dy, m02 = qy * dy;
-				S = live ? Sn : S;
-				last_cd = live ? cd : last_cd;
-				T_ = live ? test_T : T_;
-				last_alpha = live ? alpha : last_alpha;
+				S = SEL2(live0, live1, Sn, S);
+				last_cd = SEL2(live0, live1, cd, last_cd);
+				T_ = SEL2(live0, live1, test_T, T_);
+				last_alpha = SEL2(live0, live1, alpha, last_alpha);
+#undef SEL2
 				// ten per-lane quantities (two pixels each) -> three registers whose 16-lane rows carry different
 				// quantities -> within-row sums.  Row r of s0 / s1 / s2 holds component {0,2,1,3}[r] / 4+{0,2,1,3}[r] /
 				// {8,-,9,-}[r].
@@ -340,9 +357,8 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				const float r2 = half_swap_sum(m02.x + m02.y, g5v.x + g5v.y);  // [M02 | g5 ]
 				const float r3 = half_swap_sum(g6v.x + g6v.y, g7v.x + g7v.y);  // [g6  | g7 ]
 				const float r4 = half_swap_sum(g8v.x + g8v.y, g9v.x + g9v.y);  // [g8  | g9 ]
-				const float s0 = row_sum16(row_swap_sum(r0, r1));
-				const float s1 = row_sum16(row_swap_sum(r2, r3));
-				const float s2 = row_sum16(row_swap_sum(r4, 0.f));
+				float s0 = row_swap_sum(r0, r1), s1 = row_swap_sum(r2, r3), s2 = row_swap_sum(r4, 0.f);
+				row_sum16x3(s0, s1, s2);
 				if ((lane & 15) == 0) {
 					// LDS float atomics (ds_add_f32), one lane per row = four components per instruction: the two
 					// waves of the tile meet here; global memory sees one row per (tile, instance) in the flush
@@ -405,8 +421,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
     const float* __restrict__ cov3D_precomp, const GsCam* __restrict__ cam, int W, int H, float tan_fovx,
-    float tan_fovy, float h_x, float h_y, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
-    const float* __restrict__ rows,
+    float tan_fovy, float h_x, float h_y, int sh_vec4, const GsRec* __restrict__ recs,
+    const uint32_t* __restrict__ goff, const float* __restrict__ rows,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
@@ -430,8 +446,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 	float dscale[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
 	float* dsh = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : nullptr;
 	if (!vis) {
-		if (dsh)
-			for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
+		if (dsh) {
+			if (sh_vec4)
+				for (int i = 0; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+			else
+				for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
+		}
 	} else {
 		const float* view = cam->view;
 		const float* proj = cam->proj;
@@ -516,9 +536,18 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 		if (shs != nullptr) {
 			// computeColorFromSH backward (backward.cu:20-139)
 			float sh[NC * 3];
+			float osh[NC * 3];   // dL_dsh of the active coefficients, stored with 16-B vectors below
 			const float* shp = shs + (size_t)idx * M * 3;
+			if (sh_vec4 && (NC * 3) % 4 == 0) {
 #pragma unroll
-			for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+				for (int i = 0; i < NC * 3 / 4; i++) {
+					const float4 v = reinterpret_cast<const float4*>(shp)[i];
+					sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+			}
 			const float3 dir_orig = {m.x - cam->campos[0], m.y - cam->campos[1], m.z - cam->campos[2]};
 			const float len = sqrtf(FMA(dir_orig.z, dir_orig.z, FMA(dir_orig.y, dir_orig.y, dir_orig.x * dir_orig.x)));
 			const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
@@ -528,7 +557,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 			for (int ch = 0; ch < 3; ch++) dRGB[ch] = a_[6 + ch] * (((clamped >> ch) & 1u) ? 0.f : 1.f);
 			float dRGBdx[3] = {0.f, 0.f, 0.f}, dRGBdy[3] = {0.f, 0.f, 0.f}, dRGBdz[3] = {0.f, 0.f, 0.f};
 #define SH(k) sh[(k) * 3 + ch]
-#define DSH(k, coef) _Pragma("unroll") for (int ch = 0; ch < 3; ch++) dsh[(k) * 3 + ch] = (coef) * dRGB[ch]
+#define DSH(k, coef) _Pragma("unroll") for (int ch = 0; ch < 3; ch++) osh[(k) * 3 + ch] = (coef) * dRGB[ch]
 			DSH(0, bSH_C0);
 			if (D > 0) {
 				const float d1_ = -bSH_C1 * y, d2_ = bSH_C1 * z, d3_ = -bSH_C1 * x;
@@ -585,7 +614,16 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 			}
 #undef SH
 #undef DSH
-			for (int i = NC * 3; i < M * 3; i++) dsh[i] = 0.f;   // coefficients above the active degree
+			if (sh_vec4 && (NC * 3) % 4 == 0) {
+#pragma unroll
+				for (int i = 0; i < NC * 3 / 4; i++)
+					reinterpret_cast<float4*>(dsh)[i] = make_float4(osh[4 * i], osh[4 * i + 1], osh[4 * i + 2], osh[4 * i + 3]);
+				for (int i = NC * 3 / 4; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+			} else {
+#pragma unroll
+				for (int i = 0; i < NC * 3; i++) dsh[i] = osh[i];
+				for (int i = NC * 3; i < M * 3; i++) dsh[i] = 0.f;   // coefficients above the active degree
+			}
 			const float ddx = FMA(dRGBdx[2], dRGB[2], FMA(dRGBdx[1], dRGB[1], dRGBdx[0] * dRGB[0]));
 			const float ddy = FMA(dRGBdy[2], dRGB[2], FMA(dRGBdy[1], dRGB[1], dRGBdy[0] * dRGB[0]));
 			const float ddz = FMA(dRGBdz[2], dRGB[2], FMA(dRGBdz[1], dRGB[1], dRGBdz[0] * dRGB[0]));
@@ -655,11 +693,14 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 {
 	const float h_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:391-392
 	const float h_x = a.W / (2.0f * a.tan_fovx);
+	// 16-B vector access to the SH rows / dL_dsh rows needs 16-B aligned bases and a row size multiple of 16 B
+	const int sh_vec4 = (a.shs != nullptr && dL_dsh != nullptr && ((uintptr_t)a.shs % 16 == 0) &&
+	                     ((uintptr_t)dL_dsh % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0;
 	dim3 grid((a.P + 255) / 256), block(256);
 #define GSR_LAUNCH_PB(DEG)                                                                                         \
 	hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, a.scales, \
 	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
-	                   h_y, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
+	                   h_y, sh_vec4, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
 	                   dL_drot)
 	const int D = a.shs ? a.D : 0;
 	switch (D) {
