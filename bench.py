@@ -100,12 +100,19 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GSR_BENCH_BACKEND=gloo + fewer GPUs than ranks is a plumbing test of the N > 1 path on a 1-GPU box
+    # (ranks share device 0, the collective goes through gloo); the measured configuration is nccl = RCCL.
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gaustudio_amd import _C, parallel, scenes
     from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
@@ -145,6 +152,7 @@ def main():
         state["out"] = (color, radii, depth, median, opac)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

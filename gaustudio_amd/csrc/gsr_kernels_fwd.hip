@@ -586,11 +586,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 				const bool stop = valid && test_T < 0.0001f;                         // forward.cu:357-361
 				done = done || stop;
 				const bool apply = valid && !stop;
-				const float w = alpha * T_;
-				C0 = apply ? FMA(Cc.x, w, C0) : C0;
-				C1 = apply ? FMA(Cc.y, w, C1) : C1;
-				C2 = apply ? FMA(Cc.z, w, C2) : C2;
-				Dacc = apply ? FMA(B.z, w, Dacc) : Dacc;
+				// a skipped pair contributes with weight exactly 0: fma(c, 0, acc) == acc for finite c, so one select
+				// on the weight replaces four on the accumulators (results stay bit-identical)
+				const float w = apply ? alpha * T_ : 0.f;
+				C0 = FMA(Cc.x, w, C0);
+				C1 = FMA(Cc.y, w, C1);
+				C2 = FMA(Cc.z, w, C2);
+				Dacc = FMA(B.z, w, Dacc);
 				const bool med = apply && T_ > 0.5f && test_T < 0.5f;                // forward.cu:368-373
 				median_D = med ? B.z : median_D;
 				median_weight = med ? w : median_weight;

@@ -1,0 +1,144 @@
+"""-m gpu: behaviour of the operator interface on a real device (SURVEY.md s8b contracts that need a GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gaustudio_amd import scenes
+
+from util import hip_forward, scene_kwargs, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(cam, D=3, dev="cuda", bg=None, debug=False, mod=1.0):
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy,
+                                         torch.zeros(3) if bg is None else bg, mod, cam.viewmatrix.to(dev),
+                                         cam.projmatrix.to(dev), D, cam.campos.to(dev), False, debug)
+
+
+def _render(sc, cam, rs, dev="cuda", leaves=None):
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizer
+    if leaves is None:
+        leaves = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    out = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                 shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+    return out, leaves, means2D
+
+
+def test_two_forwards_then_backward_of_the_first_and_retain_graph():
+    """The opaque buffers belong to each call (ctx.save_for_backward); a later forward must not disturb an
+    earlier graph, and backward may run twice with retain_graph."""
+    camA, camB = scenes.make_camera(160, 96), scenes.make_camera(96, 160)
+    sc = scenes.make_scene(4000, camA, seed=3, sigma_px_median=2.0)
+    (cA, rA, dA, mA, oA), leaves, _ = _render(sc, camA, _settings(camA))
+    (cB, *_), _, _ = _render(sc, camB, _settings(camB), leaves=leaves)
+    g = torch.autograd.grad(cA.sum() + dA.sum(), list(leaves.values()), retain_graph=True)
+    g2 = torch.autograd.grad(cA.sum() + dA.sum(), list(leaves.values()))
+    for a, b in zip(g, g2):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max()))   # 2-wave LDS meeting is unordered
+    cB.sum().backward()
+    assert all(v.grad is not None and torch.isfinite(v.grad).all() for v in leaves.values())
+
+
+def test_no_grad_and_non_contiguous_inputs():
+    cam = scenes.make_camera(128, 80)
+    sc = scenes.make_scene(3000, cam, seed=9)
+    ref = hip_forward(sc, cam, 3, scene_kwargs(sc, True, False))
+    dev = "cuda"
+    big = torch.zeros(3000, 6, device=dev)
+    big[:, ::2] = sc.means3D.to(dev)
+    means_nc = big[:, ::2]                                      # stride-2 view, same values
+    assert not means_nc.is_contiguous()
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizer
+    with torch.no_grad():
+        color, radii, depth, median, opac = GaussianRasterizer(_settings(cam))(
+            means3D=means_nc, means2D=torch.zeros(3000, 3, device=dev), opacities=sc.opacities.to(dev),
+            shs=sc.shs.to(dev), scales=sc.scales.to(dev), rotations=sc.rotations.to(dev))
+    assert torch.equal(color, ref["color"]) and torch.equal(radii, ref["radii"]) and not color.requires_grad
+
+
+def test_bg_on_device_or_host_and_viewmatrix_on_host():
+    cam = scenes.make_camera(96, 64)
+    sc = scenes.make_scene(1500, cam, seed=2)
+    kw = scene_kwargs(sc, True, False)
+    a = hip_forward(sc, cam, 2, kw, bg=torch.ones(3))           # CPU bg, as gaustudio's renderers pass it
+    b = hip_forward(sc, cam, 2, kw, bg=torch.ones(3).cuda())
+    assert torch.equal(a["color"], b["color"])
+    from gaustudio_amd import _C
+    e = torch.Tensor([])
+    out = _C.rasterize_gaussians(torch.zeros(3), sc.means3D.cuda(), e, sc.opacities.cuda(), sc.scales.cuda(),
+                                 sc.rotations.cuda(), 1.0, e, cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy,
+                                 cam.height, cam.width, sc.shs.cuda(), 2, cam.campos, False, False)   # host camera tensors
+    assert torch.equal(out[1], a["color"])
+
+
+def test_debug_mode_syncs_per_stage_and_dumps_snapshot_on_failure(tmp_path, monkeypatch):
+    cam = scenes.make_camera(64, 64)
+    sc = scenes.make_scene(800, cam, seed=5)
+    (color, *_), leaves, _ = _render(sc, cam, _settings(cam, debug=True))
+    color.sum().backward()
+    assert torch.isfinite(leaves["means3D"].grad).all()
+    # failure path: SH degree 3 with only 4 stored coefficients is rejected by the library -> snapshot_fw.dump
+    monkeypatch.chdir(tmp_path)
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizer
+    with pytest.raises(RuntimeError, match="SH degree"):
+        GaussianRasterizer(_settings(cam, D=3, debug=True))(
+            means3D=sc.means3D.cuda(), means2D=torch.zeros(800, 3, device="cuda"), opacities=sc.opacities.cuda(),
+            shs=sc.shs[:, :4].contiguous().cuda(), scales=sc.scales.cuda(), rotations=sc.rotations.cuda())
+    assert os.path.exists(tmp_path / "snapshot_fw.dump")
+    snap = torch.load(tmp_path / "snapshot_fw.dump")
+    assert isinstance(snap, tuple) and snap[1].shape == (800, 3) and snap[1].device.type == "cpu"
+
+
+def test_wrong_dtype_and_shape_errors():
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(32, 32)
+    e = torch.Tensor([])
+    args = lambda means, col: (torch.zeros(3), means, col, torch.ones(4, 1).cuda(), torch.ones(4, 3).cuda(),
+                               torch.ones(4, 4).cuda(), 1.0, e, cam.viewmatrix.cuda(), cam.projmatrix.cuda(), cam.tanfovx,
+                               cam.tanfovy, 32, 32, e, 0, cam.campos.cuda(), False, False)
+    with pytest.raises(RuntimeError, match="float32"):
+        _C.rasterize_gaussians(*args(torch.zeros(4, 3, dtype=torch.float64).cuda(), torch.zeros(4, 3).cuda()))
+    with pytest.raises(RuntimeError, match=r"colors_precomp must have dimensions \(num_points, 3\)"):
+        _C.rasterize_gaussians(*args(torch.zeros(4, 3).cuda(), torch.zeros(4, 4).cuda()))
+    with pytest.raises(RuntimeError, match="provide precomputed Gaussian colors"):        # rasterizer_impl.cu:245-248
+        _C.rasterize_gaussians(*args(torch.zeros(4, 3).cuda(), e))
+
+
+def test_two_dimensional_scales_padded_like_vanilla_renderer():
+    """vanilla_renderer.py:38-39 pads 2-D scales with 1e-7; degenerate (flat) Gaussians must render finitely."""
+    cam = scenes.make_camera(96, 96)
+    sc = scenes.make_scene(1000, cam, seed=4, sigma_px_median=3.0)
+    s2 = torch.cat([sc.scales[:, :2], torch.zeros_like(sc.scales[:, :1]) + 1e-7], dim=-1)
+    sc = sc._replace(scales=s2.contiguous())
+    hs = hip_forward(sc, cam, 3, scene_kwargs(sc, True, False))
+    assert torch.isfinite(hs["color"]).all() and hs["num_rendered"] > 0
+
+
+def test_streams_follow_torch_current_stream():
+    cam = scenes.make_camera(128, 128)
+    sc = scenes.make_scene(5000, cam, seed=6)
+    kw = scene_kwargs(sc, True, False)
+    ref = hip_forward(sc, cam, 3, kw)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        got = hip_forward(sc, cam, 3, kw)
+    s.synchronize()
+    assert torch.equal(ref["color"], got["color"])
+
+
+def test_profiling_stage_times_reported():
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(256, 256)
+    sc = scenes.make_scene(20000, cam, seed=7)
+    _C.set_profiling(True)
+    for _ in range(3):
+        hip_forward(sc, cam, 0, scene_kwargs(sc, True, False))
+    ms = _C.last_forward_ms()
+    _C.set_profiling(False)
+    assert ms is not None and ms["calls"] == 3 and ms["composite"] > 0 and ms["preprocess"] > 0
+    assert _C.last_forward_ms() is None
