@@ -317,10 +317,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 		            __FILE__, __LINE__);
 	if (R > 0x7fffffffu) return fail(GSR_ERR_ARG, "gsr_forward: more than 2^31 instances", __FILE__, __LINE__);
 
-	const BinLayout bl((size_t)R);
+	const BinLayout bl((size_t)R, max_tile > GSR_SORT_LDS_MAX);
 	char* bin = binning_alloc(binning_ctx, bl.total);
 	if (!bin) return fail(GSR_ERR_ALLOC, "gsr_forward: binning allocator returned NULL", __FILE__, __LINE__);
 	uint64_t* keys = reinterpret_cast<uint64_t*>(bin + bl.keys);
+	uint64_t* keys2 = reinterpret_cast<uint64_t*>(bin + bl.keys2);
 	uint32_t* point_list = reinterpret_cast<uint32_t*>(bin + bl.point_list);
 
 	tm.mark();
@@ -333,7 +334,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	}
 	tm.mark();
 	if (R > 0) {
-		launch_tile_sort(il.T, max_tile, ranges, keys, point_list, s);
+		launch_tile_sort(il.T, max_tile, ranges, keys, keys2, point_list, s);
 		STAGE_CHECK("tile_sort", debug, s);
 	}
 	tm.mark();

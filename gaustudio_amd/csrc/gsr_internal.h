@@ -41,18 +41,22 @@ struct ImgLayout {
 	}
 };
 
-// binning buffer: [keys u64 x R][point_list u32 x R]   (replaces BinningState, rasterizer_impl.h:59-68:
-// 2x u64 keys + 2x u32 values + CUB temp = 24 B/instance + temp; here 12 B/instance)
+// binning buffer: [point_list u32 x R][keys u64 x R][keys2 u64 x R, only when a tile list is long enough for
+// the radix path]   (replaces BinningState, rasterizer_impl.h:59-68: 2x u64 keys + 2x u32 values + CUB temp =
+// 24 B/instance + temp; here 12 B/instance, 20 B with the radix ping-pong buffer).  Backward reads point_list only.
 struct BinLayout {
-	size_t keys, point_list, total;
-	explicit BinLayout(size_t R)
+	size_t point_list, keys, keys2, total;
+	explicit BinLayout(size_t R, bool with_tmp = false)
 	{
-		keys = 0;
-		point_list = align_up(sizeof(uint64_t) * R);
-		total = point_list + align_up(sizeof(uint32_t) * R);
+		point_list = 0;
+		keys = align_up(sizeof(uint32_t) * R);
+		keys2 = keys + align_up(sizeof(uint64_t) * R);
+		total = with_tmp ? keys2 + align_up(sizeof(uint64_t) * R) : keys2;
 		if (total == 0) total = 256;
 	}
 };
+// per-tile lists longer than this are sorted by the radix path (needs the keys2 ping-pong buffer)
+#define GSR_SORT_LDS_MAX 1024u
 
 struct FwdArgs {
 	int P, D, M, W, H;
@@ -83,8 +87,8 @@ void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const 
                      uint32_t* tile_count, hipStream_t s);
 void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
                          const uint2* ranges, uint64_t* keys, hipStream_t s);
-void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
-                      hipStream_t s);
+void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
+                      uint32_t* point_list, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
                           float* out_opacity, float* final_T, uint32_t* n_contrib, hipStream_t s);

@@ -480,30 +480,108 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint2* __restrict_
 	for (uint32_t i = tid; i < n; i += 256) point_list[range.x + i] = (uint32_t)a[i];
 }
 
-void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
-                      hipStream_t s)
+// Long lists (> GSR_SORT_LDS_MAX keys, e.g. 5 M Gaussians in a 1297x840 frame: 4.7 k per tile on average): a
+// bitonic network is O(n log^2 n) and took 2.5 ms there.  tile_radix_sort is a per-tile stable LSD radix sort on
+// the 32 depth bits (4 passes of 8 bits) ping-ponging between `keys` and `keys2` in global memory (a tile's
+// segment stays in L2), one workgroup per tile:
+//   each wave owns a contiguous quarter of the list; per pass: per-wave digit histograms (LDS atomics),
+//   exclusive scan over (digit, wave), then every wave walks its quarter in order 64 keys at a time, ranking
+//   equal digits inside the group with 8 ballots (match-any) -- stable by construction.
+// Equal depths come out in arbitrary id order (the scatter order is arbitrary), so a final pass orders every run
+// of equal depth by id: the key (depth, id) ordering of the reference's stable radix sort.
+__global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __restrict__ ranges,
+                                                              uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
+                                                              uint32_t* __restrict__ point_list, uint32_t lo)
+{
+	__shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave running offsets
+	__shared__ uint32_t s_tot[4];
+	const uint2 range = ranges[blockIdx.x];
+	const uint32_t n = range.y - range.x;
+	if (n <= lo) return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	uint64_t* src = keys + range.x;
+	uint64_t* dst = keys2 + range.x;
+	// wave w owns [wb, we): quarters rounded to multiples of 64 so that groups never straddle waves
+	const uint32_t per = ((n + 3) / 4 + 63) / 64 * 64;
+	const uint32_t wb = min(n, (uint32_t)wv * per), we = min(n, wb + per);
+	for (int pass = 0; pass < 4; pass++) {
+		const int shift = 32 + 8 * pass;
+		for (int i = tid; i < 1024; i += 256) (&whist[0][0])[i] = 0;
+		__syncthreads();
+		for (uint32_t i = wb + lane; i < we; i += 64) atomicAdd(&whist[wv][(uint32_t)(src[i] >> shift) & 255u], 1u);
+		__syncthreads();
+		// thread d: exclusive offsets of digit d for the four waves; then add the prefix over digits
+		{
+			const uint32_t c0 = whist[0][tid], c1 = whist[1][tid], c2 = whist[2][tid], c3 = whist[3][tid];
+			const uint32_t tot = c0 + c1 + c2 + c3;
+			uint32_t incl = tot;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+				if (lane >= o) incl += t;
+			}
+			if (lane == 63) s_tot[wv] = incl;
+			__syncthreads();
+			uint32_t base = incl - tot;
+			for (int w = 0; w < wv; w++) base += s_tot[w];
+			whist[0][tid] = base;
+			whist[1][tid] = base + c0;
+			whist[2][tid] = base + c0 + c1;
+			whist[3][tid] = base + c0 + c1 + c2;
+		}
+		__syncthreads();
+		for (uint32_t g0 = wb; g0 < we; g0 += 64) {
+			const uint32_t i = g0 + lane;
+			const bool act = i < we;
+			const uint64_t k = act ? src[i] : 0ull;
+			const uint32_t d = act ? (uint32_t)(k >> shift) & 255u : 256u;
+			// lanes holding the same digit (match-any over 8 bits)
+			unsigned long long same = __ballot(act);
+#pragma unroll
+			for (int b = 0; b < 8; b++) {
+				const unsigned long long bm = __ballot((d >> b) & 1u);
+				same &= ((d >> b) & 1u) ? bm : ~bm;
+			}
+			if (act) {
+				const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+				const uint32_t base = whist[wv][d];
+				dst[base + rank] = k;
+				if (rank == 0) whist[wv][d] = base + (uint32_t)__popcll(same);   // group leader advances the cursor
+			}
+		}
+		__syncthreads();
+		uint64_t* t = src; src = dst; dst = t;
+	}
+	// after 4 passes the data is back in `keys`; order runs of equal depth by id (rare), then emit the ids
+	for (uint32_t i = tid; i < n; i += 256) {
+		const uint32_t dep = (uint32_t)(src[i] >> 32);
+		const bool starts = (i == 0 || (uint32_t)(src[i - 1] >> 32) != dep) && (i + 1 < n) && (uint32_t)(src[i + 1] >> 32) == dep;
+		if (starts) {
+			uint32_t e = i + 1;
+			while (e < n && (uint32_t)(src[e] >> 32) == dep) e++;
+			for (uint32_t a = i + 1; a < e; a++) {   // insertion sort of the run [i, e) by full key (= by id)
+				const uint64_t v = src[a];
+				uint32_t b = a;
+				while (b > i && src[b - 1] > v) { src[b] = src[b - 1]; b--; }
+				src[b] = v;
+			}
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += 256) point_list[range.x + i] = (uint32_t)src[i];
+}
+
+void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
+                      uint32_t* point_list, hipStream_t s)
 {
 	if (max_tile_count == 0) return;
-	// small: <= 4096 keys (32 KiB LDS, several workgroups per CU); large: <= 16384 (128 KiB); huge: global
-	const uint32_t CAP_S = 4096, CAP_L = 16384;
-	{
-		const uint32_t cap = max_tile_count < CAP_S ? max(256u, max_tile_count) : CAP_S;
-		hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(T), dim3(256), cap * sizeof(uint64_t), s, ranges, keys,
-		                   point_list, 0u, CAP_S);
-	}
-	if (max_tile_count > CAP_S) {
-		static bool attr_set = false;
-		if (!attr_set) {
-			(void)hipFuncSetAttribute((const void*)tile_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                          CAP_L * sizeof(uint64_t));
-			attr_set = true;
-		}
-		hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(T), dim3(256), CAP_L * sizeof(uint64_t), s, ranges, keys,
-		                   point_list, CAP_S, CAP_L);
-	}
-	if (max_tile_count > CAP_L)
-		hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(T), dim3(256), 0, s, ranges, keys, point_list, CAP_L,
-		                   0xffffffffu);
+	// <= GSR_SORT_LDS_MAX keys: bitonic network in LDS (32 KiB, several workgroups per CU); longer: radix path
+	const uint32_t cap = max_tile_count < GSR_SORT_LDS_MAX ? max(256u, max_tile_count) : GSR_SORT_LDS_MAX;
+	hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(T), dim3(256), cap * sizeof(uint64_t), s, ranges, keys, point_list, 0u,
+	                   GSR_SORT_LDS_MAX);
+	if (max_tile_count > GSR_SORT_LDS_MAX)
+		hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list,
+		                   GSR_SORT_LDS_MAX);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -60,8 +60,8 @@ def test_large_footprints_cooperative_binning(oracle):
 
 @pytest.mark.parametrize("P,lo,hi", [(2500, 256, 4096), (12000, 4096, 16384), (100000, 16384, 1 << 30)])
 def test_long_tile_lists_lds_and_global_sort(oracle, P, lo, hi):
-    """Per-tile lists in each regime of tile_sort: <= 4096 keys (small LDS), <= 16384 (128 KiB LDS),
-    beyond (in-place global fallback)."""
+    """Per-tile lists in each regime of tile_sort: <= 4096 keys (bitonic network in LDS) and the per-tile
+    radix sort beyond (12 k and 93 k keys per tile)."""
     cam = scenes.make_camera(48, 32)
     sc = scenes.make_scene(P, cam, seed=13, sigma_px_median=6.0)
     kw = scene_kwargs(sc, True, False)
@@ -72,10 +72,12 @@ def test_long_tile_lists_lds_and_global_sort(oracle, P, lo, hi):
     compare_forward_exact(hs, os_)
 
 
-def test_depth_ties_resolve_by_id(oracle):
-    """Equal depths inside a tile must order by ascending Gaussian id."""
+@pytest.mark.parametrize("P", [2000, 40000])
+def test_depth_ties_resolve_by_id(oracle, P):
+    """Equal depths inside a tile must order by ascending Gaussian id; P=40000 puts ~10 k keys
+    with only ~18 distinct depths in each tile, i.e. the radix path's equal-depth run fix-up."""
     cam = scenes.make_camera(64, 64)
-    sc = scenes.make_scene(2000, cam, seed=17, sigma_px_median=4.0)
+    sc = scenes.make_scene(P, cam, seed=17, sigma_px_median=4.0)
     means = sc.means3D.clone()
     z = torch.round(means[:, 2])          # only ~18 distinct depths
     means[:, 0] *= z / means[:, 2]
