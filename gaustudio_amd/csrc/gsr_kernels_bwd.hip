@@ -296,7 +296,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		for (int sub = 0; sub < cnt; sub += 64) {
 			const int jl = sub + lane;
 			bool hit = false;
-			if (jl < cnt && top - 1 - jl < wmax) hit = gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
+			if ((jl < cnt) & (top - 1 - jl < wmax)) hit = gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
 			unsigned long long m = __ballot(hit);
 			while (m) {
 				const int j = sub + __ffsll((long long)m) - 1;
@@ -316,9 +316,10 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				const v2f G = gs_exp2(power);
 				const v2f alpha = v2f{fminf(0.99f, B.y * G.x), fminf(0.99f, B.y * G.y)};
 				// per-pixel predicates stay scalar bools (SGPR lane masks): a select is then ONE v_cndmask
-				const bool live0 = pos < last_contributor.x && power.x <= 0.0f && power.x >= B.w && !(alpha.x < 1.0f / 255.0f);
-				const bool live1 = pos < last_contributor.y && power.y <= 0.0f && power.y >= B.w && !(alpha.y < 1.0f / 255.0f);
-				if (__ballot(live0 || live1) == 0ull) continue;
+				// (no short-circuit evaluation: `&` keeps the body free of exec-mask branches)
+				const bool live0 = (pos < last_contributor.x) & (power.x <= 0.0f) & (power.x >= B.w) & (!(alpha.x < 1.0f / 255.0f));
+				const bool live1 = (pos < last_contributor.y) & (power.y <= 0.0f) & (power.y >= B.w) & (!(alpha.y < 1.0f / 255.0f));
+				if (__ballot(live0 | live1) == 0ull) continue;
 #define SEL2(c0, c1, a, b) v2f{(c0) ? (a).x : (b).x, (c1) ? (a).y : (b).y}
 				const v2f zero2 = {0.f, 0.f};
 				// 1/(1-alpha) once, by v_rcp_f32 (1 ulp) instead of two IEEE divisions (backward.cu:536,587): the
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				const v2f gq = G * dL_dalpha;
 				const v2f qa = SEL2(live0, live1, gq, zero2);                         // dL_dG * G / opacity
 				// median-depth gradient (backward.cu:566-569)
-				const bool med0 = live0 && test_T.x > 0.5f && T_.x < 0.5f, med1 = live1 && test_T.y > 0.5f && T_.y < 0.5f;
+				const bool med0 = live0 & (test_T.x > 0.5f) & (T_.x < 0.5f), med1 = live1 & (test_T.y > 0.5f) & (T_.y < 0.5f);
 				const v2f g6v = w * dLp0, g7v = w * dLp1, g8v = w * dLp2;
 				const v2f g9v = vfma(w, dLd, SEL2(med0, med1, dLm, zero2));
 				const v2f g5v = vfma(w, dLo, qa);                                     // backward.cu:575 + :607

@@ -640,16 +640,16 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 			sC[tid] = c;
 		}
 		__syncthreads();
-		bool wave_live = __ballot(!done) != 0ull;
-		for (int sub = 0; wave_live && sub < cnt; sub += 64) {
+		for (int sub = 0; sub < cnt; sub += 64) {
+			if (__ballot(!done) == 0ull) break;   // every pixel of this wave has saturated
 			const int jl = sub + lane;
 			bool hit = false;
 			if (jl < cnt) hit = gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
 			unsigned long long m = __ballot(hit);
-			if (m == 0ull) continue;
 			// walk the surviving instances in list order; the body is straight-line predicated code (no
-			// per-test branches: within a hit block about half of the lanes are live, so branches would
-			// almost never be wave-uniformly skippable); records come from LDS with wave-uniform reads.
+			// per-test branches, no short-circuit evaluation: within a hit block about half of the lanes are
+			// live, so branches would almost never be wave-uniformly skippable); records come from LDS with
+			// wave-uniform reads.
 			while (m) {
 				const int j = sub + __ffsll((long long)m) - 1;
 				m &= m - 1;
@@ -657,13 +657,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 				const float dx = A.x - pixfx, dy = A.y - pixfy;
 				// power = -0.5(a dx^2 + c dy^2) - b dx dy with pre-scaled conic (forward.cu:338)
 				const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
-				bool valid = !done && power <= 0.0f && power >= B.w;                 // forward.cu:339 + pcut
 				const float alpha = fminf(0.99f, B.y * gs_exp(power));
-				valid = valid && !(alpha < 1.0f / 255.0f);                           // forward.cu:346
+				// forward.cu:339 (+ pcut), :346
+				const bool valid = (!done) & (power <= 0.0f) & (power >= B.w) & (!(alpha < 1.0f / 255.0f));
 				const float test_T = T_ * (1 - alpha);
-				const bool stop = valid && test_T < 0.0001f;                         // forward.cu:357-361
-				done = done || stop;
-				const bool apply = valid && !stop;
+				const bool stop = valid & (test_T < 0.0001f);                        // forward.cu:357-361
+				done = done | stop;
+				const bool apply = valid & (!stop);
 				// a skipped pair contributes with weight exactly 0: fma(c, 0, acc) == acc for finite c, so one select
 				// on the weight replaces four on the accumulators (results stay bit-identical)
 				const float w = apply ? alpha * T_ : 0.f;
@@ -671,16 +671,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 				C1 = FMA(Cc.y, w, C1);
 				C2 = FMA(Cc.z, w, C2);
 				Dacc = FMA(B.z, w, Dacc);
-				const bool med = apply && T_ > 0.5f && test_T < 0.5f;                // forward.cu:368-373
+				const bool med = apply & (T_ > 0.5f) & (test_T < 0.5f);              // forward.cu:368-373
 				median_D = med ? B.z : median_D;
 				median_weight = med ? w : median_weight;
 				median_id = med ? (float)__float_as_int(Cc.w) : median_id;
 				T_ = apply ? test_T : T_;
 				last_contributor = apply ? (uint32_t)(base + j + 1) : last_contributor;
-				if (__ballot(!done) == 0ull) {   // every pixel of this wave has saturated
-					wave_live = false;
-					break;
-				}
+				m = (__ballot(!done) == 0ull) ? 0ull : m;   // all saturated: drop the rest of the list
 			}
 		}
 	}

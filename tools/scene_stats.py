@@ -41,3 +41,34 @@ for t in tiles.tolist():
     bh = torch.stack([live[blk == k].any(0) for k in range(4)])
     tot_inst += ids.numel(); tot_blockhit += int(bh.sum()); tot_pairs += live.numel(); tot_live += int(live.sum())
 print(f"sampled {len(tiles)} tiles: instances {tot_inst}; (block,instance) with any live pixel: {tot_blockhit / (4 * tot_inst):.3f}; live (pixel,instance) pairs: {tot_live / tot_pairs:.4f}")
+
+# ---- how tight is the kernel's conservative box test (gs_box_may_touch) compared with the exact "any live pixel"? ----
+def box_test(xy, co, bx0, by0, bx1, by1):
+    ha, nb, hc = -0.5 * co[:, 0], -co[:, 1], -0.5 * co[:, 2]
+    pcut = torch.clamp_min(-torch.log(255.0 * co[:, 3]) - 0.001, -80.0)
+    X0, X1 = xy[:, 0] - bx1, xy[:, 0] - bx0
+    Y0, Y1 = xy[:, 1] - by1, xy[:, 1] - by0
+    xn = torch.minimum(torch.clamp_min(X0, 0.0), X1); xn = torch.where((X0 <= 0) & (X1 >= 0), torch.zeros_like(xn), torch.where(X0 > 0, X0, X1))
+    yn = torch.where((Y0 <= 0) & (Y1 >= 0), torch.zeros_like(Y0), torch.where(Y0 > 0, Y0, Y1))
+    inside = (xn == 0) & (yn == 0)
+    dy = torch.minimum(torch.maximum(-0.5 * nb * xn / hc, Y0), Y1)
+    px_ = ha * xn * xn + (hc * dy + nb * xn) * dy
+    dx = torch.minimum(torch.maximum(-0.5 * nb * yn / ha, X0), X1)
+    py_ = hc * yn * yn + (ha * dx + nb * yn) * dx
+    best = torch.where(xn != 0, px_, torch.full_like(px_, -3e38))
+    best = torch.where(yn != 0, torch.maximum(best, py_), best)
+    return (pcut <= 0) & (inside | (best >= pcut - 0.05))
+
+tot = hit88 = hit816 = ex816 = 0
+for t in tiles.tolist():
+    a, b = int(r[t, 0]), int(r[t, 1])
+    if b <= a: continue
+    ids = pl[a:b]; tx, ty = t % gx, t // gx
+    for q in range(4):
+        bx0 = tx * 16 + (q & 1) * 8; by0 = ty * 16 + (q >> 1) * 8
+        hit88 += int(box_test(xy[ids], co[ids], bx0, by0, min(bx0 + 7, W - 1), min(by0 + 7, H - 1)).sum())
+    for w in range(2):
+        bx0 = tx * 16 + w * 8; by0 = ty * 16
+        hit816 += int(box_test(xy[ids], co[ids], bx0, by0, min(bx0 + 7, W - 1), min(by0 + 15, H - 1)).sum())
+    tot += ids.numel()
+print(f"kernel box test pass rate: 8x8 {hit88 / (4 * tot):.3f} (exact any-live {tot_blockhit / (4 * tot_inst):.3f}); 8x16 {hit816 / (2 * tot):.3f}")
