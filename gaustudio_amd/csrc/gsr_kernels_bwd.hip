@@ -430,7 +430,6 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
-	constexpr int NC = (D + 1) * (D + 1);
 	const bool vis = radii[idx] > 0;
 	float a_[GSR_ROW_STRIDE];
 	gs_sum_rows(vis, idx, recs, goff, rows, a_);
@@ -445,15 +444,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 
 	float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float dscale[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
-	float* dsh = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : nullptr;
-	if (!vis) {
-		if (dsh) {
-			if (sh_vec4)
-				for (int i = 0; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-			else
-				for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
-		}
-	} else {
+	if (vis) {
 		const float* view = cam->view;
 		const float* proj = cam->proj;
 		const float3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
@@ -534,10 +525,86 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 		dmean[1] += FMA(-view[7], mul3, view[6]) * gd;
 		dmean[2] += FMA(-view[11], mul3, view[10]) * gd;
 
-		if (shs != nullptr) {
+		if (scales != nullptr) {
+			// computeCov3D backward (backward.cu:278-341)
+			const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+			const float r = q.x, x = q.y, y = q.z, z = q.w;
+			const M3 R = quat_to_R(q);
+			const float s[3] = {scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
+			                    scale_modifier * scales[3 * idx + 2]};
+			M3 S;
+#pragma unroll
+			for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+				for (int ri = 0; ri < 3; ri++) S.m[ci][ri] = 0.f;
+			S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+			const M3 Mm = m3_mul(S, R);
+			M3 dSig;
+			dSig.m[0][0] = dcov[0]; dSig.m[0][1] = 0.5f * dcov[1]; dSig.m[0][2] = 0.5f * dcov[2];
+			dSig.m[1][0] = 0.5f * dcov[1]; dSig.m[1][1] = dcov[3]; dSig.m[1][2] = 0.5f * dcov[4];
+			dSig.m[2][0] = 0.5f * dcov[2]; dSig.m[2][1] = 0.5f * dcov[4]; dSig.m[2][2] = dcov[5];
+			M3 M2;
+#pragma unroll
+			for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+				for (int ri = 0; ri < 3; ri++) M2.m[ci][ri] = 2.0f * Mm.m[ci][ri];
+			const M3 dL_dM = m3_mul(M2, dSig);
+			const M3 Rt = m3_t(R);
+			M3 dMt = m3_t(dL_dM);
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+				dscale[i] = FMA(Rt.m[i][2], dMt.m[i][2], FMA(Rt.m[i][1], dMt.m[i][1], Rt.m[i][0] * dMt.m[i][0]));
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+#pragma unroll
+				for (int j = 0; j < 3; j++) dMt.m[i][j] *= s[i];
+#define D_(i, j) dMt.m[i][j]
+			dq[0] = FMA(2 * x, D_(1, 2) - D_(2, 1), FMA(2 * y, D_(2, 0) - D_(0, 2), 2 * z * (D_(0, 1) - D_(1, 0))));
+			dq[1] = FMA(-4 * x, D_(2, 2) + D_(1, 1), FMA(2 * r, D_(1, 2) - D_(2, 1), FMA(2 * z, D_(2, 0) + D_(0, 2), 2 * y * (D_(1, 0) + D_(0, 1)))));
+			dq[2] = FMA(-4 * y, D_(2, 2) + D_(0, 0), FMA(2 * z, D_(1, 2) + D_(2, 1), FMA(2 * r, D_(2, 0) - D_(0, 2), 2 * x * (D_(1, 0) + D_(0, 1)))));
+			dq[3] = FMA(-4 * z, D_(1, 1) + D_(0, 0), FMA(2 * y, D_(1, 2) + D_(2, 1), FMA(2 * x, D_(2, 0) + D_(0, 2), 2 * r * (D_(0, 1) - D_(1, 0)))));
+#undef D_
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] = dmean[i];
+#pragma unroll
+	for (int i = 0; i < 6; i++) dL_dcov[6 * (size_t)idx + i] = dcov[i];
+#pragma unroll
+	for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
+	*reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SH part of the per-Gaussian backward (computeColorFromSH backward, backward.cu:20-139), its own kernel:
+// fused into preprocess_bwd it pushed that kernel to 146 VGPRs (3 waves/SIMD) for work that lives on
+// memory-level parallelism.  Runs after preprocess_bwd: reads dL_dcolor, adds its mean gradient to dL_dmeans.
+template <int D>
+__global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
+    int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
+    const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs, const float* __restrict__ dL_dcolor,
+    float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	constexpr int NC = (D + 1) * (D + 1);
+	float* dsh = dL_dsh + (size_t)idx * M * 3;
+	if (!(radii[idx] > 0)) {
+		if (sh_vec4)
+			for (int i = 0; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		else
+			for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
+		return;
+	}
+	const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+	const float a_[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, dL_dcolor[3 * (size_t)idx], dL_dcolor[3 * (size_t)idx + 1],
+	                     dL_dcolor[3 * (size_t)idx + 2]};
+	float dmean[3] = {dL_dmeans[3 * (size_t)idx], dL_dmeans[3 * (size_t)idx + 1], dL_dmeans[3 * (size_t)idx + 2]};
+	{
+
 			// computeColorFromSH backward (backward.cu:20-139)
 			float sh[NC * 3];
-			float osh[NC * 3];   // dL_dsh of the active coefficients, stored with 16-B vectors below
+			float dc[NC];        // d(rgb)/d(sh_k): dL_dsh[k][ch] = dc[k] * dL_dRGB[ch], formed at store time (keeps 32 registers free)
 			const float* shp = shs + (size_t)idx * M * 3;
 			if (sh_vec4 && (NC * 3) % 4 == 0) {
 #pragma unroll
@@ -558,7 +625,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 			for (int ch = 0; ch < 3; ch++) dRGB[ch] = a_[6 + ch] * (((clamped >> ch) & 1u) ? 0.f : 1.f);
 			float dRGBdx[3] = {0.f, 0.f, 0.f}, dRGBdy[3] = {0.f, 0.f, 0.f}, dRGBdz[3] = {0.f, 0.f, 0.f};
 #define SH(k) sh[(k) * 3 + ch]
-#define DSH(k, coef) _Pragma("unroll") for (int ch = 0; ch < 3; ch++) osh[(k) * 3 + ch] = (coef) * dRGB[ch]
+#define DSH(k, coef) dc[k] = (coef)
 			DSH(0, bSH_C0);
 			if (D > 0) {
 				const float d1_ = -bSH_C1 * y, d2_ = bSH_C1 * z, d3_ = -bSH_C1 * x;
@@ -615,16 +682,18 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 			}
 #undef SH
 #undef DSH
+#define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
 			if (sh_vec4 && (NC * 3) % 4 == 0) {
 #pragma unroll
 				for (int i = 0; i < NC * 3 / 4; i++)
-					reinterpret_cast<float4*>(dsh)[i] = make_float4(osh[4 * i], osh[4 * i + 1], osh[4 * i + 2], osh[4 * i + 3]);
+					reinterpret_cast<float4*>(dsh)[i] = make_float4(OSH(4 * i), OSH(4 * i + 1), OSH(4 * i + 2), OSH(4 * i + 3));
 				for (int i = NC * 3 / 4; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 			} else {
 #pragma unroll
-				for (int i = 0; i < NC * 3; i++) dsh[i] = osh[i];
+				for (int i = 0; i < NC * 3; i++) dsh[i] = OSH(i);
 				for (int i = NC * 3; i < M * 3; i++) dsh[i] = 0.f;   // coefficients above the active degree
 			}
+#undef OSH
 			const float ddx = FMA(dRGBdx[2], dRGB[2], FMA(dRGBdx[1], dRGB[1], dRGBdx[0] * dRGB[0]));
 			const float ddy = FMA(dRGBdy[2], dRGB[2], FMA(dRGBdy[1], dRGB[1], dRGBdy[0] * dRGB[0]));
 			const float ddz = FMA(dRGBdz[2], dRGB[2], FMA(dRGBdz[1], dRGB[1], dRGBdz[0] * dRGB[0]));
@@ -635,56 +704,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 			dmean[0] += (FMA(-(v.z * v.x), ddz, FMA(-(v.y * v.x), ddy, FMA(-v.x, v.x, sum2) * ddx))) * invsum32;
 			dmean[1] += (FMA(-(v.z * v.y), ddz, FMA(FMA(-v.y, v.y, sum2), ddy, (-v.x * v.y) * ddx))) * invsum32;
 			dmean[2] += (FMA(FMA(-v.z, v.z, sum2), ddz, FMA(-(v.y * v.z), ddy, (-v.x * v.z) * ddx))) * invsum32;
-		}
-
-		if (scales != nullptr) {
-			// computeCov3D backward (backward.cu:278-341)
-			const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
-			const float r = q.x, x = q.y, y = q.z, z = q.w;
-			const M3 R = quat_to_R(q);
-			const float s[3] = {scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
-			                    scale_modifier * scales[3 * idx + 2]};
-			M3 S;
-#pragma unroll
-			for (int ci = 0; ci < 3; ci++)
-#pragma unroll
-				for (int ri = 0; ri < 3; ri++) S.m[ci][ri] = 0.f;
-			S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
-			const M3 Mm = m3_mul(S, R);
-			M3 dSig;
-			dSig.m[0][0] = dcov[0]; dSig.m[0][1] = 0.5f * dcov[1]; dSig.m[0][2] = 0.5f * dcov[2];
-			dSig.m[1][0] = 0.5f * dcov[1]; dSig.m[1][1] = dcov[3]; dSig.m[1][2] = 0.5f * dcov[4];
-			dSig.m[2][0] = 0.5f * dcov[2]; dSig.m[2][1] = 0.5f * dcov[4]; dSig.m[2][2] = dcov[5];
-			M3 M2;
-#pragma unroll
-			for (int ci = 0; ci < 3; ci++)
-#pragma unroll
-				for (int ri = 0; ri < 3; ri++) M2.m[ci][ri] = 2.0f * Mm.m[ci][ri];
-			const M3 dL_dM = m3_mul(M2, dSig);
-			const M3 Rt = m3_t(R);
-			M3 dMt = m3_t(dL_dM);
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-				dscale[i] = FMA(Rt.m[i][2], dMt.m[i][2], FMA(Rt.m[i][1], dMt.m[i][1], Rt.m[i][0] * dMt.m[i][0]));
-#pragma unroll
-			for (int i = 0; i < 3; i++)
-#pragma unroll
-				for (int j = 0; j < 3; j++) dMt.m[i][j] *= s[i];
-#define D_(i, j) dMt.m[i][j]
-			dq[0] = FMA(2 * x, D_(1, 2) - D_(2, 1), FMA(2 * y, D_(2, 0) - D_(0, 2), 2 * z * (D_(0, 1) - D_(1, 0))));
-			dq[1] = FMA(-4 * x, D_(2, 2) + D_(1, 1), FMA(2 * r, D_(1, 2) - D_(2, 1), FMA(2 * z, D_(2, 0) + D_(0, 2), 2 * y * (D_(1, 0) + D_(0, 1)))));
-			dq[2] = FMA(-4 * y, D_(2, 2) + D_(0, 0), FMA(2 * z, D_(1, 2) + D_(2, 1), FMA(2 * r, D_(2, 0) - D_(0, 2), 2 * x * (D_(1, 0) + D_(0, 1)))));
-			dq[3] = FMA(-4 * z, D_(1, 1) + D_(0, 0), FMA(2 * y, D_(1, 2) + D_(2, 1), FMA(2 * x, D_(2, 0) + D_(0, 2), 2 * r * (D_(0, 1) - D_(1, 0)))));
-#undef D_
-		}
+		
 	}
 #pragma unroll
 	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] = dmean[i];
-#pragma unroll
-	for (int i = 0; i < 6; i++) dL_dcov[6 * (size_t)idx + i] = dcov[i];
-#pragma unroll
-	for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
-	*reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
 }
 
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
@@ -703,14 +726,22 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
 	                   h_y, sh_vec4, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
 	                   dL_drot)
-	const int D = a.shs ? a.D : 0;
-	switch (D) {
-		case 0: GSR_LAUNCH_PB(0); break;
-		case 1: GSR_LAUNCH_PB(1); break;
-		case 2: GSR_LAUNCH_PB(2); break;
-		default: GSR_LAUNCH_PB(3); break;
-	}
+	GSR_LAUNCH_PB(0);
 #undef GSR_LAUNCH_PB
+	if (a.shs != nullptr) {
+#define GSR_LAUNCH_SH(DEG)                                                                                       \
+	hipLaunchKernelGGL(preprocess_bwd_sh_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, cam,  \
+	                   sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh)
+		switch (a.D) {
+			case 0: GSR_LAUNCH_SH(0); break;
+			case 1: GSR_LAUNCH_SH(1); break;
+			case 2: GSR_LAUNCH_SH(2); break;
+			default: GSR_LAUNCH_SH(3); break;
+		}
+#undef GSR_LAUNCH_SH
+	} else if (dL_dsh != nullptr && a.M > 0) {
+		(void)hipMemsetAsync(dL_dsh, 0, sizeof(float) * 3 * (size_t)a.M * (size_t)a.P, s);
+	}
 }
 
 }  // namespace gsr
