@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Per-kernel summary (calls, total / mean / min / max duration) of a rocprofv3 rocpd SQLite database
 (`rocprofv3 --kernel-trace --stats -d DIR -o NAME -- cmd` writes DIR/NAME_results.db on ROCm 7.2).
+Dispatches are grouped by (kernel, grid size) so that the benchmark-sized launches are not averaged with the
+tiny start-up launches of runtime.warm_start().
 Usage: python tools/rocpd_summary.py gpurun_out/prof/x_results.db > profiles/rNN_x_kernel_stats.txt"""
 import sqlite3
 import sys
@@ -8,18 +10,20 @@ import sys
 
 def main(path):
     db = sqlite3.connect(path)
-    rows = db.execute("select name, start, end from kernels").fetchall()
+    rows = db.execute("select name, start, end, grid_x, workgroup_x, vgpr_count, lds_size from kernels").fetchall()
     agg = {}
-    for name, s, e in rows:
-        a = agg.setdefault(name, [0, 0, 1 << 62, 0])
+    for name, s, e, gx, wx, vg, lds in rows:
+        a = agg.setdefault((name, gx, wx, vg, lds), [0, 0, 1 << 62, 0])
         d = e - s
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
     total = sum(a[1] for a in agg.values()) or 1
-    print(f"# rocprofv3 --kernel-trace --stats summary of {path}")
-    print(f"# {'kernel':<72} {'calls':>6} {'total_us':>12} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}")
-    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        short = name if len(name) <= 72 else name[:69] + "..."
-        print(f"  {short:<72} {a[0]:>6} {a[1] / 1e3:>12.1f} {a[1] / a[0] / 1e3:>10.2f} {a[2] / 1e3:>10.2f} {a[3] / 1e3:>10.2f} {100 * a[1] / total:>6.2f}")
+    print(f"# rocprofv3 --kernel-trace --stats summary of {path}  (grouped by kernel and grid size; grid in work-items)")
+    print(f"# {'kernel':<58} {'grid':>9} {'wg':>4} {'vgpr':>4} {'lds':>6} {'calls':>5} {'total_us':>10} {'avg_us':>9} {'min_us':>9} {'max_us':>9} {'pct':>6}")
+    for (name, gx, wx, vg, lds), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        if a[1] / total < 0.0005:
+            continue
+        short = name if len(name) <= 58 else name[:55] + "..."
+        print(f"  {short:<58} {gx:>9} {wx:>4} {vg:>4} {lds:>6} {a[0]:>5} {a[1] / 1e3:>10.1f} {a[1] / a[0] / 1e3:>9.2f} {a[2] / 1e3:>9.2f} {a[3] / 1e3:>9.2f} {100 * a[1] / total:>6.2f}")
 
 
 if __name__ == "__main__":
