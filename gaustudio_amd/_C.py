@@ -6,10 +6,11 @@
     rasterize_gaussians_backward(...)  -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]
 
-This module is glue only: shape checks, output allocation through torch's caching allocator, the
-current HIP stream.  All compute happens in hand-written HIP kernels inside libgsrast.so.  There is
-no CPU or PyTorch fallback: if the library is missing, or the tensors are not on a ROCm device, the
-calls raise.
+The three entry points are implemented natively in csrc/torch_binding.cpp (pybind11 module `_Cnative`, host C++
+only: shape checks, output allocation through torch's caching allocator, torch's current HIP stream) over the C
+ABI; this Python module forwards to it and adds ctypes access to the library's introspection / profiling entry
+points for tests.  All compute happens in hand-written HIP kernels inside libgsrast.so.  There is no CPU or
+PyTorch fallback: if the libraries are missing, or the tensors are not on a ROCm device, the calls raise.
 """
 import ctypes
 import os
@@ -19,8 +20,6 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libgsrast.so")
 _lib = None
-
-_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 
 
 def lib():
@@ -57,151 +56,54 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _f32c(t, name):
-    if t is None:
-        return None
-    if t.numel() and t.dtype != torch.float32:
-        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
-    return t.contiguous()
-
-
-def _require_device(t, name):
-    if not t.is_cuda:
-        raise RuntimeError(
-            f"{name} is on '{t.device}': gaustudio_amd runs on ROCm devices only (hand-written HIP kernels, "
-            "no CPU fallback)")
-
-
-class _Buf:
-    """Allocator callback target: the opaque byte tensors the reference resizes through
-    resizeFunctional (rasterize_points.cu:27-33)."""
-
-    def __init__(self, device):
-        self.device = device
-        self.t = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _ALLOC_FN(self._alloc)
-
-    def _alloc(self, _ctx, n):
-        try:
-            self.t = torch.empty(int(n), dtype=torch.uint8, device=self.device)
-            return self.t.data_ptr()
-        except Exception:   # pragma: no cover - OOM surfaces as GSR_ERR_ALLOC
-            return 0
-
-
 def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_native = None
+
+
+def native():
+    """The compiled torch adapter gaustudio_amd/_Cnative*.so (csrc/torch_binding.cpp, pybind11): the same role as
+    the reference's `_C` extension module.  Linked against libgsrast.so; no fallback if it is missing."""
+    global _native
+    if _native is None:
+        lib()                                            # loud, explicit error if the HIP library is not built
+        try:
+            from . import _Cnative as n
+        except ImportError as e:
+            raise ImportError(
+                "gaustudio_amd/_Cnative*.so not found or not loadable: build it with `make -C gaustudio_amd/csrc` "
+                f"(__graft_entry__.build()). gaustudio_amd has no CPU / pure-Python fallback. [{e}]") from e
+        _native = n
+    return _native
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
                         campos, prefiltered, debug):
-    """RasterizeGaussiansCUDA, rasterize_points.cu:35-121."""
-    if means3D.ndimension() != 2 or means3D.size(1) != 3:
-        raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:57-59
-    L = lib()
-    _require_device(means3D, "means3D")
-    dev = means3D.device
-    P = means3D.size(0)
-    H, W = int(image_height), int(image_width)
-    means3D = _f32c(means3D, "means3D")
-    colors = _f32c(colors, "colors_precomp"); opacity = _f32c(opacity, "opacities")
-    scales = _f32c(scales, "scales"); rotations = _f32c(rotations, "rotations")
-    cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp"); sh = _f32c(sh, "sh")
-    viewmatrix = _f32c(viewmatrix, "viewmatrix"); projmatrix = _f32c(projmatrix, "projmatrix")
-    campos = _f32c(campos, "campos"); background = _f32c(background, "bg")
-    if colors.numel() and (colors.ndimension() != 2 or colors.size(1) != 3):
-        raise RuntimeError("colors_precomp must have dimensions (num_points, 3)")   # NUM_CHANNELS == 3, config.h:15
-    for t, name in ((colors, "colors_precomp"), (opacity, "opacities"), (scales, "scales"), (rotations, "rotations"),
-                    (cov3D_precomp, "cov3D_precomp"), (sh, "sh")):
-        if t.numel():
-            _require_device(t, name)
-
-    with torch.cuda.device(dev):
-        fo = dict(dtype=torch.float32, device=dev)
-        out_color = torch.empty((3, H, W), **fo)
-        out_depth = torch.empty((1, H, W), **fo)
-        out_median = torch.empty((3, H, W), **fo)
-        out_opacity = torch.empty((1, H, W), **fo)
-        radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        geom, binning, img = _Buf(dev), _Buf(dev), _Buf(dev)
-        M = sh.size(1) if sh.numel() != 0 and sh.size(0) != 0 else 0     # rasterize_points.cu:86-90
-        rc = L.gsr_forward(geom.cb, None, binning.cb, None, img.cb, None,
-                           ctypes.c_int(P), ctypes.c_int(int(degree)), ctypes.c_int(M), _ptr(background),
-                           ctypes.c_int(W), ctypes.c_int(H), _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
-                           _ptr(scales), ctypes.c_float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
-                           _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), ctypes.c_float(tan_fovx),
-                           ctypes.c_float(tan_fovy), ctypes.c_int(bool(prefiltered)), _ptr(out_color),
-                           _ptr(out_depth), _ptr(out_median), _ptr(out_opacity), _ptr(radii),
-                           ctypes.c_int(bool(debug)), _stream(dev))
-    if rc < 0:
-        raise _err(L, rc)
-    return rc, out_color, out_depth, out_median, out_opacity, radii, geom.t, binning.t, img.t
+    """RasterizeGaussiansCUDA, rasterize_points.cu:35-121 -> csrc/torch_binding.cpp RasterizeGaussians."""
+    return native().rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier),
+                                        cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
+                                        int(image_height), int(image_width), sh, int(degree), campos,
+                                        bool(prefiltered), bool(debug))
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
                                  binningBuffer, imageBuffer, debug):
-    """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:123-210."""
-    L = lib()
-    _require_device(means3D, "means3D")
-    dev = means3D.device
-    P = means3D.size(0)
-    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
-    M = sh.size(1) if sh.numel() != 0 and sh.size(0) != 0 else 0
-    means3D = _f32c(means3D, "means3D"); colors = _f32c(colors, "colors_precomp")
-    scales = _f32c(scales, "scales"); rotations = _f32c(rotations, "rotations")
-    cov3D_precomp = _f32c(cov3D_precomp, "cov3D_precomp"); sh = _f32c(sh, "sh")
-    background = _f32c(background, "bg")
-    g_color = _f32c(dL_dout_color, "dL_dout_color"); g_depth = _f32c(dL_dout_depth, "dL_dout_depth")
-    g_median = _f32c(dL_dout_median_depth, "dL_dout_median_depth")
-    g_op = _f32c(dL_dout_final_opacity, "dL_dout_final_opacity")
-    radii = radii.contiguous()
-    with torch.cuda.device(dev):
-        fo = dict(dtype=torch.float32, device=dev)
-        dL_dmeans3D = torch.empty((P, 3), **fo)
-        dL_dmeans2D = torch.empty((P, 3), **fo)
-        dL_dcolors = torch.empty((P, 3), **fo)
-        dL_dopacity = torch.empty((P, 1), **fo)
-        dL_dcov3D = torch.empty((P, 6), **fo)
-        dL_dsh = torch.empty((P, M, 3), **fo)
-        dL_dscales = torch.empty((P, 3), **fo)
-        dL_drotations = torch.empty((P, 4), **fo)
-        if P != 0:
-            scratch = torch.empty(L.gsr_backward_scratch_bytes(ctypes.c_int(P), ctypes.c_int(int(R))), dtype=torch.uint8,
-                                  device=dev)
-            rc = L.gsr_backward(ctypes.c_int(P), ctypes.c_int(int(degree)), ctypes.c_int(M), ctypes.c_int(int(R)),
-                                _ptr(background), ctypes.c_int(W), ctypes.c_int(H), _ptr(means3D), _ptr(sh),
-                                _ptr(colors), _ptr(scales), ctypes.c_float(scale_modifier), _ptr(rotations),
-                                _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
-                                ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), _ptr(radii),
-                                _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(g_color),
-                                _ptr(g_depth), _ptr(g_median), _ptr(g_op), _ptr(dL_dmeans2D), _ptr(dL_dopacity),
-                                _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
-                                _ptr(dL_dscales), _ptr(dL_drotations), _ptr(scratch), ctypes.c_int(bool(debug)),
-                                _stream(dev))
-            if rc < 0:
-                raise _err(L, rc)
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:123-210 -> torch_binding.cpp RasterizeGaussiansBackward."""
+    return native().rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations,
+                                                 float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix,
+                                                 float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth,
+                                                 dL_dout_median_depth, dL_dout_final_opacity, sh, int(degree), campos,
+                                                 geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
-    """markVisible, rasterize_points.cu:212-231."""
-    L = lib()
-    _require_device(means3D, "means3D")
-    dev = means3D.device
-    P = means3D.size(0)
-    means3D = _f32c(means3D, "means3D")
-    viewmatrix = _f32c(viewmatrix, "viewmatrix"); projmatrix = _f32c(projmatrix, "projmatrix")
-    present = torch.zeros((P,), dtype=torch.bool, device=dev)
-    if P != 0:
-        with torch.cuda.device(dev):
-            rc = L.gsr_mark_visible(ctypes.c_int(P), _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix),
-                                    _ptr(present), _stream(dev))
-        if rc < 0:
-            raise _err(L, rc)
-    return present
+    """markVisible, rasterize_points.cu:212-231 -> torch_binding.cpp markVisible."""
+    return native().mark_visible(means3D, viewmatrix, projmatrix)
 
 
 # ---- introspection of the opaque buffers (tests / debugging; include/gsrast.h gsr_inspect_*) ----

@@ -1,0 +1,174 @@
+// torch_binding.cpp -- the native torch adapter over the C ABI of libgsrast.so (include/gsrast.h).
+//
+// Replaces $RAST/rasterize_points.cu:35-231 + $RAST/ext.cpp:15-19: same three entry points, same argument
+// order, same return tuples.  Host code only (no device code, no hipify): shape checks, output allocation
+// through torch's caching allocator, torch's CURRENT HIP stream.  Built by `make -C gaustudio_amd/csrc` into
+// gaustudio_amd/_Cnative*.so and loaded by gaustudio_amd/_C.py.
+#include <torch/extension.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include <stdexcept>
+#include <string>
+#include <tuple>
+
+#include "../../include/gsrast.h"
+
+namespace {
+
+// replaces resizeFunctional (rasterize_points.cu:27-33)
+char* resize_cb(void* ctx, size_t n)
+{
+	auto* t = static_cast<torch::Tensor*>(ctx);
+	try {
+		t->resize_({(long long)n});
+	} catch (...) {
+		return nullptr;
+	}
+	return reinterpret_cast<char*>(t->data_ptr());
+}
+
+// "absent" = empty tensor (the reference passes torch.Tensor([]) whose data_ptr is null, __init__.py:200-210)
+const float* fptr(const torch::Tensor& t, const char* name)
+{
+	if (t.numel() == 0) return nullptr;
+	TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " must be float32 (got ", t.scalar_type(), ")");
+	TORCH_CHECK(t.is_contiguous(), name, " must be contiguous here (made so by the caller)");
+	return t.data_ptr<float>();
+}
+
+void require_device(const torch::Tensor& t, const char* name)
+{
+	TORCH_CHECK(t.is_cuda(), name, " is on '", t.device(), "': gaustudio_amd runs on ROCm devices only "
+	            "(hand-written HIP kernels, no CPU fallback)");
+}
+
+[[noreturn]] void fail(int rc)
+{
+	throw std::runtime_error(std::string(gsr_last_error()) + " [gsrast rc=" + std::to_string(rc) + "]");
+}
+
+void* current_stream(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
+
+}  // namespace
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D_, const torch::Tensor& colors_,
+                   const torch::Tensor& opacity_, const torch::Tensor& scales_, const torch::Tensor& rotations_,
+                   const float scale_modifier, const torch::Tensor& cov3D_precomp_, const torch::Tensor& viewmatrix_,
+                   const torch::Tensor& projmatrix_, const float tan_fovx, const float tan_fovy, const int image_height,
+                   const int image_width, const torch::Tensor& sh_, const int degree, const torch::Tensor& campos_,
+                   const bool prefiltered, const bool debug)
+{
+	if (means3D_.ndimension() != 2 || means3D_.size(1) != 3) {
+		AT_ERROR("means3D must have dimensions (num_points, 3)");   // rasterize_points.cu:57-59
+	}
+	require_device(means3D_, "means3D");
+	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
+	const int P = means3D_.size(0), H = image_height, W = image_width;
+	const auto means3D = means3D_.contiguous(), colors = colors_.contiguous(), opacity = opacity_.contiguous();
+	const auto scales = scales_.contiguous(), rotations = rotations_.contiguous();
+	const auto cov3D_precomp = cov3D_precomp_.contiguous(), sh = sh_.contiguous();
+	const auto viewmatrix = viewmatrix_.contiguous(), projmatrix = projmatrix_.contiguous();
+	const auto campos = campos_.contiguous(), bg = background.contiguous();
+	if (colors.numel() != 0 && (colors.ndimension() != 2 || colors.size(1) != 3))
+		AT_ERROR("colors_precomp must have dimensions (num_points, 3)");   // NUM_CHANNELS == 3, config.h:15
+	for (const auto& p : {std::make_pair(&colors, "colors_precomp"), std::make_pair(&opacity, "opacities"),
+	                      std::make_pair(&scales, "scales"), std::make_pair(&rotations, "rotations"),
+	                      std::make_pair(&cov3D_precomp, "cov3D_precomp"), std::make_pair(&sh, "sh")})
+		if (p.first->numel() != 0) require_device(*p.first, p.second);
+
+	const auto fo = means3D.options().dtype(torch::kFloat32);
+	torch::Tensor out_color = torch::empty({3, H, W}, fo);      // fully overwritten by the library
+	torch::Tensor out_depth = torch::empty({1, H, W}, fo);
+	torch::Tensor out_median = torch::empty({3, H, W}, fo);
+	torch::Tensor out_opacity = torch::empty({1, H, W}, fo);
+	torch::Tensor radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
+	const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
+	torch::Tensor geom = torch::empty({0}, bo), binning = torch::empty({0}, bo), img = torch::empty({0}, bo);
+	const int M = (sh.numel() != 0 && sh.size(0) != 0) ? (int)sh.size(1) : 0;   // rasterize_points.cu:86-90
+
+	const int rc = gsr_forward(resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, degree, M, fptr(bg, "bg"), W, H,
+	                           fptr(means3D, "means3D"), fptr(sh, "sh"), fptr(colors, "colors_precomp"),
+	                           fptr(opacity, "opacities"), fptr(scales, "scales"), scale_modifier,
+	                           fptr(rotations, "rotations"), fptr(cov3D_precomp, "cov3D_precomp"),
+	                           fptr(viewmatrix, "viewmatrix"), fptr(projmatrix, "projmatrix"), fptr(campos, "campos"),
+	                           tan_fovx, tan_fovy, prefiltered ? 1 : 0, out_color.data_ptr<float>(),
+	                           out_depth.data_ptr<float>(), out_median.data_ptr<float>(), out_opacity.data_ptr<float>(),
+	                           P ? radii.data_ptr<int>() : nullptr, debug ? 1 : 0, current_stream(means3D));
+	if (rc < 0) fail(rc);
+	return std::make_tuple(rc, out_color, out_depth, out_median, out_opacity, radii, geom, binning, img);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor& means3D_, const torch::Tensor& radii_,
+                           const torch::Tensor& colors_, const torch::Tensor& scales_, const torch::Tensor& rotations_,
+                           const float scale_modifier, const torch::Tensor& cov3D_precomp_,
+                           const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, const float tan_fovx,
+                           const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_depth,
+                           const torch::Tensor& dL_dout_median_depth, const torch::Tensor& dL_dout_final_opacity,
+                           const torch::Tensor& sh_, const int degree, const torch::Tensor& campos_,
+                           const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer,
+                           const torch::Tensor& imageBuffer, const bool debug)
+{
+	require_device(means3D_, "means3D");
+	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
+	const int P = means3D_.size(0);
+	const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+	const auto means3D = means3D_.contiguous(), colors = colors_.contiguous(), scales = scales_.contiguous();
+	const auto rotations = rotations_.contiguous(), cov3D_precomp = cov3D_precomp_.contiguous(), sh = sh_.contiguous();
+	const auto viewmatrix = viewmatrix_.contiguous(), projmatrix = projmatrix_.contiguous();
+	const auto campos = campos_.contiguous(), bg = background.contiguous(), radii = radii_.contiguous();
+	const auto g_color = dL_dout_color.contiguous(), g_depth = dL_dout_depth.contiguous();
+	const auto g_median = dL_dout_median_depth.contiguous(), g_op = dL_dout_final_opacity.contiguous();
+	const int M = (sh.numel() != 0 && sh.size(0) != 0) ? (int)sh.size(1) : 0;
+
+	const auto fo = means3D.options().dtype(torch::kFloat32);
+	// torch::empty: the library writes every row (zeros for culled Gaussians); the reference needed torch::zeros
+	torch::Tensor dL_dmeans3D = torch::empty({P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
+	torch::Tensor dL_dcolors = torch::empty({P, 3}, fo), dL_dopacity = torch::empty({P, 1}, fo);
+	torch::Tensor dL_dcov3D = torch::empty({P, 6}, fo), dL_dsh = torch::empty({P, M, 3}, fo);
+	torch::Tensor dL_dscales = torch::empty({P, 3}, fo), dL_drotations = torch::empty({P, 4}, fo);
+	if (P != 0) {
+		const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
+		torch::Tensor scratch = torch::empty({(long long)gsr_backward_scratch_bytes(P, R)}, bo);
+		const int rc = gsr_backward(
+		    P, degree, M, R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(sh, "sh"), fptr(colors, "colors_precomp"),
+		    fptr(scales, "scales"), scale_modifier, fptr(rotations, "rotations"), fptr(cov3D_precomp, "cov3D_precomp"),
+		    fptr(viewmatrix, "viewmatrix"), fptr(projmatrix, "projmatrix"), fptr(campos, "campos"), tan_fovx, tan_fovy,
+		    radii.data_ptr<int>(), reinterpret_cast<const char*>(geomBuffer.data_ptr()),
+		    reinterpret_cast<const char*>(binningBuffer.data_ptr()), reinterpret_cast<const char*>(imageBuffer.data_ptr()),
+		    fptr(g_color, "dL_dout_color"), fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"),
+		    fptr(g_op, "dL_dout_final_opacity"), dL_dmeans2D.data_ptr<float>(), dL_dopacity.data_ptr<float>(),
+		    dL_dcolors.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(),
+		    M ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(),
+		    reinterpret_cast<char*>(scratch.data_ptr()), debug ? 1 : 0, current_stream(means3D));
+		if (rc < 0) fail(rc);
+	}
+	return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+}
+
+torch::Tensor markVisible(torch::Tensor& means3D_, torch::Tensor& viewmatrix_, torch::Tensor& projmatrix_)
+{
+	require_device(means3D_, "means3D");
+	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
+	const int P = means3D_.size(0);
+	const auto means3D = means3D_.contiguous(), viewmatrix = viewmatrix_.contiguous(), projmatrix = projmatrix_.contiguous();
+	torch::Tensor present = torch::full({P}, false, means3D.options().dtype(at::kBool));
+	if (P != 0) {
+		const int rc = gsr_mark_visible(P, fptr(means3D, "means3D"), fptr(viewmatrix, "viewmatrix"),
+		                                fptr(projmatrix, "projmatrix"), reinterpret_cast<unsigned char*>(present.data_ptr()),
+		                                current_stream(means3D));
+		if (rc < 0) fail(rc);
+	}
+	return present;
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+	m.def("rasterize_gaussians", &RasterizeGaussians);
+	m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
+	m.def("mark_visible", &markVisible);
+}

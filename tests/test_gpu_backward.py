@@ -124,3 +124,20 @@ def test_autograd_function_end_to_end(oracle):
         assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max(), k
     a = to_np(means2D.grad); b = ob["dL_dmeans2D"]
     assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
+
+
+def test_backward_is_run_to_run_deterministic():
+    """The reference's float atomicAdd makes its gradients order-dependent.  Here every sum has a fixed order:
+    DPP / lane-swap tree inside a wave, exactly two waves meeting per (tile, Gaussian) in LDS (a + b == b + a),
+    per-Gaussian rows added in ascending tile order -> bit-identical gradients on every run."""
+    cam = scenes.make_camera(800, 800)
+    sc = scenes.make_scene(300000, cam, seed=2)
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam)
+    hs = hip_forward(sc, cam, 3, kw)
+    a = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+    b = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+    hs2 = hip_forward(sc, cam, 3, kw)
+    c = hip_backward_raw(hs2, sc, cam, 3, kw, grads)
+    for k in GRAD_KEYS:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
