@@ -83,6 +83,32 @@ def cpu_baseline(sc, cam, D, grads, budget_s=20.0):
                       f"every {step}th 16x16 tile of the same frame ({tiles}/{T} tiles), per-Gaussian stages in full"}
 
 
+def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
+    """Achieved algorithmic GB/s of every stage against the 8 TB/s HBM roofline (BASELINE.md s4 byte counts; the
+    records are 64 B here instead of the reference's 48 B of SoA fields, counted as written)."""
+    sh = 12 * (D + 1) ** 2
+    HW = H * W
+    stages = {}
+    if fwd_ms:
+        b = {"preprocess": P * (12 + 12 + 16 + 4 + sh) + P_vis * (64 + 4 + 4),
+             "scatter": R * 8 + P_vis * 64, "sort": R * 12,
+             "composite": R * 44 + T * 8 + HW * 32 + (0 if fwd_only else HW * 8)}
+        for k, nbytes in b.items():
+            if fwd_ms.get(k):
+                gbs = nbytes / (fwd_ms[k] * 1e-3) / 1e9
+                stages[k + "_fwd" if k in ("preprocess", "composite") else k] = {
+                    "ms": round(fwd_ms[k], 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1), "frac_hbm": round(gbs / 8000.0, 4)}
+    if bwd_ms:
+        b = {"composite_bwd": R * 44 + HW * 32 + R * 48,
+             "preprocess_bwd": R * 48 + P_vis * (12 + 4 + sh + 64 + 12 + 16 + 8) + P * (12 + 4 + 12 + 12 + 24 + 12 * 16 + 12 + 16)}
+        for k, nbytes in b.items():
+            if bwd_ms.get(k):
+                gbs = nbytes / (bwd_ms[k] * 1e-3) / 1e9
+                stages[k] = {"ms": round(bwd_ms[k], 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1),
+                             "frac_hbm": round(gbs / 8000.0, 4)}
+    return stages
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +246,7 @@ def main():
                        "parallelism": f"one camera per GPU x{world}, 1 flat RCCL all-reduce of "
                                       f"{0 if bucket is None else bucket.nbytes} B/rank" if world > 1 else "single GPU"},
             "stage_ms": {"forward": fwd_ms, "backward": bwd_ms},
+            "stage_roofline": stage_roofline(P, vis, R, T, H, W, D, fwd_ms, bwd_ms, a.fwd_only),
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -1,0 +1,68 @@
+"""Post-render epilogue on the GPU: what gs-extract-mesh / gs-extract-pcd do right after
+the operator (gaustudio/scripts/extract_mesh.py:101-110, extract_pcd.py:325-329), as two HIP streaming kernels
+instead of ~15 torch ops with [H,W,3] intermediates.
+
+Mirrors gaustudio.datasets.Camera.depth2point / depth2normal (datasets/__init__.py:307-380): same arguments, with
+the camera given by its `intrinsics` [3,3] and `extrinsics` [4,4] (world-to-camera) tensors.
+"""
+import ctypes
+
+import torch
+
+from . import _C
+
+
+def _host16(t, n):
+    if t is None:
+        return None
+    a = (ctypes.c_float * n)(*[float(v) for v in t.detach().cpu().reshape(-1).tolist()])
+    return a
+
+
+def _check(depth):
+    if depth.dim() != 2:
+        raise ValueError("depth must have shape [H, W]")
+    if not depth.is_cuda:
+        raise RuntimeError(f"depth is on '{depth.device}': gaustudio_amd runs on ROCm devices only (no CPU fallback)")
+    if depth.dtype != torch.float32:
+        raise RuntimeError("depth must be float32")
+    return depth.contiguous()
+
+
+def depth_to_points(depth, intrinsics, extrinsics=None, coordinate="camera"):
+    """Camera.depth2point: [H,W] depth -> [H,W,3] points in 'camera' or 'world' coordinates."""
+    if coordinate not in ("camera", "world"):
+        raise ValueError("Invalid coordinate system.")
+    depth = _check(depth)
+    H, W = depth.shape
+    L = _C.lib()
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=depth.device)
+    K = _host16(intrinsics, 9)
+    E = _host16(extrinsics, 16) if coordinate == "world" else None
+    if coordinate == "world" and E is None:
+        raise ValueError("extrinsics are required for world coordinates")
+    with torch.cuda.device(depth.device):
+        rc = L.gsr_depth_to_points(_C._ptr(depth), ctypes.c_int(W), ctypes.c_int(H), K, E, _C._ptr(out), _C._stream(depth.device))
+    if rc < 0:
+        raise RuntimeError(f"gsr_depth_to_points failed (rc={rc}): singular intrinsics / extrinsics?")
+    return out
+
+
+def depth_to_normals(depth, intrinsics, extrinsics=None, k=3, d_min=1e-3, d_max=100000.0, coordinate="camera"):
+    """Camera.depth2normal: [H,W] depth -> [H,W,3] normals, (-1,-1,-1) where invalid."""
+    if coordinate not in ("camera", "world"):
+        raise ValueError("Invalid coordinate system.")
+    depth = _check(depth)
+    H, W = depth.shape
+    L = _C.lib()
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=depth.device)
+    K = _host16(intrinsics, 9)
+    E = _host16(extrinsics, 16) if coordinate == "world" else None
+    if coordinate == "world" and E is None:
+        raise ValueError("extrinsics are required for world coordinates")
+    with torch.cuda.device(depth.device):
+        rc = L.gsr_depth_to_normals(_C._ptr(depth), ctypes.c_int(W), ctypes.c_int(H), K, ctypes.c_int(int(k)),
+                                    ctypes.c_float(d_min), ctypes.c_float(d_max), E, _C._ptr(out), _C._stream(depth.device))
+    if rc < 0:
+        raise RuntimeError(f"gsr_depth_to_normals failed (rc={rc})")
+    return out

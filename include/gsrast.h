@@ -160,6 +160,21 @@ int gsr_inspect_binning(const char* binning_buffer, const char* image_buffer, in
 int gsr_inspect_image(const char* image_buffer, int width, int height, float* final_T,
                       uint32_t* n_contrib, void* stream);
 
+/* ---- post-render epilogue: the step that follows the operator in gs-extract-mesh /
+ * gs-extract-pcd.  `intrinsics` = 3x3 row-major K and `world_to_camera` = 4x4 row-major (Camera.extrinsics,
+ * gaustudio/datasets/__init__.py:225-237) are HOST pointers (25 floats); depth / outputs are device memory. ---- */
+
+/* Replaces Camera.depth2point(depth, 'camera' | 'world') (datasets/__init__.py:307-339 with ndc_2_cam :106-112):
+ * points[H,W,3]; world_to_camera == NULL -> camera coordinates. */
+int gsr_depth_to_points(const float* depth, int width, int height, const float* intrinsics,
+                        const float* world_to_camera, float* points, void* stream);
+
+/* Replaces Camera.depth2normal(depth, k, d_min, d_max, 'camera' | 'world') (datasets/__init__.py:342-380): five-tap
+ * cross-product normals[H,W,3] of the unprojected depth, (-1,-1,-1) where any tap is outside (d_min, d_max) or
+ * outside the image. */
+int gsr_depth_to_normals(const float* depth, int width, int height, const float* intrinsics, int k, float d_min,
+                         float d_max, const float* world_to_camera, float* normals, void* stream);
+
 /* Per-stage GPU time, averaged over every gsr_forward / gsr_backward call made on this thread since
  * gsr_set_profiling(1): milliseconds for {preprocess, scan(+readback), scatter, sort, composite} (forward)
  * or {composite_bwd, preprocess_bwd} (backward), measured with HIP events recorded on the launch stream.

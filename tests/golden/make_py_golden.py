@@ -75,5 +75,40 @@ def main():
     print("wrote", os.path.join(HERE, "py_sh_cov.npz"), os.path.getsize(os.path.join(HERE, "py_sh_cov.npz")) // 1024, "KiB")
 
 
+def make_post_golden():
+    """tests/golden/py_post.npz: Camera.depth2point / depth2normal of the reference
+    (/root/reference/gaustudio/datasets/__init__.py:307-380) on a synthetic depth map with holes."""
+    import sys
+    spec = importlib.util.spec_from_file_location("ref_datasets", os.path.join(REF, "datasets", "__init__.py"),
+                                                  submodule_search_locations=[])
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["ref_datasets"] = m
+    try:
+        spec.loader.exec_module(m)          # Camera is defined before the dataset loaders are imported (line 418)
+    except ModuleNotFoundError:
+        pass
+    Camera = m.Camera
+    g = torch.Generator().manual_seed(5)
+    W, H = 96, 64
+    a = 0.3
+    R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    cam = Camera(R=R, T=np.array([0.2, -0.1, 1.5]), FoVx=math.radians(60), FoVy=math.radians(42), image_width=W,
+                 image_height=H)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    depth = 3.0 + 0.5 * torch.sin(xx / 9.0) + 0.3 * torch.cos(yy / 7.0) + 0.02 * torch.randn(H, W, generator=g)
+    depth[torch.rand(H, W, generator=g) < 0.05] = 0.0          # holes (masked pixels are zeroed in extract_mesh.py:107)
+    out = dict(depth=depth.numpy(), intrinsics=cam.intrinsics.numpy(), extrinsics=cam.extrinsics.numpy())
+    out["points_camera"] = cam.depth2point(depth, coordinate="camera").numpy()
+    out["points_world"] = cam.depth2point(depth, coordinate="world").numpy()
+    out["normals_camera"] = cam.depth2normal(depth, coordinate="camera").numpy()
+    out["normals_world"] = cam.depth2normal(depth, coordinate="world").numpy()
+    out["normals_camera_k5"] = cam.depth2normal(depth, k=5, coordinate="camera").numpy()
+    path = os.path.join(HERE, "py_post.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
+    import math
     main()
+    make_post_golden()

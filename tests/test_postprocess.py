@@ -1,0 +1,88 @@
+"""Post-render epilogue: depth -> points / normals.
+CPU: the numpy restatement (oracle/post_oracle.py) against outputs of the reference's own Camera class
+(tests/golden/py_post.npz).  GPU: the HIP kernels (through the C ABI) against the same fixture and, at 1080p,
+against the restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "py_post.npz")
+TOL = 2e-5   # float32 torch (batched matmul, unknown contraction) vs our arithmetic, values are O(1..5)
+
+
+def _mask_eq(a, b):
+    inv_a = (a == -1).all(-1); inv_b = (b == -1).all(-1)
+    return inv_a, inv_b
+
+
+def test_numpy_restatement_matches_reference_camera():
+    from oracle import post_oracle as po
+    z = np.load(GOLD)
+    K, E, d = z["intrinsics"], z["extrinsics"], z["depth"]
+    assert np.abs(po.depth2point(d, K) - z["points_camera"]).max() < TOL
+    assert np.abs(po.depth2point(d, K, E) - z["points_world"]).max() < TOL
+    for key, kw in (("normals_camera", {}), ("normals_world", dict(w2c=E)), ("normals_camera_k5", dict(k=5))):
+        n = po.depth2normal(d, K, **kw)
+        ia, ib = _mask_eq(n, z[key])
+        assert np.array_equal(ia, ib), key
+        assert np.abs(n - z[key]).max() < 1e-4, key
+        assert 0.05 < ia.mean() < 0.6
+
+
+@pytest.mark.gpu
+def test_hip_epilogue_matches_reference_camera_fixture():
+    from gaustudio_amd import postprocess as pp
+    z = np.load(GOLD)
+    K, E = torch.from_numpy(z["intrinsics"]), torch.from_numpy(z["extrinsics"])
+    d = torch.from_numpy(z["depth"]).cuda()
+    assert np.abs(pp.depth_to_points(d, K).cpu().numpy() - z["points_camera"]).max() < TOL
+    assert np.abs(pp.depth_to_points(d, K, E, "world").cpu().numpy() - z["points_world"]).max() < TOL
+    for key, kw in (("normals_camera", {}), ("normals_world", dict(extrinsics=E, coordinate="world")),
+                    ("normals_camera_k5", dict(k=5))):
+        n = pp.depth_to_normals(d, K, **kw).cpu().numpy()
+        ia, ib = _mask_eq(n, z[key])
+        assert np.array_equal(ia, ib), key
+        assert np.abs(n - z[key]).max() < 1e-4, key
+
+
+@pytest.mark.gpu
+def test_hip_epilogue_on_a_rendered_1080p_depth_and_throughput():
+    """The gs-extract-mesh sequence on the C3 frame: render -> median depth -> mask -> world points / normals."""
+    from oracle import post_oracle as po
+    from gaustudio_amd import postprocess as pp, scenes
+    from util import hip_forward, scene_kwargs
+    cam = scenes.make_camera(1920, 1080)
+    sc = scenes.make_scene(200000, cam, seed=0, sigma_px_median=3.0)
+    hs = hip_forward(sc, cam, 0, scene_kwargs(sc, True, False))
+    depth = hs["median"][0].clone()
+    depth[hs["opacity"][0] < 0.5] = 0.0                                   # extract_mesh.py:104-107
+    fx, fy = 1920 / (2 * cam.tanfovx), 1080 / (2 * cam.tanfovy)
+    K = torch.tensor([[fx, 0, 960.0], [0, fy, 540.0], [0, 0, 1]])
+    E = cam.viewmatrix.t().contiguous()                                   # Camera.extrinsics = world_view_transform^T
+    pts = pp.depth_to_points(depth, K, E, "world")
+    nrm = pp.depth_to_normals(depth, K, E, coordinate="world")
+    dn = depth.cpu().numpy()
+    assert np.abs(pts.cpu().numpy() - po.depth2point(dn, K.numpy(), E.numpy())).max() < 1e-4
+    ref_n = po.depth2normal(dn, K.numpy(), E.numpy())
+    got_n = nrm.cpu().numpy()
+    ia, ib = _mask_eq(got_n, ref_n)
+    assert (ia != ib).mean() < 1e-5 and np.abs(got_n - ref_n)[~(ia | ib)].max() < 2e-3
+    # throughput: 4 B read + 12 B written per pixel
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(50):
+        pp.depth_to_normals(depth, K, E, coordinate="world")
+    ev[1].record(); torch.cuda.synchronize()
+    us = ev[0].elapsed_time(ev[1]) / 50 * 1e3
+    print(f"depth_to_normals 1080p: {us:.1f} us -> {1920 * 1080 * 16 / us / 1e3:.0f} GB/s")
+
+
+def test_epilogue_rejects_cpu_tensors():
+    from gaustudio_amd import postprocess as pp
+    with pytest.raises(RuntimeError, match="ROCm devices only"):
+        pp.depth_to_points(torch.zeros(4, 4), torch.eye(3))
+    with pytest.raises(ValueError, match="Invalid coordinate"):
+        pp.depth_to_points(torch.zeros(4, 4), torch.eye(3), coordinate="ndc")
