@@ -248,11 +248,3 @@ __device__ __forceinline__ bool gs_box_may_touch(const float4 A, const float4 B,
 	}
 	return best >= pcut - (0.05f + 1e-5f * mag);
 }
-
-// 64-lane sum, result valid in every lane (butterfly over DPP-free shuffles; gfx950 wave64).
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-	return v;
-}

@@ -432,24 +432,19 @@ void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-tile sort.  Normalised bitonic network (every comparator ascending), so that virtual +inf
-// padding beyond n never moves and arbitrary n needs no padding storage.
-//   MODE 0: n <= cap (dynamic LDS of cap keys)      MODE 1: any n, in place in global memory.
-template <int MODE>
-__global__ __launch_bounds__(256) void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ point_list, uint32_t lo, uint32_t hi)
+// Per-tile sort of short lists (n <= hi <= GSR_SORT_LDS_MAX keys) in LDS.  Normalised bitonic network (every
+// comparator ascending), so that virtual +inf padding beyond n never moves and arbitrary n needs no padding.
+__global__ __launch_bounds__(256) void tile_sort_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ point_list, uint32_t hi)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
+	uint64_t* a = reinterpret_cast<uint64_t*>(smem_raw);
 	const uint2 range = ranges[blockIdx.x];
 	const uint32_t n = range.y - range.x;
-	if (n <= lo || n > hi) return;   // handled by another launch (or empty)
+	if (n == 0 || n > hi) return;   // empty, or handled by tile_radix_sort
 	const uint32_t tid = threadIdx.x;
-	uint64_t* g = keys + range.x;
-	uint64_t* a = MODE == 0 ? s : g;
-	if (MODE == 0) {
-		for (uint32_t i = tid; i < n; i += 256) s[i] = g[i];
-	}
+	const uint64_t* g = keys + range.x;
+	for (uint32_t i = tid; i < n; i += 256) a[i] = g[i];
 	__syncthreads();
 	uint32_t npad = 2;
 	while (npad < n) npad <<= 1;
@@ -575,9 +570,9 @@ void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint6
                       uint32_t* point_list, hipStream_t s)
 {
 	if (max_tile_count == 0) return;
-	// <= GSR_SORT_LDS_MAX keys: bitonic network in LDS (32 KiB, several workgroups per CU); longer: radix path
-	const uint32_t cap = max_tile_count < GSR_SORT_LDS_MAX ? max(256u, max_tile_count) : GSR_SORT_LDS_MAX;
-	hipLaunchKernelGGL(tile_sort_kernel<0>, dim3(T), dim3(256), cap * sizeof(uint64_t), s, ranges, keys, point_list, 0u,
+	// <= GSR_SORT_LDS_MAX keys: bitonic network in LDS (<= 8 KiB, many workgroups per CU); longer: radix path
+	const uint32_t cap = max_tile_count < GSR_SORT_LDS_MAX ? max(256u, max_tile_count) : GSR_SORT_LDS_MAX;   // LDS keys
+	hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(256), cap * sizeof(uint64_t), s, ranges, keys, point_list,
 	                   GSR_SORT_LDS_MAX);
 	if (max_tile_count > GSR_SORT_LDS_MAX)
 		hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list,
