@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void inspect_image_kernel(int gx, int W, int H
 
 extern "C" {
 
-int gsr_abi_version(void) { return 2; }
+int gsr_abi_version(void) { return 3; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -251,13 +251,14 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 	return GSR_OK;
 }
 
-int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
-                gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
-                int height, const float* means3D, const float* shs, const float* colors_precomp,
-                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth,
-                float* out_median_depth, float* out_opacity, int* radii, int debug, void* stream)
+static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
+                        gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                        int width, int height, const float* means3D, const float* shs, const float* shs_rest,
+                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, int activation_flags,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                        float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_median_depth,
+                        float* out_opacity, int* radii, int debug, void* stream)
 {
 	hipStream_t s = (hipStream_t)stream;
 	g_err.clear();
@@ -316,6 +317,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
 	a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
 	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.prefiltered = prefiltered;
+	a.shs_rest = shs_rest; a.act = activation_flags;
 
 	tm.mark();
 	uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + gl.tiles_touched);
@@ -369,24 +371,54 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 	return (int)R;
 }
 
+int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
+                gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth,
+                float* out_median_depth, float* out_opacity, int* radii, int debug, void* stream)
+{
+	return forward_impl(geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
+	                    background, width, height, means3D, shs, nullptr, colors_precomp, opacities, scales,
+	                    scale_modifier, rotations, cov3D_precomp, 0, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+	                    prefiltered, out_color, out_depth, out_median_depth, out_opacity, radii, debug, stream);
+}
+
+int gsr_forward_raw(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
+                    gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                    int height, const float* means3D, const float* f_dc, const float* f_rest, const float* raw_opacities,
+                    const float* raw_scales, float scale_modifier, const float* raw_rotations, int activation_flags,
+                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                    float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_median_depth,
+                    float* out_opacity, int* radii, int debug, void* stream)
+{
+	if (P > 0 && (!f_dc || (M > 1 && !f_rest) || !raw_scales || !raw_rotations))
+		return fail(GSR_ERR_ARG, "gsr_forward_raw: f_dc, f_rest, raw_scales and raw_rotations are required", __FILE__, __LINE__);
+	return forward_impl(geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
+	                    background, width, height, means3D, f_dc, M > 1 ? f_rest : nullptr, nullptr, raw_opacities,
+	                    raw_scales, scale_modifier, raw_rotations, nullptr, activation_flags, viewmatrix, projmatrix, cam_pos,
+	                    tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_median_depth, out_opacity, radii, debug,
+	                    stream);
+}
+
 size_t gsr_backward_scratch_bytes(int P, int R)
 {
 	return BwdLayout((size_t)(P > 0 ? P : 0), (size_t)(R > 0 ? R : 0)).total;
 }
 
-int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
-                 const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
-                 const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_median_depth,
-                 const float* dL_dpix_final_opacity, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
-                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                 char* scratch, int debug, void* stream)
+static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
+                         const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                         int activation_flags, float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
+                         const char* binning_buffer, const char* image_buffer, const float* dL_dpix,
+                         const float* dL_dpix_depth, const float* dL_dpix_median_depth,
+                         const float* dL_dpix_final_opacity, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                         float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
+                         float* dL_drot, char* scratch, int debug, void* stream)
 {
 	hipStream_t s = (hipStream_t)stream;
 	g_err.clear();
-	(void)viewmatrix; (void)projmatrix; (void)campos;   // the device copies made by gsr_forward are used
 	if (P <= 0) return GSR_OK;   // rasterize_points.cu:171
 	if (!geom_buffer || !image_buffer || !binning_buffer || !scratch || !radii || !means3D)
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL buffer", __FILE__, __LINE__);
@@ -432,6 +464,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
 	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
 	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.radii = radii;
+	a.shs_rest = shs_rest; a.act = activation_flags;
 
 	tm.mark();
 	if (R > 0) {
@@ -441,10 +474,46 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 	}
 	tm.mark();
 	launch_preprocess_bwd(a, cam, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-	                      dL_dscale, dL_drot, s);
+	                      dL_dsh_rest, dL_dscale, dL_drot, s);
 	STAGE_CHECK("preprocess_bwd", debug, s);
 	tm.mark();
 	return GSR_OK;
+}
+
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                 const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_median_depth,
+                 const float* dL_dpix_final_opacity, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 char* scratch, int debug, void* stream)
+{
+	(void)viewmatrix; (void)projmatrix; (void)campos;   // the device copies made by gsr_forward are used
+	return backward_impl(P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp, scales,
+	                     scale_modifier, rotations, cov3D_precomp, 0, tan_fovx, tan_fovy, radii, geom_buffer,
+	                     binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
+	                     dL_dpix_final_opacity, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+	                     nullptr, dL_dscale, dL_drot, scratch, debug, stream);
+}
+
+int gsr_backward_raw(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                     const float* f_dc, const float* f_rest, const float* raw_scales, float scale_modifier,
+                     const float* raw_rotations, int activation_flags, float tan_fovx, float tan_fovy,
+                     const int* radii, const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                     const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_median_depth,
+                     const float* dL_dpix_final_opacity, float* dL_dmean2D, float* dL_draw_opacity, float* dL_dcolor,
+                     float* dL_dmean3D, float* dL_dcov3D, float* dL_df_dc, float* dL_df_rest, float* dL_draw_scale,
+                     float* dL_draw_rot, char* scratch, int debug, void* stream)
+{
+	if (P > 0 && (!f_dc || (M > 1 && (!f_rest || !dL_df_rest)) || !dL_df_dc))
+		return fail(GSR_ERR_ARG, "gsr_backward_raw: f_dc / f_rest and their gradient outputs are required", __FILE__, __LINE__);
+	return backward_impl(P, D, M, R, background, width, height, means3D, f_dc, M > 1 ? f_rest : nullptr, nullptr, raw_scales,
+	                     scale_modifier, raw_rotations, nullptr, activation_flags, tan_fovx, tan_fovy, radii, geom_buffer,
+	                     binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
+	                     dL_dpix_final_opacity, dL_dmean2D, dL_draw_opacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_df_dc,
+	                     M > 1 ? dL_df_rest : nullptr, dL_draw_scale, dL_draw_rot, scratch, debug, stream);
 }
 
 int gsr_inspect_geometry(const char* geom_buffer, int P, const int* radii, float* means2D, float* depths,

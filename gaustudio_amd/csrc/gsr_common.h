@@ -163,6 +163,33 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float3 scale, float m
 	cov3D[5] = Sg.m[2][2];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused parameter activations: the operator can read GauStudio's RAW point-cloud
+// attributes and apply VanillaPointCloud's activations itself (gaustudio/models/vanilla_sg.py:33-37,58-63 ->
+// models/utils.py:6-31: exp / sigmoid / F.normalize) instead of having torch materialise activated copies.
+// ---------------------------------------------------------------------------------------------
+#define GSR_ACT_OPACITY_SIGMOID 1   // opacity = 1 / (1 + exp(-x))
+#define GSR_ACT_SCALE_EXP 2         // scale   = exp(x)
+#define GSR_ACT_ROT_NORMALIZE 4     // rot     = x / max(||x||_2, 1e-12)      (F.normalize defaults)
+
+__device__ __forceinline__ float gs_act_opacity(float x, int act) { return (act & GSR_ACT_OPACITY_SIGMOID) ? 1.0f / (1.0f + expf(-x)) : x; }
+__device__ __forceinline__ float3 gs_act_scale(float3 s, int act)
+{
+	if (act & GSR_ACT_SCALE_EXP) { s.x = expf(s.x); s.y = expf(s.y); s.z = expf(s.z); }
+	return s;
+}
+// returns the activated quaternion; *inv_len = 1 / max(||q||, eps) (1 when no activation)
+__device__ __forceinline__ float4 gs_act_rot(float4 q, int act, float* inv_len)
+{
+	*inv_len = 1.0f;
+	if (act & GSR_ACT_ROT_NORMALIZE) {
+		const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+		*inv_len = 1.0f / n;
+		q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+	}
+	return q;
+}
+
 struct Cov2D {
 	float3 t;
 	float txtz, tytz, limx, limy;

@@ -70,6 +70,8 @@ struct FwdArgs {
 	const float* cov3D_precomp;
 	float tan_fovx, tan_fovy;
 	int prefiltered;
+	const float* shs_rest;   // f1: SH given as [P,1,3] (shs) + [P,M-1,3] (shs_rest); nullptr = shs holds all M
+	int act;                 // f1: GSR_ACT_* flags
 };
 
 // --- launchers (gsr_kernels_fwd.hip) ---
@@ -105,6 +107,8 @@ struct BwdArgs {
 	const float* cov3D_precomp;
 	float tan_fovx, tan_fovy;
 	const int* radii;
+	const float* shs_rest;
+	int act;
 };
 // Backward data flow (no global atomics): composite_bwd leaves ONE 48-B row of partial sums per
 // (tile, Gaussian) instance, stored in GAUSSIAN-MAJOR order: row index = goff[g] + k, where goff is
@@ -135,8 +139,8 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
                            const float* rows, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
-                           float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                           hipStream_t s);
+                           float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
+                           float* dL_drot, hipStream_t s);
 void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint32_t* goff, const float* rows,
                          float* sums10, hipStream_t s);
 

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
     const float* __restrict__ cov3D_precomp, const GsCam* __restrict__ cam, int W, int H, float tan_fovx,
-    float tan_fovy, float h_x, float h_y, int sh_vec4, const GsRec* __restrict__ recs,
+    float tan_fovy, float h_x, float h_y, int sh_vec4, int act, const GsRec* __restrict__ recs,
     const uint32_t* __restrict__ goff, const float* __restrict__ rows,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
@@ -437,7 +437,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 	dL_dmean2D[3 * (size_t)idx] = a_[0];
 	dL_dmean2D[3 * (size_t)idx + 1] = a_[1];
 	dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-	dL_dopacity[idx] = a_[5];
+	// f1: d/d(raw opacity) = dL_dopacity * op * (1 - op), op = sigmoid(raw) kept in the record
+	dL_dopacity[idx] = (vis && (act & GSR_ACT_OPACITY_SIGMOID)) ? a_[5] * recs[idx].q1.y * (1.f - recs[idx].q1.y) : a_[5];
 	dL_dcolor[3 * (size_t)idx] = a_[6];
 	dL_dcolor[3 * (size_t)idx + 1] = a_[7];
 	dL_dcolor[3 * (size_t)idx + 2] = a_[8];
@@ -453,8 +454,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 #pragma unroll
 			for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
 		} else {
-			const float3 sc = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
-			const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+			float inv_len;
+			const float3 sc = gs_act_scale({scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]}, act);
+			const float4 q = gs_act_rot(*reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx), act, &inv_len);
 			cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);   // recomputed, bit-identical to forward
 		}
 		// ---- computeCov2DCUDA (backward.cu:144-274) ----
@@ -527,11 +529,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 
 		if (scales != nullptr) {
 			// computeCov3D backward (backward.cu:278-341)
-			const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+			float inv_len;
+			const float4 q = gs_act_rot(*reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx), act, &inv_len);
+			const float3 sa = gs_act_scale({scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]}, act);
 			const float r = q.x, x = q.y, y = q.z, z = q.w;
 			const M3 R = quat_to_R(q);
-			const float s[3] = {scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
-			                    scale_modifier * scales[3 * idx + 2]};
+			const float s[3] = {scale_modifier * sa.x, scale_modifier * sa.y, scale_modifier * sa.z};
 			M3 S;
 #pragma unroll
 			for (int ci = 0; ci < 3; ci++)
@@ -564,6 +567,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 			dq[2] = FMA(-4 * y, D_(2, 2) + D_(0, 0), FMA(2 * z, D_(1, 2) + D_(2, 1), FMA(2 * r, D_(2, 0) - D_(0, 2), 2 * x * (D_(1, 0) + D_(0, 1)))));
 			dq[3] = FMA(-4 * z, D_(1, 1) + D_(0, 0), FMA(2 * y, D_(1, 2) + D_(2, 1), FMA(2 * x, D_(2, 0) + D_(0, 2), 2 * r * (D_(0, 1) - D_(1, 0)))));
 #undef D_
+			// f1 chain rules: scale = exp(raw) -> * scale ; rot = raw / |raw| -> (g - q (q.g)) / |raw|
+			if (act & GSR_ACT_SCALE_EXP) { dscale[0] *= sa.x; dscale[1] *= sa.y; dscale[2] *= sa.z; }
+			if (act & GSR_ACT_ROT_NORMALIZE) {
+				const float qg = q.x * dq[0] + q.y * dq[1] + q.z * dq[2] + q.w * dq[3];
+				dq[0] = (dq[0] - q.x * qg) * inv_len; dq[1] = (dq[1] - q.y * qg) * inv_len;
+				dq[2] = (dq[2] - q.z * qg) * inv_len; dq[3] = (dq[3] - q.w * qg) * inv_len;
+			}
 		}
 	}
 #pragma unroll
@@ -579,159 +589,184 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 // SH part of the per-Gaussian backward (computeColorFromSH backward, backward.cu:20-139), its own kernel:
 // fused into preprocess_bwd it pushed that kernel to 146 VGPRs (3 waves/SIMD) for work that lives on
 // memory-level parallelism.  Runs after preprocess_bwd: reads dL_dcolor, adds its mean gradient to dL_dmeans.
+//
+// gs_sh_backward: from the SH coefficients `sh` (active degree D) returns dc[k] = d(rgb)/d(sh_k) (so that
+// dL_dsh[k][ch] = dc[k] * dRGB[ch]), dRGB = dL_dcolor with the clamped channels zeroed (Q12), and dmean_sh, the
+// gradient reaching the mean through the view direction (backward.cu:126-138).
+template <int D>
+__device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __restrict__ cam, uint32_t clamped,
+                                               const float* __restrict__ dLc, const float* sh, float* dc, float* dRGB,
+                                               float* dmean_sh)
+{
+		const float3 dir_orig = {m.x - cam->campos[0], m.y - cam->campos[1], m.z - cam->campos[2]};
+		const float len = sqrtf(FMA(dir_orig.z, dir_orig.z, FMA(dir_orig.y, dir_orig.y, dir_orig.x * dir_orig.x)));
+		const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) dRGB[ch] = dLc[ch] * (((clamped >> ch) & 1u) ? 0.f : 1.f);
+		float dRGBdx[3] = {0.f, 0.f, 0.f}, dRGBdy[3] = {0.f, 0.f, 0.f}, dRGBdz[3] = {0.f, 0.f, 0.f};
+#define SH(k) sh[(k) * 3 + ch]
+#define DSH(k, coef) dc[k] = (coef)
+		DSH(0, bSH_C0);
+		if (D > 0) {
+			const float d1_ = -bSH_C1 * y, d2_ = bSH_C1 * z, d3_ = -bSH_C1 * x;
+			DSH(1, d1_); DSH(2, d2_); DSH(3, d3_);
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) {
+				dRGBdx[ch] = -bSH_C1 * SH(3);
+				dRGBdy[ch] = -bSH_C1 * SH(1);
+				dRGBdz[ch] = bSH_C1 * SH(2);
+			}
+			if (D > 1) {
+				const float xx = x * x, yy = y * y, zz = z * z;
+				const float xy = x * y, yz = y * z, xz = x * z;
+				const float d4_ = bSH_C2[0] * xy, d5_ = bSH_C2[1] * yz;
+				const float d6_ = bSH_C2[2] * (FMA(2.f, zz, -xx) - yy);
+				const float d7_ = bSH_C2[3] * xz, d8_ = bSH_C2[4] * (xx - yy);
+				DSH(4, d4_); DSH(5, d5_); DSH(6, d6_); DSH(7, d7_); DSH(8, d8_);
+#pragma unroll
+				for (int ch = 0; ch < 3; ch++) {
+					dRGBdx[ch] += FMA(bSH_C2[4] * 2.f * x, SH(8), FMA(bSH_C2[3] * z, SH(7), FMA(bSH_C2[2] * 2.f * -x, SH(6), bSH_C2[0] * y * SH(4))));
+					dRGBdy[ch] += FMA(bSH_C2[4] * 2.f * -y, SH(8), FMA(bSH_C2[2] * 2.f * -y, SH(6), FMA(bSH_C2[1] * z, SH(5), bSH_C2[0] * x * SH(4))));
+					dRGBdz[ch] += FMA(bSH_C2[3] * x, SH(7), FMA(bSH_C2[2] * 2.f * 2.f * z, SH(6), bSH_C2[1] * y * SH(5)));
+				}
+				if (D > 2) {
+					const float d9_ = bSH_C3[0] * y * FMA(3.f, xx, -yy);
+					const float d10_ = bSH_C3[1] * xy * z;
+					const float d11_ = bSH_C3[2] * y * (FMA(4.f, zz, -xx) - yy);
+					const float d12_ = bSH_C3[3] * z * FMA(-3.f, yy, FMA(-3.f, xx, 2.f * zz));
+					const float d13_ = bSH_C3[4] * x * (FMA(4.f, zz, -xx) - yy);
+					const float d14_ = bSH_C3[5] * z * (xx - yy);
+					const float d15_ = bSH_C3[6] * x * FMA(-3.f, yy, xx);
+					DSH(9, d9_); DSH(10, d10_); DSH(11, d11_); DSH(12, d12_); DSH(13, d13_); DSH(14, d14_); DSH(15, d15_);
+#pragma unroll
+					for (int ch = 0; ch < 3; ch++) {
+						dRGBdx[ch] += FMA(bSH_C3[6] * SH(15) * 3.f, xx - yy,
+						              FMA(bSH_C3[5] * SH(14) * 2.f, xz,
+						              FMA(bSH_C3[4] * SH(13), FMA(4.f, zz, -3.f * xx) - yy,
+						              FMA(bSH_C3[3] * SH(12) * -3.f * 2.f, xz,
+						              FMA(bSH_C3[2] * SH(11) * -2.f, xy,
+						              FMA(bSH_C3[1] * SH(10), yz, bSH_C3[0] * SH(9) * 3.f * 2.f * xy))))));
+						dRGBdy[ch] += FMA(bSH_C3[6] * SH(15) * -3.f * 2.f, xy,
+						              FMA(bSH_C3[5] * SH(14) * -2.f, yz,
+						              FMA(bSH_C3[4] * SH(13) * -2.f, xy,
+						              FMA(bSH_C3[3] * SH(12) * -3.f * 2.f, yz,
+						              FMA(bSH_C3[2] * SH(11), FMA(4.f, zz, -3.f * yy) - xx,
+						              FMA(bSH_C3[1] * SH(10), xz, bSH_C3[0] * SH(9) * 3.f * (xx - yy)))))));
+						dRGBdz[ch] += FMA(bSH_C3[5] * SH(14), xx - yy,
+						              FMA(bSH_C3[4] * SH(13) * 4.f * 2.f, xz,
+						              FMA(bSH_C3[3] * SH(12) * 3.f, FMA(2.f, zz, -xx) - yy,
+						              FMA(bSH_C3[2] * SH(11) * 4.f * 2.f, yz, bSH_C3[1] * SH(10) * xy))));
+					}
+				}
+			}
+		}
+#undef SH
+#undef DSH
+		const float ddx = FMA(dRGBdx[2], dRGB[2], FMA(dRGBdx[1], dRGB[1], dRGBdx[0] * dRGB[0]));
+		const float ddy = FMA(dRGBdy[2], dRGB[2], FMA(dRGBdy[1], dRGB[1], dRGBdy[0] * dRGB[0]));
+		const float ddz = FMA(dRGBdz[2], dRGB[2], FMA(dRGBdz[1], dRGB[1], dRGBdz[0] * dRGB[0]));
+		// dnormvdv (auxiliary.h:107-117)
+		const float3 v = dir_orig;
+		const float sum2 = FMA(v.z, v.z, FMA(v.y, v.y, v.x * v.x));
+		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+		dmean_sh[0] = (FMA(-(v.z * v.x), ddz, FMA(-(v.y * v.x), ddy, FMA(-v.x, v.x, sum2) * ddx))) * invsum32;
+		dmean_sh[1] = (FMA(-(v.z * v.y), ddz, FMA(FMA(-v.y, v.y, sum2), ddy, (-v.x * v.y) * ddx))) * invsum32;
+		dmean_sh[2] = (FMA(FMA(-v.z, v.z, sum2), ddz, FMA(-(v.y * v.z), ddy, (-v.x * v.z) * ddx))) * invsum32;
+	
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
     int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
-    const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs, const float* __restrict__ dL_dcolor,
-    float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh)
+    const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs,
+    const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dsh_rest)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
 	constexpr int NC = (D + 1) * (D + 1);
-	float* dsh = dL_dsh + (size_t)idx * M * 3;
-	if (!(radii[idx] > 0)) {
-		if (sh_vec4)
-			for (int i = 0; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-		else
-			for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
-		return;
-	}
-	const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-	const float a_[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, dL_dcolor[3 * (size_t)idx], dL_dcolor[3 * (size_t)idx + 1],
-	                     dL_dcolor[3 * (size_t)idx + 2]};
-	float dmean[3] = {dL_dmeans[3 * (size_t)idx], dL_dmeans[3 * (size_t)idx + 1], dL_dmeans[3 * (size_t)idx + 2]};
-	{
-
-			// computeColorFromSH backward (backward.cu:20-139)
-			float sh[NC * 3];
-			float dc[NC];        // d(rgb)/d(sh_k): dL_dsh[k][ch] = dc[k] * dL_dRGB[ch], formed at store time (keeps 32 registers free)
-			const float* shp = shs + (size_t)idx * M * 3;
-			if (sh_vec4 && (NC * 3) % 4 == 0) {
+	const bool vis = radii[idx] > 0;
+	float sh[NC * 3], dc[NC], dRGB[3], dmean_sh[3];
+	if (shs_rest != nullptr) {
+		// split storage (f1): dL_dsh -> dL_df_dc [P,1,3], dL_dsh_rest -> dL_df_rest [P,M-1,3]
+		float* ddc = dL_dsh + 3 * (size_t)idx;
+		float* drest = dL_dsh_rest + (size_t)idx * (M - 1) * 3;
+		if (!vis) {
+			ddc[0] = ddc[1] = ddc[2] = 0.f;
+			for (int i = 0; i < (M - 1) * 3; i++) drest[i] = 0.f;
+			return;
+		}
+		sh[0] = shs[3 * (size_t)idx]; sh[1] = shs[3 * (size_t)idx + 1]; sh[2] = shs[3 * (size_t)idx + 2];
+		const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
 #pragma unroll
-				for (int i = 0; i < NC * 3 / 4; i++) {
-					const float4 v = reinterpret_cast<const float4*>(shp)[i];
-					sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
-				}
-			} else {
+		for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
+		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
+		ddc[0] = dc[0] * dRGB[0]; ddc[1] = dc[0] * dRGB[1]; ddc[2] = dc[0] * dRGB[2];
 #pragma unroll
-				for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+		for (int i = 3; i < NC * 3; i++) drest[i - 3] = dc[i / 3] * dRGB[i % 3];
+		for (int i = NC * 3; i < M * 3; i++) drest[i - 3] = 0.f;   // coefficients above the active degree
+	} else {
+		float* dsh = dL_dsh + (size_t)idx * M * 3;
+		if (!vis) {
+			if (sh_vec4)
+				for (int i = 0; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+			else
+				for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
+			return;
+		}
+		const float* shp = shs + (size_t)idx * M * 3;
+		if (sh_vec4 && (NC * 3) % 4 == 0) {
+#pragma unroll
+			for (int i = 0; i < NC * 3 / 4; i++) {
+				const float4 v = reinterpret_cast<const float4*>(shp)[i];
+				sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
 			}
-			const float3 dir_orig = {m.x - cam->campos[0], m.y - cam->campos[1], m.z - cam->campos[2]};
-			const float len = sqrtf(FMA(dir_orig.z, dir_orig.z, FMA(dir_orig.y, dir_orig.y, dir_orig.x * dir_orig.x)));
-			const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-			const uint32_t clamped = recs[idx].q3.z;
-			float dRGB[3];
+		} else {
 #pragma unroll
-			for (int ch = 0; ch < 3; ch++) dRGB[ch] = a_[6 + ch] * (((clamped >> ch) & 1u) ? 0.f : 1.f);
-			float dRGBdx[3] = {0.f, 0.f, 0.f}, dRGBdy[3] = {0.f, 0.f, 0.f}, dRGBdz[3] = {0.f, 0.f, 0.f};
-#define SH(k) sh[(k) * 3 + ch]
-#define DSH(k, coef) dc[k] = (coef)
-			DSH(0, bSH_C0);
-			if (D > 0) {
-				const float d1_ = -bSH_C1 * y, d2_ = bSH_C1 * z, d3_ = -bSH_C1 * x;
-				DSH(1, d1_); DSH(2, d2_); DSH(3, d3_);
-#pragma unroll
-				for (int ch = 0; ch < 3; ch++) {
-					dRGBdx[ch] = -bSH_C1 * SH(3);
-					dRGBdy[ch] = -bSH_C1 * SH(1);
-					dRGBdz[ch] = bSH_C1 * SH(2);
-				}
-				if (D > 1) {
-					const float xx = x * x, yy = y * y, zz = z * z;
-					const float xy = x * y, yz = y * z, xz = x * z;
-					const float d4_ = bSH_C2[0] * xy, d5_ = bSH_C2[1] * yz;
-					const float d6_ = bSH_C2[2] * (FMA(2.f, zz, -xx) - yy);
-					const float d7_ = bSH_C2[3] * xz, d8_ = bSH_C2[4] * (xx - yy);
-					DSH(4, d4_); DSH(5, d5_); DSH(6, d6_); DSH(7, d7_); DSH(8, d8_);
-#pragma unroll
-					for (int ch = 0; ch < 3; ch++) {
-						dRGBdx[ch] += FMA(bSH_C2[4] * 2.f * x, SH(8), FMA(bSH_C2[3] * z, SH(7), FMA(bSH_C2[2] * 2.f * -x, SH(6), bSH_C2[0] * y * SH(4))));
-						dRGBdy[ch] += FMA(bSH_C2[4] * 2.f * -y, SH(8), FMA(bSH_C2[2] * 2.f * -y, SH(6), FMA(bSH_C2[1] * z, SH(5), bSH_C2[0] * x * SH(4))));
-						dRGBdz[ch] += FMA(bSH_C2[3] * x, SH(7), FMA(bSH_C2[2] * 2.f * 2.f * z, SH(6), bSH_C2[1] * y * SH(5)));
-					}
-					if (D > 2) {
-						const float d9_ = bSH_C3[0] * y * FMA(3.f, xx, -yy);
-						const float d10_ = bSH_C3[1] * xy * z;
-						const float d11_ = bSH_C3[2] * y * (FMA(4.f, zz, -xx) - yy);
-						const float d12_ = bSH_C3[3] * z * FMA(-3.f, yy, FMA(-3.f, xx, 2.f * zz));
-						const float d13_ = bSH_C3[4] * x * (FMA(4.f, zz, -xx) - yy);
-						const float d14_ = bSH_C3[5] * z * (xx - yy);
-						const float d15_ = bSH_C3[6] * x * FMA(-3.f, yy, xx);
-						DSH(9, d9_); DSH(10, d10_); DSH(11, d11_); DSH(12, d12_); DSH(13, d13_); DSH(14, d14_); DSH(15, d15_);
-#pragma unroll
-						for (int ch = 0; ch < 3; ch++) {
-							dRGBdx[ch] += FMA(bSH_C3[6] * SH(15) * 3.f, xx - yy,
-							              FMA(bSH_C3[5] * SH(14) * 2.f, xz,
-							              FMA(bSH_C3[4] * SH(13), FMA(4.f, zz, -3.f * xx) - yy,
-							              FMA(bSH_C3[3] * SH(12) * -3.f * 2.f, xz,
-							              FMA(bSH_C3[2] * SH(11) * -2.f, xy,
-							              FMA(bSH_C3[1] * SH(10), yz, bSH_C3[0] * SH(9) * 3.f * 2.f * xy))))));
-							dRGBdy[ch] += FMA(bSH_C3[6] * SH(15) * -3.f * 2.f, xy,
-							              FMA(bSH_C3[5] * SH(14) * -2.f, yz,
-							              FMA(bSH_C3[4] * SH(13) * -2.f, xy,
-							              FMA(bSH_C3[3] * SH(12) * -3.f * 2.f, yz,
-							              FMA(bSH_C3[2] * SH(11), FMA(4.f, zz, -3.f * yy) - xx,
-							              FMA(bSH_C3[1] * SH(10), xz, bSH_C3[0] * SH(9) * 3.f * (xx - yy)))))));
-							dRGBdz[ch] += FMA(bSH_C3[5] * SH(14), xx - yy,
-							              FMA(bSH_C3[4] * SH(13) * 4.f * 2.f, xz,
-							              FMA(bSH_C3[3] * SH(12) * 3.f, FMA(2.f, zz, -xx) - yy,
-							              FMA(bSH_C3[2] * SH(11) * 4.f * 2.f, yz, bSH_C3[1] * SH(10) * xy))));
-						}
-					}
-				}
-			}
-#undef SH
-#undef DSH
+			for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+		}
+		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
 #define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
-			if (sh_vec4 && (NC * 3) % 4 == 0) {
+		if (sh_vec4 && (NC * 3) % 4 == 0) {
 #pragma unroll
-				for (int i = 0; i < NC * 3 / 4; i++)
-					reinterpret_cast<float4*>(dsh)[i] = make_float4(OSH(4 * i), OSH(4 * i + 1), OSH(4 * i + 2), OSH(4 * i + 3));
-				for (int i = NC * 3 / 4; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-			} else {
+			for (int i = 0; i < NC * 3 / 4; i++)
+				reinterpret_cast<float4*>(dsh)[i] = make_float4(OSH(4 * i), OSH(4 * i + 1), OSH(4 * i + 2), OSH(4 * i + 3));
+			for (int i = NC * 3 / 4; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		} else {
 #pragma unroll
-				for (int i = 0; i < NC * 3; i++) dsh[i] = OSH(i);
-				for (int i = NC * 3; i < M * 3; i++) dsh[i] = 0.f;   // coefficients above the active degree
-			}
+			for (int i = 0; i < NC * 3; i++) dsh[i] = OSH(i);
+			for (int i = NC * 3; i < M * 3; i++) dsh[i] = 0.f;   // coefficients above the active degree
+		}
 #undef OSH
-			const float ddx = FMA(dRGBdx[2], dRGB[2], FMA(dRGBdx[1], dRGB[1], dRGBdx[0] * dRGB[0]));
-			const float ddy = FMA(dRGBdy[2], dRGB[2], FMA(dRGBdy[1], dRGB[1], dRGBdy[0] * dRGB[0]));
-			const float ddz = FMA(dRGBdz[2], dRGB[2], FMA(dRGBdz[1], dRGB[1], dRGBdz[0] * dRGB[0]));
-			// dnormvdv (auxiliary.h:107-117)
-			const float3 v = dir_orig;
-			const float sum2 = FMA(v.z, v.z, FMA(v.y, v.y, v.x * v.x));
-			const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-			dmean[0] += (FMA(-(v.z * v.x), ddz, FMA(-(v.y * v.x), ddy, FMA(-v.x, v.x, sum2) * ddx))) * invsum32;
-			dmean[1] += (FMA(-(v.z * v.y), ddz, FMA(FMA(-v.y, v.y, sum2), ddy, (-v.x * v.y) * ddx))) * invsum32;
-			dmean[2] += (FMA(FMA(-v.z, v.z, sum2), ddz, FMA(-(v.y * v.z), ddy, (-v.x * v.z) * ddx))) * invsum32;
-		
 	}
 #pragma unroll
-	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] = dmean[i];
+	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] += dmean_sh[i];
 }
 
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
                            const float* rows, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
-                           float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                           hipStream_t s)
+                           float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
+                           float* dL_drot, hipStream_t s)
 {
 	const float h_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:391-392
 	const float h_x = a.W / (2.0f * a.tan_fovx);
 	// 16-B vector access to the SH rows / dL_dsh rows needs 16-B aligned bases and a row size multiple of 16 B
-	const int sh_vec4 = (a.shs != nullptr && dL_dsh != nullptr && ((uintptr_t)a.shs % 16 == 0) &&
+	const int sh_vec4 = (a.shs != nullptr && a.shs_rest == nullptr && dL_dsh != nullptr && ((uintptr_t)a.shs % 16 == 0) &&
 	                     ((uintptr_t)dL_dsh % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0;
 	dim3 grid((a.P + 255) / 256), block(256);
 #define GSR_LAUNCH_PB(DEG)                                                                                         \
 	hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, a.scales, \
 	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
-	                   h_y, sh_vec4, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
+	                   h_y, sh_vec4, a.act, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
 	                   dL_drot)
 	GSR_LAUNCH_PB(0);
 #undef GSR_LAUNCH_PB
 	if (a.shs != nullptr) {
 #define GSR_LAUNCH_SH(DEG)                                                                                       \
-	hipLaunchKernelGGL(preprocess_bwd_sh_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, cam,  \
-	                   sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh)
+	hipLaunchKernelGGL(preprocess_bwd_sh_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs,       \
+	                   a.shs_rest, cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
 		switch (a.D) {
 			case 0: GSR_LAUNCH_SH(0); break;
 			case 1: GSR_LAUNCH_SH(1); break;

@@ -77,7 +77,7 @@ template <int D>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int P, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
-    const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs_rest, int act, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const GsCam* __restrict__ cam, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int gx, int gy, int prefiltered, int sh_vec4, int* __restrict__ radii, GsRec* __restrict__ recs,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count, GsCtl* __restrict__ ctl)
@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 #pragma unroll
 				for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
 			} else {
-				const float3 sc = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
-				const float4 q = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+				float inv_len;
+				const float3 sc = gs_act_scale({scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]}, act);
+				const float4 q = gs_act_rot(*reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx), act, &inv_len);
 				cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
 			}
 			Cov2D c;
@@ -140,7 +141,14 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 				constexpr int NC = (D + 1) * (D + 1);
 				float sh[NC * 3];
 				const float* shp = shs + (size_t)idx * M * 3;
-				if (sh_vec4 && (NC * 3) % 4 == 0) {
+				if (shs_rest != nullptr) {
+					// split storage (f_dc [P,1,3] + f_rest [P,M-1,3], models/vanilla_sg.py:103-106): no torch.cat copy
+					const float* dcp = shs + 3 * (size_t)idx;
+					const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
+					sh[0] = dcp[0]; sh[1] = dcp[1]; sh[2] = dcp[2];
+#pragma unroll
+					for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
+				} else if (sh_vec4 && (NC * 3) % 4 == 0) {
 #pragma unroll
 					for (int i = 0; i < NC * 3 / 4; i++) {
 						const float4 v = reinterpret_cast<const float4*>(shp)[i];
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 				rgb[1] = colors_precomp[3 * (size_t)idx + 1];
 				rgb[2] = colors_precomp[3 * (size_t)idx + 2];
 			}
-			const float op = opacities[idx];
+			const float op = gs_act_opacity(opacities[idx], act);
 			// pcut: power < pcut  ==>  op*exp(power) < 1/255 with a 1e-3 margin, so skipping the pair is
 			// bit-identical to evaluating it and failing `alpha < 1/255` (forward.cu:346).  Clamped to the
 			// domain of gs_exp.  op <= 0 -> +inf (always skipped); NaN -> -80 (never skipped by pcut).
@@ -225,7 +233,7 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 	dim3 grid((a.P + 255) / 256), block(256);
 #define GSR_LAUNCH_PRE(DEG)                                                                                        \
 	hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.scales,               \
-	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.cov3D_precomp, a.colors_precomp, cam,   \
+	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.shs_rest, a.act, a.cov3D_precomp, a.colors_precomp, cam,   \
 	                   a.W, a.H, a.tan_fovx, a.tan_fovy, focal_x, focal_y, il.gx, il.gy, a.prefiltered, sh_vec4,     \
 	                   radii, recs, tiles_touched, tile_count, ctl)
 	const int D = a.colors_precomp ? 0 : a.D;

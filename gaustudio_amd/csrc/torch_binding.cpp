@@ -8,6 +8,7 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -166,9 +167,100 @@ torch::Tensor markVisible(torch::Tensor& means3D_, torch::Tensor& viewmatrix_, t
 	return present;
 }
 
+// ---- fused parameter activations: raw point-cloud attributes in, gradients w.r.t. them out ----
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansRaw(const torch::Tensor& background, const torch::Tensor& means3D_, const torch::Tensor& f_dc_,
+                      const torch::Tensor& f_rest_, const torch::Tensor& raw_opacity_, const torch::Tensor& raw_scales_,
+                      const torch::Tensor& raw_rotations_, const float scale_modifier, const int activation_flags,
+                      const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, const float tan_fovx,
+                      const float tan_fovy, const int image_height, const int image_width, const int degree,
+                      const torch::Tensor& campos_, const bool prefiltered, const bool debug)
+{
+	if (means3D_.ndimension() != 2 || means3D_.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
+	require_device(means3D_, "means3D");
+	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
+	const int P = means3D_.size(0), H = image_height, W = image_width;
+	const auto means3D = means3D_.contiguous(), f_dc = f_dc_.contiguous(), f_rest = f_rest_.contiguous();
+	const auto opacity = raw_opacity_.contiguous(), scales = raw_scales_.contiguous(), rotations = raw_rotations_.contiguous();
+	const auto viewmatrix = viewmatrix_.contiguous(), projmatrix = projmatrix_.contiguous();
+	const auto campos = campos_.contiguous(), bg = background.contiguous();
+	for (const auto& p : {std::make_pair(&f_dc, "f_dc"), std::make_pair(&f_rest, "f_rest"), std::make_pair(&opacity, "opacity"),
+	                      std::make_pair(&scales, "scales"), std::make_pair(&rotations, "rotations")})
+		if (p.first->numel() != 0) require_device(*p.first, p.second);
+	TORCH_CHECK(f_dc.numel() == (int64_t)P * 3, "f_dc must hold 3 values per Gaussian");
+	TORCH_CHECK(f_rest.numel() % ((int64_t)std::max(P, 1) * 3) == 0, "f_rest must be [P, M-1, 3]");
+	const int M = 1 + (P ? (int)(f_rest.numel() / ((int64_t)P * 3)) : 0);
+
+	const auto fo = means3D.options().dtype(torch::kFloat32);
+	torch::Tensor out_color = torch::empty({3, H, W}, fo), out_depth = torch::empty({1, H, W}, fo);
+	torch::Tensor out_median = torch::empty({3, H, W}, fo), out_opacity = torch::empty({1, H, W}, fo);
+	torch::Tensor radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
+	const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
+	torch::Tensor geom = torch::empty({0}, bo), binning = torch::empty({0}, bo), img = torch::empty({0}, bo);
+	const int rc = gsr_forward_raw(resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, degree, M, fptr(bg, "bg"), W, H,
+	                               fptr(means3D, "means3D"), fptr(f_dc, "f_dc"), fptr(f_rest, "f_rest"),
+	                               fptr(opacity, "opacity"), fptr(scales, "scales"), scale_modifier,
+	                               fptr(rotations, "rotations"), activation_flags, fptr(viewmatrix, "viewmatrix"),
+	                               fptr(projmatrix, "projmatrix"), fptr(campos, "campos"), tan_fovx, tan_fovy,
+	                               prefiltered ? 1 : 0, out_color.data_ptr<float>(), out_depth.data_ptr<float>(),
+	                               out_median.data_ptr<float>(), out_opacity.data_ptr<float>(),
+	                               P ? radii.data_ptr<int>() : nullptr, debug ? 1 : 0, current_stream(means3D));
+	if (rc < 0) fail(rc);
+	return std::make_tuple(rc, out_color, out_depth, out_median, out_opacity, radii, geom, binning, img);
+}
+
+// returns (dL_dmeans2D, dL_draw_opacity, dL_dmeans3D, dL_df_dc, dL_df_rest, dL_draw_scales, dL_draw_rotations)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansRawBackward(const torch::Tensor& background, const torch::Tensor& means3D_, const torch::Tensor& radii_,
+                              const torch::Tensor& f_dc_, const torch::Tensor& f_rest_, const torch::Tensor& raw_scales_,
+                              const torch::Tensor& raw_rotations_, const float scale_modifier, const int activation_flags,
+                              const float tan_fovx, const float tan_fovy, const torch::Tensor& dL_dout_color,
+                              const torch::Tensor& dL_dout_depth, const torch::Tensor& dL_dout_median_depth,
+                              const torch::Tensor& dL_dout_final_opacity, const int degree,
+                              const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer,
+                              const torch::Tensor& imageBuffer, const bool debug)
+{
+	require_device(means3D_, "means3D");
+	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
+	const int P = means3D_.size(0);
+	const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+	const auto means3D = means3D_.contiguous(), f_dc = f_dc_.contiguous(), f_rest = f_rest_.contiguous();
+	const auto scales = raw_scales_.contiguous(), rotations = raw_rotations_.contiguous(), bg = background.contiguous();
+	const auto radii = radii_.contiguous();
+	const auto g_color = dL_dout_color.contiguous(), g_depth = dL_dout_depth.contiguous();
+	const auto g_median = dL_dout_median_depth.contiguous(), g_op = dL_dout_final_opacity.contiguous();
+	const int M = 1 + (P ? (int)(f_rest.numel() / ((int64_t)P * 3)) : 0);
+	const auto fo = means3D.options().dtype(torch::kFloat32);
+	torch::Tensor dL_dmeans3D = torch::empty({P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
+	torch::Tensor dL_dcolors = torch::empty({P, 3}, fo), dL_dopacity = torch::empty_like(raw_scales_.new_empty({P, 1}));
+	torch::Tensor dL_dcov3D = torch::empty({P, 6}, fo);
+	torch::Tensor dL_df_dc = torch::empty_like(f_dc), dL_df_rest = torch::empty_like(f_rest);
+	torch::Tensor dL_dscales = torch::empty({P, 3}, fo), dL_drotations = torch::empty({P, 4}, fo);
+	if (P != 0) {
+		const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
+		torch::Tensor scratch = torch::empty({(long long)gsr_backward_scratch_bytes(P, R)}, bo);
+		const int rc = gsr_backward_raw(
+		    P, degree, M, R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(f_dc, "f_dc"), fptr(f_rest, "f_rest"),
+		    fptr(scales, "scales"), scale_modifier, fptr(rotations, "rotations"), activation_flags, tan_fovx, tan_fovy,
+		    radii.data_ptr<int>(), reinterpret_cast<const char*>(geomBuffer.data_ptr()),
+		    reinterpret_cast<const char*>(binningBuffer.data_ptr()), reinterpret_cast<const char*>(imageBuffer.data_ptr()),
+		    fptr(g_color, "dL_dout_color"), fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"),
+		    fptr(g_op, "dL_dout_final_opacity"), dL_dmeans2D.data_ptr<float>(), dL_dopacity.data_ptr<float>(),
+		    dL_dcolors.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(),
+		    dL_df_dc.data_ptr<float>(), M > 1 ? dL_df_rest.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
+		    dL_drotations.data_ptr<float>(), reinterpret_cast<char*>(scratch.data_ptr()), debug ? 1 : 0,
+		    current_stream(means3D));
+		if (rc < 0) fail(rc);
+	}
+	return std::make_tuple(dL_dmeans2D, dL_dopacity, dL_dmeans3D, dL_df_dc, dL_df_rest, dL_dscales, dL_drotations);
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
 	m.def("rasterize_gaussians", &RasterizeGaussians);
 	m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
 	m.def("mark_visible", &markVisible);
+	m.def("rasterize_gaussians_raw", &RasterizeGaussiansRaw);
+	m.def("rasterize_gaussians_raw_backward", &RasterizeGaussiansRawBackward);
 }

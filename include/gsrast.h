@@ -135,6 +135,32 @@ int gsr_backward(int P, int D, int M, int R,
                  int debug,
                  void* stream);
 
+/* ---- fused parameter activations (new, not in the reference's interface) ----
+ * gsr_forward_raw / gsr_backward_raw take GauStudio's RAW point-cloud attributes -- f_dc[P,1,3] and f_rest[P,M-1,3]
+ * instead of the concatenated sh[P,M,3] (models/vanilla_sg.py:103-106), pre-activation opacity / scale / rotation --
+ * and apply VanillaPointCloud's activations inside the kernels (models/vanilla_sg.py:33-37: exp, sigmoid,
+ * F.normalize) according to activation_flags.  Gradients are returned w.r.t. the raw attributes. */
+#define GSR_ACT_OPACITY_SIGMOID 1
+#define GSR_ACT_SCALE_EXP 2
+#define GSR_ACT_ROT_NORMALIZE 4
+
+int gsr_forward_raw(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
+                    gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                    int height, const float* means3D, const float* f_dc, const float* f_rest, const float* raw_opacities,
+                    const float* raw_scales, float scale_modifier, const float* raw_rotations, int activation_flags,
+                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                    float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_median_depth,
+                    float* out_opacity, int* radii, int debug, void* stream);
+
+int gsr_backward_raw(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                     const float* f_dc, const float* f_rest, const float* raw_scales, float scale_modifier,
+                     const float* raw_rotations, int activation_flags, float tan_fovx, float tan_fovy,
+                     const int* radii, const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                     const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_median_depth,
+                     const float* dL_dpix_final_opacity, float* dL_dmean2D, float* dL_draw_opacity, float* dL_dcolor,
+                     float* dL_dmean3D, float* dL_dcov3D, float* dL_df_dc, float* dL_df_rest, float* dL_draw_scale,
+                     float* dL_draw_rot, char* scratch, int debug, void* stream);
+
 /* ---- introspection of the opaque buffers (tests, debugging).  The reference exposes the same state
  * only implicitly through GeometryState/BinningState/ImageState (rasterizer_impl.h:33-64).
  * Any output pointer may be NULL.  All outputs are device memory. ---- */
