@@ -108,7 +108,71 @@ def make_post_golden():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_camera_golden():
+    """tests/golden/py_cameras.npz + py_cameras.json: cameras.json entries pushed through the reference's
+    JSON_to_camera (utils/cameras_utils.py:8-38) -> Camera (datasets/__init__.py:113-183) -> camera_to_JSON
+    (datasets/utils.py:58-80).  plyfile (imported at the top of datasets/utils.py, absent here) is stubbed;
+    the camera functions do not touch it."""
+    import json
+    import sys
+    spec = importlib.util.spec_from_file_location("ref_datasets", os.path.join(REF, "datasets", "__init__.py"),
+                                                  submodule_search_locations=[])
+    ds = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(ds)
+    except ModuleNotFoundError:
+        pass
+    pkg = types.ModuleType("gaustudio")
+    pkg.datasets = ds
+    ply = types.ModuleType("plyfile")
+    ply.PlyData = ply.PlyElement = None
+    saved = {k: sys.modules.get(k) for k in ("gaustudio", "gaustudio.datasets", "plyfile")}
+    sys.modules.update({"gaustudio": pkg, "gaustudio.datasets": ds, "plyfile": ply})
+    try:
+        mods = []
+        for rel in (("utils", "cameras_utils.py"), ("datasets", "utils.py")):
+            sp = importlib.util.spec_from_file_location("ref_" + rel[1][:-3], os.path.join(REF, *rel))
+            m = importlib.util.module_from_spec(sp)
+            sp.loader.exec_module(m)
+            mods.append(m)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    cu, du = mods
+    rng = np.random.default_rng(17)
+    entries = []
+    for i in range(4):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        r, x, y, z = q
+        rot = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                        [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                        [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+        w, h = [(1920, 1080), (800, 800), (1296, 968), (640, 360)][i]
+        entries.append({"id": i, "img_name": f"frame_{(7 * i) % 4:05d}", "width": w, "height": h,
+                        "position": (rng.normal(size=3) * 3).tolist(), "rotation": [row.tolist() for row in rot],
+                        "fy": float(h * rng.uniform(0.8, 1.6)), "fx": float(w * rng.uniform(0.5, 1.1))})
+    out = {}
+    back = []
+    for i, e in enumerate(entries):
+        cam = cu.JSON_to_camera(e)
+        out[f"view_{i}"] = cam.world_view_transform.numpy()
+        out[f"full_{i}"] = cam.full_proj_transform.numpy()
+        out[f"campos_{i}"] = cam.camera_center.numpy()
+        out[f"fov_{i}"] = np.array([cam.FoVx, cam.FoVy], dtype=np.float64)
+        out[f"RT_{i}"] = np.concatenate([np.asarray(cam.R, dtype=np.float64).reshape(-1), np.asarray(cam.T, dtype=np.float64)])
+        back.append(du.camera_to_JSON(i, cam))
+    np.savez_compressed(os.path.join(HERE, "py_cameras.npz"), **out)
+    with open(os.path.join(HERE, "py_cameras.json"), "w") as f:
+        json.dump({"entries": entries, "roundtrip": back}, f, indent=1)
+    print("wrote py_cameras.npz / py_cameras.json")
+
+
 if __name__ == "__main__":
     import math
     main()
     make_post_golden()
+    make_camera_golden()
