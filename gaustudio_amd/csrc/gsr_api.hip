@@ -341,7 +341,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	if (err_pref)
 		return fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!",
 		            __FILE__, __LINE__);
-	if (R > 0x7fffffffu) return fail(GSR_ERR_ARG, "gsr_forward: more than 2^31 instances", __FILE__, __LINE__);
+	if (host[3] || R > 0x7fffffffu)
+		return fail(GSR_ERR_ARG, "gsr_forward: more than 2^31 - 1 (tile, Gaussian) instances", __FILE__, __LINE__);
 
 	const BinLayout bl((size_t)R, max_tile > GSR_SORT_LDS_MAX);
 	char* bin = binning_alloc(binning_ctx, bl.total);

@@ -42,7 +42,7 @@ struct GsCtl {
 	uint32_t num_rendered;   // R
 	uint32_t max_tile_count; // longest per-tile list
 	uint32_t err_prefiltered;
-	uint32_t pad;
+	uint32_t err_overflow;   // R does not fit the reference's int num_rendered
 };
 
 __device__ __forceinline__ float gs_exp(float p)
@@ -274,4 +274,58 @@ __device__ __forceinline__ bool gs_box_may_touch(const float4 A, const float4 B,
 		mag = fmaxf(mag, fabsf(t0) + fabsf(ha * dx * dx) + fabsf(nb * yn * dx));
 	}
 	return best >= pcut - (0.05f + 1e-5f * mag);
+}
+
+// ---- wave-cooperative row staging (SH rows: 192 B per Gaussian at degree 3) -------------------------------
+// A lane that reads "its" row with per-lane dwordx4 loads makes every load instruction touch 64 different rows
+// (16 B out of each); staged through LDS instead, the wave copies its 64 consecutive rows as ONE contiguous
+// 64*RF-float chunk, 1 KiB per load instruction, and each lane then picks its row out of the wave's LDS slab.
+// `chunk` must be 16-B aligned (base 16-B aligned; 64 rows are a multiple of 256 B).  Rows whose bit in `mask`
+// is clear are not fetched.  Caller brackets these with __builtin_amdgcn_wave_barrier() (LDS is in-order per wave).
+template <int RF>
+__device__ __forceinline__ void gs_wave_rows_to_lds(const float* __restrict__ chunk, int nrows, unsigned long long mask,
+                                                    float* __restrict__ slab, int lane)
+{
+	const int nfl = nrows * RF, nv = nfl >> 2;
+#pragma unroll
+	for (int it = 0; it < (16 * RF + 63) / 64; it++) {
+		const int j = it * 64 + lane;
+		if (j < nv) {
+			const int r0 = (4 * j) / RF, r1 = (4 * j + 3) / RF;
+			if (((mask >> r0) | (mask >> r1)) & 1ull)
+				reinterpret_cast<float4*>(slab)[j] = reinterpret_cast<const float4*>(chunk)[j];
+		}
+	}
+	const int t = (nv << 2) + lane;   // < 4 trailing floats, only in the last (partial) wave of a launch
+	if (t < nfl && ((mask >> (t / RF)) & 1ull)) slab[t] = chunk[t];
+}
+
+template <int RF>
+__device__ __forceinline__ void gs_wave_lds_to_rows(float* __restrict__ chunk, int nrows, const float* __restrict__ slab,
+                                                    int lane)
+{
+	const int nfl = nrows * RF, nv = nfl >> 2;
+#pragma unroll
+	for (int it = 0; it < (16 * RF + 63) / 64; it++) {
+		const int j = it * 64 + lane;
+		if (j < nv) reinterpret_cast<float4*>(chunk)[j] = reinterpret_cast<const float4*>(slab)[j];
+	}
+	const int t = (nv << 2) + lane;
+	if (t < nfl) chunk[t] = slab[t];
+}
+
+// lane-private row in the slab <-> registers (float4 accesses when rows are 16-B multiples)
+template <int RF>
+__device__ __forceinline__ void gs_row_from_lds(const float* __restrict__ row, float* __restrict__ out)
+{
+	if (RF % 4 == 0) {
+#pragma unroll
+		for (int i = 0; i < RF / 4; i++) {
+			const float4 v = reinterpret_cast<const float4*>(row)[i];
+			out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < RF; i++) out[i] = row[i];
+	}
 }

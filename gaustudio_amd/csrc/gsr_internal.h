@@ -117,6 +117,7 @@ struct BwdArgs {
 // contiguous read and a fixed summation order.
 //   row: 0,1 dL_dmean2D.xy | 2,3,4 dL_dconic a,b,c | 5 dL_dopacity | 6,7,8 dL_dcolor | 9 dL_ddepth | 10,11 unused
 #define GSR_ROW_STRIDE 12
+#define GSR_SUM_SLAB 160   // rows per LDS slab of preprocess_bwd's cooperative row fetch (7.5 KiB per wave)
 // scratch: [goff u32 x (P+1)][block sums u32 x (nb+1)][bg f32 x 4][rows f32 x R*12]
 #define GSR_SCAN_BLOCK 2048
 struct BwdLayout {

@@ -429,10 +429,43 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
+	float a_[GSR_ROW_STRIDE];
+	{
+		// Same sums, same order as gs_sum_rows, but the rows are fetched wave-cooperatively: the rows of 64
+		// consecutive Gaussians are ONE contiguous span [goff[g0], goff[g0 + 64]) of 48-B records (~14 KB at C3),
+		// copied through LDS in slabs of GSR_SUM_SLAB rows with 1 KiB per load instruction; each lane then adds
+		// its own rows out of the slab in ascending order.  (Per-lane gathers touched 64 cache lines per
+		// instruction: 130 us at C3.)
+		__shared__ float4 s_rows[4][GSR_SUM_SLAB * 3];
+		const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+		const int g0 = blockIdx.x * 256 + wv * 64;
+		if (g0 >= P) return;   // wave-uniform
+		const uint32_t b = goff[min(idx, P)], e = idx < P ? goff[idx + 1] : b;   // goff has P + 1 entries
+		const uint32_t wb = goff[g0], we = goff[min(g0 + 64, P)];
+#pragma unroll
+		for (int i = 0; i < GSR_ROW_STRIDE; i++) a_[i] = 0.f;
+		float4* slab = s_rows[wv];
+		for (uint32_t base = wb; base < we; base += GSR_SUM_SLAB) {
+			const uint32_t cnt = min((uint32_t)GSR_SUM_SLAB, we - base);
+			const float4* src = reinterpret_cast<const float4*>(rows + (size_t)base * GSR_ROW_STRIDE);
+#pragma unroll
+			for (int it = 0; it < (GSR_SUM_SLAB * 3 + 63) / 64; it++) {
+				const uint32_t j = it * 64 + lane;
+				if (j < cnt * 3) slab[j] = src[j];
+			}
+			__builtin_amdgcn_wave_barrier();
+			const uint32_t lo = max(b, base), hi = min(e, base + cnt);
+			for (uint32_t r = lo; r < hi; r++) {
+				const float4* ar = slab + (r - base) * 3;
+				const float4 v0 = ar[0], v1 = ar[1], v2 = ar[2];
+				a_[0] += v0.x; a_[1] += v0.y; a_[2] += v0.z; a_[3] += v0.w; a_[4] += v1.x; a_[5] += v1.y;
+				a_[6] += v1.z; a_[7] += v1.w; a_[8] += v2.x; a_[9] += v2.y;
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
 	if (idx >= P) return;
 	const bool vis = radii[idx] > 0;
-	float a_[GSR_ROW_STRIDE];
-	gs_sum_rows(vis, idx, recs, goff, rows, a_);
 	// user-facing copies of the composite-stage gradients (rasterize_points.cu:209 returns them)
 	dL_dmean2D[3 * (size_t)idx] = a_[0];
 	dL_dmean2D[3 * (size_t)idx + 1] = a_[1];
@@ -675,7 +708,76 @@ __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __re
 	
 }
 
-template <int D>
+// preprocess_bwd_sh with the SH rows and their gradients staged through LDS wave-cooperatively (gs_wave_rows_to_lds):
+// used when the stored rows hold exactly the active degree (M == (D+1)^2, the steady state) and the bases are
+// 16-B aligned; every global access is then a full 1 KiB-per-instruction stream.  Same arithmetic, same results.
+template <int D, bool SPLIT>
+__global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
+    int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
+    const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, const GsRec* __restrict__ recs,
+    const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dsh_rest)
+{
+	extern __shared__ __attribute__((aligned(16))) float sh_slab[];
+	constexpr int NC = (D + 1) * (D + 1);
+	constexpr int RF = SPLIT ? (NC - 1) * 3 : NC * 3;   // floats per staged row
+	constexpr int RFA = RF > 0 ? RF : 1;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int g0 = blockIdx.x * 256 + wv * 64;
+	const int nrows = min(64, P - g0);
+	if (nrows <= 0) return;   // wave-uniform
+	const bool vis = idx < P && radii[idx] > 0;
+	const unsigned long long vm = __ballot(vis);
+	float* slab = sh_slab + wv * 64 * RF;
+	float* row = slab + lane * RF;
+	if (RF > 0) {
+		const float* src = (SPLIT ? shs_rest : shs) + (size_t)g0 * RF;
+		if (vm) gs_wave_rows_to_lds<RFA>(src, nrows, vm, slab, lane);
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (vis) {
+		float sh[NC * 3], dc[NC], dRGB[3], dmean_sh[3];
+		if (SPLIT) {
+			sh[0] = shs[3 * (size_t)idx]; sh[1] = shs[3 * (size_t)idx + 1]; sh[2] = shs[3 * (size_t)idx + 2];
+			if (RF > 0) gs_row_from_lds<RFA>(row, sh + 3);
+		} else {
+			gs_row_from_lds<RFA>(row, sh);
+		}
+		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
+#define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
+		if (SPLIT) {
+			float* ddc = dL_dsh + 3 * (size_t)idx;
+			ddc[0] = OSH(0); ddc[1] = OSH(1); ddc[2] = OSH(2);
+#pragma unroll
+			for (int i = 3; i < NC * 3; i++) row[i - 3] = OSH(i);
+		} else if (RF % 4 == 0) {
+#pragma unroll
+			for (int i = 0; i < RF / 4; i++)
+				reinterpret_cast<float4*>(row)[i] = make_float4(OSH(4 * i), OSH(4 * i + 1), OSH(4 * i + 2), OSH(4 * i + 3));
+		} else {
+#pragma unroll
+			for (int i = 0; i < RF; i++) row[i] = OSH(i);
+		}
+#undef OSH
+#pragma unroll
+		for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] += dmean_sh[i];
+	} else if (idx < P) {
+		if (SPLIT) {
+			float* ddc = dL_dsh + 3 * (size_t)idx;
+			ddc[0] = ddc[1] = ddc[2] = 0.f;
+		}
+#pragma unroll
+		for (int i = 0; i < RF; i++) row[i] = 0.f;
+	}
+	if (RF > 0) {
+		__builtin_amdgcn_wave_barrier();
+		gs_wave_lds_to_rows<RFA>((SPLIT ? dL_dsh_rest : dL_dsh) + (size_t)g0 * RF, nrows, slab, lane);
+	}
+}
+
+template <int D, bool SPLIT>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
     int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs,
@@ -687,7 +789,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 	constexpr int NC = (D + 1) * (D + 1);
 	const bool vis = radii[idx] > 0;
 	float sh[NC * 3], dc[NC], dRGB[3], dmean_sh[3];
-	if (shs_rest != nullptr) {
+	if (SPLIT) {
 		// split storage (f1): dL_dsh -> dL_df_dc [P,1,3], dL_dsh_rest -> dL_df_rest [P,M-1,3]
 		float* ddc = dL_dsh + 3 * (size_t)idx;
 		float* drest = dL_dsh_rest + (size_t)idx * (M - 1) * 3;
@@ -765,14 +867,49 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 #undef GSR_LAUNCH_PB
 	if (a.shs != nullptr) {
 #define GSR_LAUNCH_SH(DEG)                                                                                       \
-	hipLaunchKernelGGL(preprocess_bwd_sh_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs,       \
+	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT>), grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, \
 	                   a.shs_rest, cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
-		switch (a.D) {
-			case 0: GSR_LAUNCH_SH(0); break;
-			case 1: GSR_LAUNCH_SH(1); break;
-			case 2: GSR_LAUNCH_SH(2); break;
-			default: GSR_LAUNCH_SH(3); break;
+#define GSR_LAUNCH_SH_D()                        \
+		switch (a.D) {                            \
+			case 0: GSR_LAUNCH_SH(0); break;      \
+			case 1: GSR_LAUNCH_SH(1); break;      \
+			case 2: GSR_LAUNCH_SH(2); break;      \
+			default: GSR_LAUNCH_SH(3); break;     \
 		}
+		// cooperative (LDS-staged) variant: rows hold exactly the active degree and every streamed base is 16-B aligned
+		const bool split = a.shs_rest != nullptr;
+		const int NCd = (a.D + 1) * (a.D + 1);
+		const float* stream_in = split ? a.shs_rest : a.shs;
+		const float* stream_out = split ? dL_dsh_rest : dL_dsh;
+		const bool coop = a.M == NCd && ((uintptr_t)stream_in % 16 == 0) && ((uintptr_t)stream_out % 16 == 0) &&
+		                  (!split || NCd == 1 || (stream_in != nullptr && stream_out != nullptr));
+#define GSR_LAUNCH_SHC(DEG, SPL)                                                                                  \
+	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL>), grid, block,                                       \
+	                   sizeof(float) * 256 * (SPL ? ((DEG + 1) * (DEG + 1) - 1) * 3 : (DEG + 1) * (DEG + 1) * 3), s, a.P, \
+	                   a.means3D, a.radii, a.shs, a.shs_rest, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
+		if (coop && split) {
+			switch (a.D) {
+				case 0: GSR_LAUNCH_SHC(0, true); break;
+				case 1: GSR_LAUNCH_SHC(1, true); break;
+				case 2: GSR_LAUNCH_SHC(2, true); break;
+				default: GSR_LAUNCH_SHC(3, true); break;
+			}
+		} else if (coop) {
+			switch (a.D) {
+				case 0: GSR_LAUNCH_SHC(0, false); break;
+				case 1: GSR_LAUNCH_SHC(1, false); break;
+				case 2: GSR_LAUNCH_SHC(2, false); break;
+				default: GSR_LAUNCH_SHC(3, false); break;
+			}
+		} else if (split) {
+			constexpr bool SPLIT = true;
+			GSR_LAUNCH_SH_D()
+		} else {
+			constexpr bool SPLIT = false;
+			GSR_LAUNCH_SH_D()
+		}
+#undef GSR_LAUNCH_SHC
+#undef GSR_LAUNCH_SH_D
 #undef GSR_LAUNCH_SH
 	} else if (dL_dsh != nullptr && a.M > 0) {
 		(void)hipMemsetAsync(dL_dsh, 0, sizeof(float) * 3 * (size_t)a.M * (size_t)a.P, s);

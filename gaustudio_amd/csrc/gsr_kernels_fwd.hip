@@ -73,24 +73,86 @@ __device__ __forceinline__ void for_each_tile(bool active, int rminx, int rminy,
 }
 
 // ------------------------------------------------------------------------------------------------
+// SH -> RGB for one Gaussian (computeColorFromSH, forward.cu:20-71); returns the clamp mask.
 template <int D>
+__device__ __forceinline__ uint32_t gs_sh_to_rgb(const float* sh, float3 p_orig, const GsCam* __restrict__ cam, float* rgb)
+{
+	float3 dir = {p_orig.x - cam->campos[0], p_orig.y - cam->campos[1], p_orig.z - cam->campos[2]};
+	const float len = sqrtf(FMA(dir.z, dir.z, FMA(dir.y, dir.y, dir.x * dir.x)));
+	dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+	const float x = dir.x, y = dir.y, z = dir.z;
+	uint32_t clamped = 0;
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) {
+#define SH(k) sh[(k) * 3 + ch]
+		float r = kSH_C0 * SH(0);
+		if (D > 0) {
+			r = FMA(-(kSH_C1 * y), SH(1), r);
+			r = FMA(kSH_C1 * z, SH(2), r);
+			r = FMA(-(kSH_C1 * x), SH(3), r);
+			if (D > 1) {
+				const float xx = x * x, yy = y * y, zz = z * z;
+				const float xy = x * y, yz = y * z, xz = x * z;
+				r = FMA(kSH_C2[0] * xy, SH(4), r);
+				r = FMA(kSH_C2[1] * yz, SH(5), r);
+				r = FMA(kSH_C2[2] * (FMA(2.0f, zz, -xx) - yy), SH(6), r);
+				r = FMA(kSH_C2[3] * xz, SH(7), r);
+				r = FMA(kSH_C2[4] * (xx - yy), SH(8), r);
+				if (D > 2) {
+					r = FMA(kSH_C3[0] * y * FMA(3.0f, xx, -yy), SH(9), r);
+					r = FMA(kSH_C3[1] * xy * z, SH(10), r);
+					r = FMA(kSH_C3[2] * y * (FMA(4.0f, zz, -xx) - yy), SH(11), r);
+					r = FMA(kSH_C3[3] * z * FMA(-3.0f, yy, FMA(-3.0f, xx, 2.0f * zz)), SH(12), r);
+					r = FMA(kSH_C3[4] * x * (FMA(4.0f, zz, -xx) - yy), SH(13), r);
+					r = FMA(kSH_C3[5] * z * (xx - yy), SH(14), r);
+					r = FMA(kSH_C3[6] * x * FMA(-3.0f, yy, xx), SH(15), r);
+				}
+			}
+		}
+#undef SH
+		r += 0.5f;
+		if (r < 0) clamped |= 1u << ch;
+		rgb[ch] = fmaxf(r, 0.0f);
+	}
+	return clamped;
+}
+
+// RAW: the f1 interface (raw attributes: activations in-kernel, SH in two tensors).  A compile-time switch:
+// as a run-time one it cost the standard path 40 us at C3.
+// Memory-level parallelism is arranged by hand: every per-Gaussian input of the geometry is requested up front,
+// and the 192-B SH row is requested right after the near-plane test so that it is in flight during the ~300
+// instructions of covariance / conic / rect arithmetic (measured at C3: 92 us with the row loaded where it is
+// used, 88 us staged wave-cooperatively through LDS, 71 us like this).
+template <int D, bool RAW>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int P, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
-    const float* __restrict__ shs_rest, int act, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs_rest, int act_arg, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const GsCam* __restrict__ cam, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int gx, int gy, int prefiltered, int sh_vec4, int* __restrict__ radii, GsRec* __restrict__ recs,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count, GsCtl* __restrict__ ctl)
 {
+	constexpr int NC = (D + 1) * (D + 1);
 	const int idx = blockIdx.x * 256 + threadIdx.x;
+	const int act = RAW ? act_arg : 0;
 	bool vis = false;
 	int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+	int mr = 0;
+	float3 p_orig = {0.f, 0.f, 0.f};
+	float pix_x = 0.f, pix_y = 0.f, conic_x = 0.f, conic_y = 0.f, conic_z = 0.f, depth = 0.f, op_raw = 0.f;
+	float sh[NC * 3];
 	if (idx < P) {
-		int my_radius_i = 0;
 		do {
 			const float* view = cam->view;
 			const float* proj = cam->proj;
-			const float3 p_orig = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+			p_orig = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+			float3 sc_raw = {0.f, 0.f, 0.f};
+			float4 q_raw = {0.f, 0.f, 0.f, 0.f};
+			if (cov3D_precomp == nullptr) {
+				sc_raw = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+				q_raw = *reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx);
+			}
+			op_raw = opacities[idx];
 			// in_frustum (auxiliary.h:139-164)
 			const float4 p_hom = xform4x4(p_orig, proj);
 			const float p_w = 1.0f / (p_hom.w + 0.0000001f);
@@ -100,14 +162,36 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 				if (prefiltered) ctl->err_prefiltered = 1;
 				break;
 			}
+			if (colors_precomp == nullptr) {
+				if (RAW) {
+					// split storage (f_dc [P,1,3] + f_rest [P,M-1,3], models/vanilla_sg.py:103-106): no torch.cat copy
+					const float* dcp = shs + 3 * (size_t)idx;
+					const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
+					sh[0] = dcp[0]; sh[1] = dcp[1]; sh[2] = dcp[2];
+#pragma unroll
+					for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
+				} else {
+					const float* shp = shs + (size_t)idx * M * 3;
+					if (sh_vec4 && (NC * 3) % 4 == 0) {
+#pragma unroll
+						for (int i = 0; i < NC * 3 / 4; i++) {
+							const float4 v = reinterpret_cast<const float4*>(shp)[i];
+							sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+						}
+					} else {
+#pragma unroll
+						for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+					}
+				}
+			}
 			float cov3D[6];
 			if (cov3D_precomp != nullptr) {
 #pragma unroll
 				for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
 			} else {
 				float inv_len;
-				const float3 sc = gs_act_scale({scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]}, act);
-				const float4 q = gs_act_rot(*reinterpret_cast<const float4*>(rotations + 4 * (size_t)idx), act, &inv_len);
+				const float3 sc = gs_act_scale(sc_raw, act);
+				const float4 q = gs_act_rot(q_raw, act, &inv_len);
 				cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
 			}
 			Cov2D c;
@@ -118,103 +202,52 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 			const float det = FMA(-cov_y, cov_y, cov_x * cov_z);
 			if (det == 0.0f) break;
 			const float det_inv = 1.f / det;
-			const float conic_x = cov_z * det_inv, conic_y = -cov_y * det_inv, conic_z = cov_x * det_inv;
+			conic_x = cov_z * det_inv; conic_y = -cov_y * det_inv; conic_z = cov_x * det_inv;
 			const float mid = 0.5f * (cov_x + cov_z);
 			const float disc = sqrtf(fmaxf(0.1f, FMA(mid, mid, -det)));
 			const float lambda1 = mid + disc, lambda2 = mid - disc;
 			const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
 			// ndc2Pix in double (auxiliary.h:41-44)
-			const float pix_x = (float)((((double)p_proj_x + 1.0) * (double)W - 1.0) * 0.5);
-			const float pix_y = (float)((((double)p_proj_y + 1.0) * (double)H - 1.0) * 0.5);
+			pix_x = (float)((((double)p_proj_x + 1.0) * (double)W - 1.0) * 0.5);
+			pix_y = (float)((((double)p_proj_y + 1.0) * (double)H - 1.0) * 0.5);
 			// getRect (auxiliary.h:46-56)
-			const int mr = (int)my_radius;
-			rminx = min(gx, max(0, (int)((pix_x - mr) / GSR_BLOCK_X)));
-			rminy = min(gy, max(0, (int)((pix_y - mr) / GSR_BLOCK_Y)));
-			rmaxx = min(gx, max(0, (int)((pix_x + mr + GSR_BLOCK_X - 1) / GSR_BLOCK_X)));
-			rmaxy = min(gy, max(0, (int)((pix_y + mr + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y)));
+			const int r_ = (int)my_radius;
+			rminx = min(gx, max(0, (int)((pix_x - r_) / GSR_BLOCK_X)));
+			rminy = min(gy, max(0, (int)((pix_y - r_) / GSR_BLOCK_Y)));
+			rmaxx = min(gx, max(0, (int)((pix_x + r_ + GSR_BLOCK_X - 1) / GSR_BLOCK_X)));
+			rmaxy = min(gy, max(0, (int)((pix_y + r_ + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y)));
 			if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
-
-			float rgb[3];
-			uint32_t clamped = 0;
-			if (colors_precomp == nullptr) {
-				// computeColorFromSH (forward.cu:20-71)
-				constexpr int NC = (D + 1) * (D + 1);
-				float sh[NC * 3];
-				const float* shp = shs + (size_t)idx * M * 3;
-				if (shs_rest != nullptr) {
-					// split storage (f_dc [P,1,3] + f_rest [P,M-1,3], models/vanilla_sg.py:103-106): no torch.cat copy
-					const float* dcp = shs + 3 * (size_t)idx;
-					const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
-					sh[0] = dcp[0]; sh[1] = dcp[1]; sh[2] = dcp[2];
-#pragma unroll
-					for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
-				} else if (sh_vec4 && (NC * 3) % 4 == 0) {
-#pragma unroll
-					for (int i = 0; i < NC * 3 / 4; i++) {
-						const float4 v = reinterpret_cast<const float4*>(shp)[i];
-						sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
-					}
-				} else {
-#pragma unroll
-					for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
-				}
-				float3 dir = {p_orig.x - cam->campos[0], p_orig.y - cam->campos[1], p_orig.z - cam->campos[2]};
-				const float len = sqrtf(FMA(dir.z, dir.z, FMA(dir.y, dir.y, dir.x * dir.x)));
-				dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
-				const float x = dir.x, y = dir.y, z = dir.z;
-#pragma unroll
-				for (int ch = 0; ch < 3; ch++) {
-#define SH(k) sh[(k) * 3 + ch]
-					float r = kSH_C0 * SH(0);
-					if (D > 0) {
-						r = FMA(-(kSH_C1 * y), SH(1), r);
-						r = FMA(kSH_C1 * z, SH(2), r);
-						r = FMA(-(kSH_C1 * x), SH(3), r);
-						if (D > 1) {
-							const float xx = x * x, yy = y * y, zz = z * z;
-							const float xy = x * y, yz = y * z, xz = x * z;
-							r = FMA(kSH_C2[0] * xy, SH(4), r);
-							r = FMA(kSH_C2[1] * yz, SH(5), r);
-							r = FMA(kSH_C2[2] * (FMA(2.0f, zz, -xx) - yy), SH(6), r);
-							r = FMA(kSH_C2[3] * xz, SH(7), r);
-							r = FMA(kSH_C2[4] * (xx - yy), SH(8), r);
-							if (D > 2) {
-								r = FMA(kSH_C3[0] * y * FMA(3.0f, xx, -yy), SH(9), r);
-								r = FMA(kSH_C3[1] * xy * z, SH(10), r);
-								r = FMA(kSH_C3[2] * y * (FMA(4.0f, zz, -xx) - yy), SH(11), r);
-								r = FMA(kSH_C3[3] * z * FMA(-3.0f, yy, FMA(-3.0f, xx, 2.0f * zz)), SH(12), r);
-								r = FMA(kSH_C3[4] * x * (FMA(4.0f, zz, -xx) - yy), SH(13), r);
-								r = FMA(kSH_C3[5] * z * (xx - yy), SH(14), r);
-								r = FMA(kSH_C3[6] * x * FMA(-3.0f, yy, xx), SH(15), r);
-							}
-						}
-					}
-#undef SH
-					r += 0.5f;
-					if (r < 0) clamped |= 1u << ch;
-					rgb[ch] = fmaxf(r, 0.0f);
-				}
-			} else {
-				rgb[0] = colors_precomp[3 * (size_t)idx];
-				rgb[1] = colors_precomp[3 * (size_t)idx + 1];
-				rgb[2] = colors_precomp[3 * (size_t)idx + 2];
-			}
-			const float op = gs_act_opacity(opacities[idx], act);
-			// pcut: power < pcut  ==>  op*exp(power) < 1/255 with a 1e-3 margin, so skipping the pair is
-			// bit-identical to evaluating it and failing `alpha < 1/255` (forward.cu:346).  Clamped to the
-			// domain of gs_exp.  op <= 0 -> +inf (always skipped); NaN -> -80 (never skipped by pcut).
-			const float pcut = fmaxf(-__logf(255.0f * op) - 0.001f, -80.0f);
-			my_radius_i = mr;
+			mr = r_;
+			depth = p_view.z;
 			vis = true;
-			GsRec rec;
-			rec.q0 = make_float4(pix_x, pix_y, -0.5f * conic_x, -conic_y);
-			rec.q1 = make_float4(-0.5f * conic_z, op, p_view.z, pcut);
-			rec.q2 = make_float4(rgb[0], rgb[1], rgb[2], __int_as_float(mr));
-			rec.q3 = make_uint4((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16),
-			                    clamped, (uint32_t)((rmaxy - rminy) * (rmaxx - rminx)));
-			recs[idx] = rec;
 		} while (0);
-		radii[idx] = my_radius_i;
+	}
+
+	if (vis) {
+		float rgb[3];
+		uint32_t clamped = 0;
+		if (colors_precomp == nullptr) {
+			clamped = gs_sh_to_rgb<D>(sh, p_orig, cam, rgb);
+		} else {
+			rgb[0] = colors_precomp[3 * (size_t)idx];
+			rgb[1] = colors_precomp[3 * (size_t)idx + 1];
+			rgb[2] = colors_precomp[3 * (size_t)idx + 2];
+		}
+		const float op = gs_act_opacity(op_raw, act);
+		// pcut: power < pcut  ==>  op*exp(power) < 1/255 with a 1e-3 margin, so skipping the pair is
+		// bit-identical to evaluating it and failing `alpha < 1/255` (forward.cu:346).  Clamped to the
+		// domain of gs_exp.  op <= 0 -> +inf (always skipped); NaN -> -80 (never skipped by pcut).
+		const float pcut = fmaxf(-__logf(255.0f * op) - 0.001f, -80.0f);
+		GsRec rec;
+		rec.q0 = make_float4(pix_x, pix_y, -0.5f * conic_x, -conic_y);
+		rec.q1 = make_float4(-0.5f * conic_z, op, depth, pcut);
+		rec.q2 = make_float4(rgb[0], rgb[1], rgb[2], __int_as_float(mr));
+		rec.q3 = make_uint4((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16),
+		                    clamped, (uint32_t)((rmaxy - rminy) * (rmaxx - rminx)));
+		recs[idx] = rec;
+	}
+	if (idx < P) {
+		radii[idx] = vis ? mr : 0;
 		tiles_touched[idx] = vis ? (uint32_t)((rmaxy - rminy) * (rmaxx - rminx)) : 0u;
 	}
 	// fallback binning only (tile grids too large for the LDS histogram): count instances per tile with
@@ -230,19 +263,23 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 	const float focal_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:225-226
 	const float focal_x = a.W / (2.0f * a.tan_fovx);
 	const int sh_vec4 = (a.shs != nullptr && ((uintptr_t)a.shs % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0;
-	dim3 grid((a.P + 255) / 256), block(256);
-#define GSR_LAUNCH_PRE(DEG)                                                                                        \
-	hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.scales,               \
-	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.shs_rest, a.act, a.cov3D_precomp, a.colors_precomp, cam,   \
-	                   a.W, a.H, a.tan_fovx, a.tan_fovy, focal_x, focal_y, il.gx, il.gy, a.prefiltered, sh_vec4,     \
-	                   radii, recs, tiles_touched, tile_count, ctl)
 	const int D = a.colors_precomp ? 0 : a.D;
-	switch (D) {
-		case 0: GSR_LAUNCH_PRE(0); break;
-		case 1: GSR_LAUNCH_PRE(1); break;
-		case 2: GSR_LAUNCH_PRE(2); break;
-		default: GSR_LAUNCH_PRE(3); break;
+	dim3 grid((a.P + 255) / 256), block(256);
+#define GSR_LAUNCH_PRE(DEG, RAW)                                                                                   \
+	hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, RAW>), grid, block, 0, s, a.P, a.M, a.means3D, a.scales,        \
+	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.shs_rest, a.act, a.cov3D_precomp,       \
+	                   a.colors_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, focal_x, focal_y, il.gx, il.gy,     \
+	                   a.prefiltered, sh_vec4, radii, recs, tiles_touched, tile_count, ctl)
+#define GSR_LAUNCH_PRE_D(RAW)                          \
+	switch (D) {                                       \
+		case 0: GSR_LAUNCH_PRE(0, RAW); break;         \
+		case 1: GSR_LAUNCH_PRE(1, RAW); break;         \
+		case 2: GSR_LAUNCH_PRE(2, RAW); break;         \
+		default: GSR_LAUNCH_PRE(3, RAW); break;        \
 	}
+	if (a.shs_rest != nullptr || a.act != 0) { GSR_LAUNCH_PRE_D(true) }
+	else { GSR_LAUNCH_PRE_D(false) }
+#undef GSR_LAUNCH_PRE_D
 #undef GSR_LAUNCH_PRE
 }
 
@@ -254,6 +291,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
 {
 	__shared__ uint32_t s_wave[16];
 	__shared__ uint32_t s_max[16];
+	__shared__ uint64_t s_wave64[16];
 	const int tid = threadIdx.x;
 	const int chunk = (T + 1023) / 1024;
 	const int b = tid * chunk, e = min(T, b + chunk);
@@ -273,13 +311,18 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+	uint64_t wsum = sum;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) wsum += (uint64_t)__shfl_xor((long long)wsum, o, 64);
 	if (lane == 63) s_wave[wv] = incl;
-	if (lane == 0) s_max[wv] = mx;
+	if (lane == 0) { s_max[wv] = mx; s_wave64[wv] = wsum; }
 	__syncthreads();
 	uint32_t base = 0, total = 0, gmax = 0;
+	uint64_t total64 = 0;                      // the u32 scan wraps past 2^32 instances; the host rejects > 2^31 - 1
 	for (int w = 0; w < 16; w++) {
 		if (w < wv) base += s_wave[w];
 		total += s_wave[w];
+		total64 += s_wave64[w];
 		gmax = max(gmax, s_max[w]);
 	}
 	uint32_t run = base + incl - sum;
@@ -292,6 +335,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
 	if (tid == 0) {
 		ctl->num_rendered = total;
 		ctl->max_tile_count = gmax;
+		ctl->err_overflow = total64 > 0x7fffffffull ? 1u : 0u;
 	}
 }
 
@@ -492,85 +536,117 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint2* __restrict_
 //   equal digits inside the group with 8 ballots (match-any) -- stable by construction.
 // Equal depths come out in arbitrary id order (the scatter order is arbitrary), so a final pass orders every run
 // of equal depth by id: the key (depth, id) ordering of the reference's stable radix sort.
+// One stable counting pass on the 8 bits at `shift` from src to dst (see tile_radix_sort_kernel).
+__device__ __forceinline__ void tile_radix_pass(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int shift,
+                                                uint32_t wb, uint32_t we, uint32_t (*whist)[256], uint32_t* s_tot)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	for (int i = tid; i < 1024; i += 256) (&whist[0][0])[i] = 0;
+	__syncthreads();
+	for (uint32_t i = wb + lane; i < we; i += 64) atomicAdd(&whist[wv][(uint32_t)(src[i] >> shift) & 255u], 1u);
+	__syncthreads();
+	// thread d: exclusive offsets of digit d for the four waves; then add the prefix over digits
+	{
+		const uint32_t c0 = whist[0][tid], c1 = whist[1][tid], c2 = whist[2][tid], c3 = whist[3][tid];
+		const uint32_t tot = c0 + c1 + c2 + c3;
+		uint32_t incl = tot;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) s_tot[wv] = incl;
+		__syncthreads();
+		uint32_t base = incl - tot;
+		for (int w = 0; w < wv; w++) base += s_tot[w];
+		whist[0][tid] = base;
+		whist[1][tid] = base + c0;
+		whist[2][tid] = base + c0 + c1;
+		whist[3][tid] = base + c0 + c1 + c2;
+	}
+	__syncthreads();
+	for (uint32_t g0 = wb; g0 < we; g0 += 64) {
+		const uint32_t i = g0 + lane;
+		const bool act = i < we;
+		const uint64_t k = act ? src[i] : 0ull;
+		const uint32_t d = act ? (uint32_t)(k >> shift) & 255u : 256u;
+		// lanes holding the same digit (match-any over 8 bits)
+		unsigned long long same = __ballot(act);
+#pragma unroll
+		for (int b = 0; b < 8; b++) {
+			const unsigned long long bm = __ballot((d >> b) & 1u);
+			same &= ((d >> b) & 1u) ? bm : ~bm;
+		}
+		if (act) {
+			const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+			const uint32_t base = whist[wv][d];
+			dst[base + rank] = k;
+			if (rank == 0) whist[wv][d] = base + (uint32_t)__popcll(same);   // group leader advances the cursor
+		}
+	}
+	__syncthreads();
+}
+
 __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __restrict__ ranges,
                                                               uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
                                                               uint32_t* __restrict__ point_list, uint32_t lo)
 {
 	__shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave running offsets
 	__shared__ uint32_t s_tot[4];
+	__shared__ uint32_t s_maxrun;
 	const uint2 range = ranges[blockIdx.x];
 	const uint32_t n = range.y - range.x;
 	if (n <= lo) return;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int tid = threadIdx.x, wv = tid >> 6;
 	uint64_t* src = keys + range.x;
 	uint64_t* dst = keys2 + range.x;
 	// wave w owns [wb, we): quarters rounded to multiples of 64 so that groups never straddle waves
 	const uint32_t per = ((n + 3) / 4 + 63) / 64 * 64;
 	const uint32_t wb = min(n, (uint32_t)wv * per), we = min(n, wb + per);
-	for (int pass = 0; pass < 4; pass++) {
-		const int shift = 32 + 8 * pass;
-		for (int i = tid; i < 1024; i += 256) (&whist[0][0])[i] = 0;
-		__syncthreads();
-		for (uint32_t i = wb + lane; i < we; i += 64) atomicAdd(&whist[wv][(uint32_t)(src[i] >> shift) & 255u], 1u);
-		__syncthreads();
-		// thread d: exclusive offsets of digit d for the four waves; then add the prefix over digits
-		{
-			const uint32_t c0 = whist[0][tid], c1 = whist[1][tid], c2 = whist[2][tid], c3 = whist[3][tid];
-			const uint32_t tot = c0 + c1 + c2 + c3;
-			uint32_t incl = tot;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) {
-				const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-				if (lane >= o) incl += t;
-			}
-			if (lane == 63) s_tot[wv] = incl;
-			__syncthreads();
-			uint32_t base = incl - tot;
-			for (int w = 0; w < wv; w++) base += s_tot[w];
-			whist[0][tid] = base;
-			whist[1][tid] = base + c0;
-			whist[2][tid] = base + c0 + c1;
-			whist[3][tid] = base + c0 + c1 + c2;
-		}
-		__syncthreads();
-		for (uint32_t g0 = wb; g0 < we; g0 += 64) {
-			const uint32_t i = g0 + lane;
-			const bool act = i < we;
-			const uint64_t k = act ? src[i] : 0ull;
-			const uint32_t d = act ? (uint32_t)(k >> shift) & 255u : 256u;
-			// lanes holding the same digit (match-any over 8 bits)
-			unsigned long long same = __ballot(act);
-#pragma unroll
-			for (int b = 0; b < 8; b++) {
-				const unsigned long long bm = __ballot((d >> b) & 1u);
-				same &= ((d >> b) & 1u) ? bm : ~bm;
-			}
-			if (act) {
-				const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-				const uint32_t base = whist[wv][d];
-				dst[base + rank] = k;
-				if (rank == 0) whist[wv][d] = base + (uint32_t)__popcll(same);   // group leader advances the cursor
-			}
-		}
-		__syncthreads();
-		uint64_t* t = src; src = dst; dst = t;
+	if (tid == 0) s_maxrun = 0;
+	for (int pass = 0; pass < 4; pass += 2) {   // an even number of passes leaves the data in `keys`
+		tile_radix_pass(src, dst, 32 + 8 * pass, wb, we, whist, s_tot);
+		tile_radix_pass(dst, src, 40 + 8 * pass, wb, we, whist, s_tot);
 	}
-	// after 4 passes the data is back in `keys`; order runs of equal depth by id (rare), then emit the ids
+	// Runs of equal depth are in scatter order.  Measure the longest one (capped): short runs (the normal case:
+	// isolated float ties) are put in id order by one thread each; long runs (a fronto-parallel sheet of Gaussians
+	// all at one depth) would make that quadratic in one thread, so the whole list is re-sorted as a full 64-bit
+	// stable LSD sort instead: four passes on the id bits, then the four depth passes again.
+	const uint32_t RUN_CAP = 32;
+	uint32_t myrun = 0;
 	for (uint32_t i = tid; i < n; i += 256) {
 		const uint32_t dep = (uint32_t)(src[i] >> 32);
-		const bool starts = (i == 0 || (uint32_t)(src[i - 1] >> 32) != dep) && (i + 1 < n) && (uint32_t)(src[i + 1] >> 32) == dep;
-		if (starts) {
+		if (i == 0 || (uint32_t)(src[i - 1] >> 32) != dep) {
 			uint32_t e = i + 1;
-			while (e < n && (uint32_t)(src[e] >> 32) == dep) e++;
-			for (uint32_t a = i + 1; a < e; a++) {   // insertion sort of the run [i, e) by full key (= by id)
-				const uint64_t v = src[a];
-				uint32_t b = a;
-				while (b > i && src[b - 1] > v) { src[b] = src[b - 1]; b--; }
-				src[b] = v;
-			}
+			while (e < n && e - i <= RUN_CAP && (uint32_t)(src[e] >> 32) == dep) e++;
+			myrun = max(myrun, e - i);
 		}
 	}
+	if (myrun > 1) atomicMax(&s_maxrun, myrun);
 	__syncthreads();
+	const uint32_t maxrun = s_maxrun;
+	if (maxrun > RUN_CAP) {
+		for (int pass = 0; pass < 8; pass += 2) {
+			tile_radix_pass(src, dst, 8 * pass, wb, we, whist, s_tot);
+			tile_radix_pass(dst, src, 8 * pass + 8, wb, we, whist, s_tot);
+		}
+	} else if (maxrun > 1) {
+		for (uint32_t i = tid; i < n; i += 256) {
+			const uint32_t dep = (uint32_t)(src[i] >> 32);
+			const bool starts = (i == 0 || (uint32_t)(src[i - 1] >> 32) != dep) && (i + 1 < n) && (uint32_t)(src[i + 1] >> 32) == dep;
+			if (starts) {
+				uint32_t e = i + 1;
+				while (e < n && (uint32_t)(src[e] >> 32) == dep) e++;
+				for (uint32_t a = i + 1; a < e; a++) {   // insertion sort of the run [i, e) by full key (= by id)
+					const uint64_t v = src[a];
+					uint32_t b = a;
+					while (b > i && src[b - 1] > v) { src[b] = src[b - 1]; b--; }
+					src[b] = v;
+				}
+			}
+		}
+		__syncthreads();
+	}
 	for (uint32_t i = tid; i < n; i += 256) point_list[range.x + i] = (uint32_t)src[i];
 }
 

@@ -72,10 +72,11 @@ def test_long_tile_lists_lds_and_global_sort(oracle, P, lo, hi):
     compare_forward_exact(hs, os_)
 
 
-@pytest.mark.parametrize("P", [2000, 40000])
+@pytest.mark.parametrize("P", [2000, 40000, 300000])
 def test_depth_ties_resolve_by_id(oracle, P):
     """Equal depths inside a tile must order by ascending Gaussian id; P=40000 puts ~10 k keys
-    with only ~18 distinct depths in each tile, i.e. the radix path's equal-depth run fix-up."""
+    with only ~18 distinct depths in each tile (runs of ~500 equal depths), P=300000 ~75 k keys with runs of
+    ~4 k: the radix path's long-run branch (full 64-bit LSD sort instead of the per-run fix-up)."""
     cam = scenes.make_camera(64, 64)
     sc = scenes.make_scene(P, cam, seed=17, sigma_px_median=4.0)
     means = sc.means3D.clone()

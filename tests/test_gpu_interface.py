@@ -142,3 +142,25 @@ def test_profiling_stage_times_reported():
     _C.set_profiling(False)
     assert ms is not None and ms["calls"] == 3 and ms["composite"] > 0 and ms["preprocess"] > 0
     assert _C.last_forward_ms() is None
+
+
+def test_instance_count_beyond_int32_is_an_error_not_a_wraparound():
+    """150 k Gaussians that each cover all 32 400 tiles of a 3840x2160 frame are 4.86e9 instances: more than the
+    reference's `int num_rendered` can hold and past a 32-bit wrap (it would come back as ~5.7e8)."""
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(3840, 2160)
+    P = 150_000
+    g = torch.Generator().manual_seed(1)
+    means = torch.cat([torch.randn(P, 2, generator=g) * 0.05, 5.0 + torch.rand(P, 1, generator=g)], dim=1).cuda()
+    e = torch.Tensor([])
+    with pytest.raises(RuntimeError, match="instances"):
+        _C.rasterize_gaussians(torch.zeros(3), means, torch.rand(P, 3, generator=g).cuda(), torch.full((P, 1), 0.01).cuda(),
+                               torch.full((P, 3), 4.0).cuda(), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1).cuda(), 1.0, e,
+                               cam.viewmatrix.cuda(), cam.projmatrix.cuda(), cam.tanfovx, cam.tanfovy, 2160, 3840, e, 0,
+                               cam.campos.cuda(), False, False)
+    # the library is usable afterwards
+    out = _C.rasterize_gaussians(torch.zeros(3), means[:10], torch.rand(10, 3).cuda(), torch.full((10, 1), 0.5).cuda(),
+                                 torch.full((10, 3), 0.01).cuda(), torch.tensor([[1.0, 0, 0, 0]]).repeat(10, 1).cuda(), 1.0, e,
+                                 cam.viewmatrix.cuda(), cam.projmatrix.cuda(), cam.tanfovx, cam.tanfovy, 2160, 3840, e, 0,
+                                 cam.campos.cuda(), False, False)
+    assert out[0] > 0
