@@ -133,6 +133,17 @@ hipError_t stage_small(const float* const src[4], float* const dst[4], const int
 	return hipGetLastError();
 }
 
+// One event per host thread and device for the forward's read-back: the host waits for the 16-byte copy only,
+// not for what was enqueued behind it.
+hipEvent_t readback_event()
+{
+	thread_local hipEvent_t ev[16] = {};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+	if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
+	return ev[dev];
+}
+
 uint32_t* pinned_words()
 {
 	thread_local uint32_t* p = nullptr;
@@ -336,7 +347,16 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	uint32_t* host = pinned_words();
 	if (!host) return fail(GSR_ERR_HIP, "hipHostMalloc", __FILE__, __LINE__);
 	HIP_TRY(hipMemcpyAsync(host, ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
+	hipEvent_t ev = readback_event();
+	if (ev) HIP_TRY(hipEventRecord(ev, s));
+	// While the host waits for R (and then sizes the binning buffer and launches the rest), the device computes
+	// goff = exclusive scan of tiles_touched, which only the backward needs: it fills the bubble instead of
+	// costing the backward three launches.
+	launch_gaussian_scan(P, tiles_touched, reinterpret_cast<uint32_t*>(geom + gl.goff),
+	                     reinterpret_cast<uint32_t*>(geom + gl.bsums), s);
+	if (ev) HIP_TRY(hipEventSynchronize(ev));
+	else HIP_TRY(hipStreamSynchronize(s));
+	STAGE_CHECK("gaussian_scan", debug, s);
 	const uint32_t R = host[0], max_tile = host[1], err_pref = host[2];
 	if (err_pref)
 		return fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!",
@@ -440,10 +460,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	const float* final_T = reinterpret_cast<const float*>(image_buffer + il.final_T);
 	const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + il.n_contrib);
 	const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + bl.point_list);
-	const uint32_t* tiles_touched = reinterpret_cast<const uint32_t*>(geom_buffer + gl.tiles_touched);
 	const BwdLayout wl((size_t)P, (size_t)(R > 0 ? R : 0));
-	uint32_t* goff = reinterpret_cast<uint32_t*>(scratch + wl.goff);
-	uint32_t* bsums = reinterpret_cast<uint32_t*>(scratch + wl.bsums);
+	const uint32_t* goff = reinterpret_cast<const uint32_t*>(geom_buffer + gl.goff);   // scanned by the forward
 	float* bg_dev = reinterpret_cast<float*>(scratch + wl.bg);
 	float* rows = reinterpret_cast<float*>(scratch + wl.rows);
 
@@ -457,8 +475,6 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 		HIP_TRY(stage_small(src, dst, n, s));
 	}
 	HIP_TRY(hipMemsetAsync(rows, 0, sizeof(float) * GSR_ROW_STRIDE * (size_t)(R > 0 ? R : 1), s));
-	launch_gaussian_scan(P, tiles_touched, goff, bsums, s);
-	STAGE_CHECK("gaussian_scan", debug, s);
 
 	BwdArgs a;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
@@ -544,7 +560,7 @@ int gsr_inspect_backward_sums(const char* geom_buffer, const char* scratch, int 
 	const GeomLayout gl((size_t)P);
 	const BwdLayout wl((size_t)P, (size_t)(R > 0 ? R : 0));
 	launch_inspect_sums(P, radii, reinterpret_cast<const GsRec*>(geom_buffer + gl.recs),
-	                    reinterpret_cast<const uint32_t*>(scratch + wl.goff),
+	                    reinterpret_cast<const uint32_t*>(geom_buffer + gl.goff),
 	                    reinterpret_cast<const float*>(scratch + wl.rows), sums, s);
 	STAGE_CHECK("inspect_backward_sums", 0, s);
 	return GSR_OK;

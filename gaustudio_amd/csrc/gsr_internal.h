@@ -7,17 +7,23 @@ namespace gsr {
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-// geometry buffer: [GsCam][GsRec x P][tiles_touched u32 x P]   (replaces GeometryState, rasterizer_impl.h:33-48:
-// depths/clamped/radii/means2D/cov3D/conic_opacity/rgb/point_offsets/tiles_touched/scan space = 79 B/Gaussian
-// in 9 arrays; here one 64-B record, cov3D is recomputed in backward instead of stored)
+// geometry buffer: [GsCam][GsRec x P][tiles_touched u32 x P][goff u32 x (P+1)][scan block sums]
+// (replaces GeometryState, rasterizer_impl.h:33-48: depths/clamped/radii/means2D/cov3D/conic_opacity/rgb/
+// point_offsets/tiles_touched/scan space = 79 B/Gaussian in 9 arrays; here one 64-B record, cov3D is recomputed
+// in backward instead of stored).  goff = exclusive scan of tiles_touched (the reference's point_offsets, shifted):
+// the backward's Gaussian-major row index; computed by the forward while the host waits for num_rendered.
+#define GSR_SCAN_BLOCK 2048
 struct GeomLayout {
-	size_t cam, recs, tiles_touched, total;
+	size_t cam, recs, tiles_touched, goff, bsums, total;
 	explicit GeomLayout(size_t P)
 	{
+		const size_t nb = (P + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
 		cam = 0;
 		recs = align_up(sizeof(GsCam));
-		tiles_touched = recs + align_up(sizeof(GsRec) * P);          // compact u32[P] (0 for culled), for the backward's scan
-		total = tiles_touched + align_up(sizeof(uint32_t) * P);
+		tiles_touched = recs + align_up(sizeof(GsRec) * P);          // compact u32[P] (0 for culled)
+		goff = tiles_touched + align_up(sizeof(uint32_t) * P);
+		bsums = goff + align_up(sizeof(uint32_t) * (P + 1));
+		total = bsums + align_up(sizeof(uint32_t) * (nb + 1));
 	}
 };
 
@@ -118,17 +124,13 @@ struct BwdArgs {
 //   row: 0,1 dL_dmean2D.xy | 2,3,4 dL_dconic a,b,c | 5 dL_dopacity | 6,7,8 dL_dcolor | 9 dL_ddepth | 10,11 unused
 #define GSR_ROW_STRIDE 12
 #define GSR_SUM_SLAB 160   // rows per LDS slab of preprocess_bwd's cooperative row fetch (7.5 KiB per wave)
-// scratch: [goff u32 x (P+1)][block sums u32 x (nb+1)][bg f32 x 4][rows f32 x R*12]
-#define GSR_SCAN_BLOCK 2048
+// scratch: [bg f32 x 4][rows f32 x R*12]
 struct BwdLayout {
-	size_t goff, bsums, bg, rows, total;
-	size_t nb;
+	size_t bg, rows, total;
 	BwdLayout(size_t P, size_t R)
 	{
-		nb = (P + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
-		goff = 0;
-		bsums = align_up(sizeof(uint32_t) * (P + 1));
-		bg = bsums + align_up(sizeof(uint32_t) * (nb + 1));
+		(void)P;
+		bg = 0;
 		rows = bg + 256;
 		total = rows + align_up(sizeof(float) * GSR_ROW_STRIDE * (R > 0 ? R : 1));
 	}

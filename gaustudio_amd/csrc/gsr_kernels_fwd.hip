@@ -388,8 +388,11 @@ void launch_bin_scatter(int P, int gx, const int* radii, const GsRec* recs, cons
 //   bin_scatter2  per chunk: LDS cursors = ranges[t].x + Hm[g][t]; every instance takes its slot with a
 //                 returning LDS atomic and stores its (depth, id) key.
 // Order inside a tile is arbitrary here; tile_sort makes it (depth, id) as before.
+// One 1024-thread workgroup per chunk (16 waves per CU instead of 4 hide the record-fetch latency: the kernels are
+// latency-, not bandwidth-bound).
+#define GSR_BIN_THREADS 1024
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void bin_chunk_kernel(int P, int chunk, int gx, int T,
+__global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int chunk, int gx, int T,
                                                         const uint32_t* __restrict__ tiles_touched,
                                                         const GsRec* __restrict__ recs,
                                                         uint32_t* __restrict__ Hm, const uint2* __restrict__ ranges,
@@ -398,11 +401,12 @@ __global__ __launch_bounds__(256) void bin_chunk_kernel(int P, int chunk, int gx
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
 	const int tid = threadIdx.x;
-	uint32_t* row = Hm + (size_t)blockIdx.x * T;
-	for (int i = tid; i < T; i += 256) cnt[i] = SCATTER ? ranges[i].x + row[i] : 0u;
+	const int g = blockIdx.x;   // (an XCD-banded chunk order was measured: no effect on the scatter)
+	uint32_t* row = Hm + (size_t)g * T;
+	for (int i = tid; i < T; i += GSR_BIN_THREADS) cnt[i] = SCATTER ? ranges[i].x + row[i] : 0u;
 	__syncthreads();
-	const int base = blockIdx.x * chunk;
-	for (int off = 0; off < chunk; off += 256) {
+	const int base = g * chunk;
+	for (int off = 0; off < chunk; off += GSR_BIN_THREADS) {
 		const int idx = base + off + tid;
 		bool vis = false;
 		int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
@@ -421,19 +425,20 @@ __global__ __launch_bounds__(256) void bin_chunk_kernel(int P, int chunk, int gx
 	}
 	if (!SCATTER) {
 		__syncthreads();
-		for (int i = tid; i < T; i += 256) row[i] = cnt[i];
+		for (int i = tid; i < T; i += GSR_BIN_THREADS) row[i] = cnt[i];
 	}
 }
 
-// thread (t, q): tile t, quarter q of the chunks; exclusive prefix over chunks in place, totals out
-__global__ __launch_bounds__(256) void bin_colscan_kernel(int G, int T, uint32_t* __restrict__ Hm,
-                                                          uint32_t* __restrict__ tile_count)
+// thread (t, q): tile t, sixteenth q of the chunks; exclusive prefix over chunks in place, totals out
+#define GSR_COLSCAN_Q 16
+__global__ __launch_bounds__(64 * GSR_COLSCAN_Q) void bin_colscan_kernel(int G, int T, uint32_t* __restrict__ Hm,
+                                                                         uint32_t* __restrict__ tile_count)
 {
-	__shared__ uint32_t s_q[4][64];
+	__shared__ uint32_t s_q[GSR_COLSCAN_Q][64];
 	const int tl = threadIdx.x & 63, q = threadIdx.x >> 6;
 	const int t = blockIdx.x * 64 + tl;
-	const int per = (G + 3) / 4;
-	const int g0 = q * per, g1 = min(G, g0 + per);
+	const int per = (G + GSR_COLSCAN_Q - 1) / GSR_COLSCAN_Q;
+	const int g0 = min(G, q * per), g1 = min(G, g0 + per);
 	uint32_t sum = 0;
 	if (t < T)
 		for (int g = g0; g < g1; g++) sum += Hm[(size_t)g * T + t];
@@ -447,11 +452,11 @@ __global__ __launch_bounds__(256) void bin_colscan_kernel(int G, int T, uint32_t
 			Hm[(size_t)g * T + t] = run;
 			run += v;
 		}
-		if (q == 3) tile_count[t] = run;
+		if (q == GSR_COLSCAN_Q - 1) tile_count[t] = run;
 	}
 }
 
-int bin_chunks(int P) { return P >= 256 * 256 ? 256 : (P + 255) / 256; }
+int bin_chunks(int P) { return P >= 256 * GSR_BIN_THREADS ? 256 : (P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS; }
 size_t bin_hist_bytes(int P, int T) { return sizeof(uint32_t) * (size_t)bin_chunks(P) * (size_t)T; }
 bool bin_lds_path_ok(int T) { return (size_t)T * sizeof(uint32_t) <= 150 * 1024; }
 
@@ -464,67 +469,106 @@ void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const 
                      uint32_t* tile_count, hipStream_t s)
 {
 	const int G = bin_chunks(P);
-	const int chunk = ((P + G - 1) / G + 255) / 256 * 256;
+	const int chunk = ((P + G - 1) / G + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS * GSR_BIN_THREADS;
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<false>, lds);
-	hipLaunchKernelGGL(bin_chunk_kernel<false>, dim3(G), dim3(256), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
+	hipLaunchKernelGGL(bin_chunk_kernel<false>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
 	                   (const uint2*)nullptr, (uint64_t*)nullptr);
-	hipLaunchKernelGGL(bin_colscan_kernel, dim3((T + 63) / 64), dim3(256), 0, s, G, T, Hm, tile_count);
+	hipLaunchKernelGGL(bin_colscan_kernel, dim3((T + 63) / 64), dim3(64 * GSR_COLSCAN_Q), 0, s, G, T, Hm, tile_count);
 }
 
 void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
                          const uint2* ranges, uint64_t* keys, hipStream_t s)
 {
 	const int G = bin_chunks(P);
-	const int chunk = ((P + G - 1) / G + 255) / 256 * 256;
+	const int chunk = ((P + G - 1) / G + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS * GSR_BIN_THREADS;
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<true>, lds);
-	hipLaunchKernelGGL(bin_chunk_kernel<true>, dim3(G), dim3(256), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
+	hipLaunchKernelGGL(bin_chunk_kernel<true>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
 	                   ranges, keys);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-tile sort of short lists (n <= hi <= GSR_SORT_LDS_MAX keys) in LDS.  Normalised bitonic network (every
-// comparator ascending), so that virtual +inf padding beyond n never moves and arbitrary n needs no padding.
-__global__ __launch_bounds__(256) void tile_sort_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ point_list, uint32_t hi)
+// Per-tile sort of short lists (n <= GSR_SORT_LDS_MAX = 1024 keys): ONE wave per tile, the keys live in registers
+// (KPL = 1..16 64-bit keys per lane, blocked: key index = lane*KPL + e), and the whole bitonic network runs without
+// LDS storage or barriers: compare-exchanges at strides < KPL are register-to-register (fully unrolled), strides
+// >= KPL exchange with lane ^ m through ds_bpermute.  For ~500 keys that is ~1.5 k wave-instructions per tile
+// against ~3.6 k plus 45 workgroup barriers for the four-wave LDS network it replaces (78 us at C3).
+// Unused slots hold +inf keys; (depth, id) keys are unique, so there are no ties.
+__device__ __forceinline__ void gs_cex(uint64_t& a, uint64_t& b, bool asc)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	uint64_t* a = reinterpret_cast<uint64_t*>(smem_raw);
-	const uint2 range = ranges[blockIdx.x];
-	const uint32_t n = range.y - range.x;
-	if (n == 0 || n > hi) return;   // empty, or handled by tile_radix_sort
-	const uint32_t tid = threadIdx.x;
-	const uint64_t* g = keys + range.x;
-	for (uint32_t i = tid; i < n; i += 256) a[i] = g[i];
-	__syncthreads();
-	uint32_t npad = 2;
-	while (npad < n) npad <<= 1;
-	const uint32_t half = npad >> 1;
-	for (uint32_t k = 2; k <= npad; k <<= 1) {
-		// first step of the merge: i <-> (block end - offset)
-		const uint32_t hk = k >> 1;
-		for (uint32_t t = tid; t < half; t += 256) {
-			const uint32_t blk = t / hk, off = t % hk;
-			const uint32_t i = blk * k + off, p = blk * k + (k - 1 - off);
-			if (p < n) {
-				const uint64_t x = a[i], y = a[p];
-				if (x > y) { a[i] = y; a[p] = x; }
-			}
-		}
-		__syncthreads();
-		for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-			for (uint32_t t = tid; t < half; t += 256) {
-				const uint32_t i = ((t / j) * (j << 1)) + (t % j), p = i + j;
-				if (p < n) {
-					const uint64_t x = a[i], y = a[p];
-					if (x > y) { a[i] = y; a[p] = x; }
-				}
-			}
-			__syncthreads();
+	const bool sw = (a > b) == asc;
+	const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+	a = lo;
+	b = hi;
+}
+
+template <int KPL>
+__device__ __forceinline__ void gs_wave_sort_tile(const uint64_t* __restrict__ keys, uint32_t* __restrict__ out, uint32_t n,
+                                                  int lane)
+{
+	uint64_t k[KPL];
+	// the input order is irrelevant to a sort: fetch striped (coalesced, 512 B per instruction); only the result
+	// is in blocked order
+#pragma unroll
+	for (int e = 0; e < KPL; e++) {
+		const uint32_t i = (uint32_t)e * 64 + lane;
+		k[e] = i < n ? keys[i] : ~0ull;
+	}
+	// sizes 2 .. KPL/2: entirely inside a lane, direction known at compile time (bit `size` of e)
+#pragma unroll
+	for (int size = 2; size < KPL; size <<= 1) {
+#pragma unroll
+		for (int j = size >> 1; j > 0; j >>= 1) {
+#pragma unroll
+			for (int e = 0; e < KPL; e++)
+				if ((e & j) == 0) gs_cex(k[e], k[e | j], (e & size) == 0);
 		}
 	}
-	for (uint32_t i = tid; i < n; i += 256) point_list[range.x + i] = (uint32_t)a[i];
+	// sizes KPL << ls, ls = 0 .. 6: direction = bit ls of the lane (0 for the final merge)
+	for (int ls = 0; ls <= 6; ls++) {
+		const bool asc = ((lane >> ls) & 1) == 0;
+		for (int m = (1 << ls) >> 1; m > 0; m >>= 1) {   // cross-lane strides m*KPL
+			const bool keep_min = ((lane & m) == 0) == asc;
+			const int src = (lane ^ m) << 2;
+#pragma unroll
+			for (int e = 0; e < KPL; e++) {
+				const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)k[e]);
+				const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(k[e] >> 32));
+				const uint64_t o = ((uint64_t)ohi << 32) | olo;
+				k[e] = ((o < k[e]) == keep_min) ? o : k[e];
+			}
+		}
+#pragma unroll
+		for (int j = KPL >> 1; j > 0; j >>= 1) {
+#pragma unroll
+			for (int e = 0; e < KPL; e++)
+				if ((e & j) == 0) gs_cex(k[e], k[e | j], asc);
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < KPL; e++) {
+		const uint32_t i = (uint32_t)lane * KPL + e;
+		if (i < n) out[i] = (uint32_t)k[e];
+	}
+}
+
+__global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ point_list)
+{
+	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per tile, no cross-wave traffic
+	if (tile >= T) return;
+	const int lane = threadIdx.x & 63;
+	const uint2 range = ranges[tile];
+	const uint32_t n = range.y - range.x;
+	if (n == 0 || n > GSR_SORT_LDS_MAX) return;   // empty, or handled by tile_radix_sort
+	const uint64_t* src = keys + range.x;
+	uint32_t* dst = point_list + range.x;
+	if (n <= 64) gs_wave_sort_tile<1>(src, dst, n, lane);
+	else if (n <= 128) gs_wave_sort_tile<2>(src, dst, n, lane);
+	else if (n <= 256) gs_wave_sort_tile<4>(src, dst, n, lane);
+	else if (n <= 512) gs_wave_sort_tile<8>(src, dst, n, lane);
+	else gs_wave_sort_tile<16>(src, dst, n, lane);
 }
 
 // Long lists (> GSR_SORT_LDS_MAX keys, e.g. 5 M Gaussians in a 1297x840 frame: 4.7 k per tile on average): a
@@ -654,10 +698,8 @@ void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint6
                       uint32_t* point_list, hipStream_t s)
 {
 	if (max_tile_count == 0) return;
-	// <= GSR_SORT_LDS_MAX keys: bitonic network in LDS (<= 8 KiB, many workgroups per CU); longer: radix path
-	const uint32_t cap = max_tile_count < GSR_SORT_LDS_MAX ? max(256u, max_tile_count) : GSR_SORT_LDS_MAX;   // LDS keys
-	hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(256), cap * sizeof(uint64_t), s, ranges, keys, point_list,
-	                   GSR_SORT_LDS_MAX);
+	// <= GSR_SORT_LDS_MAX keys: register bitonic network, one wave per tile; longer: radix path
+	hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list);
 	if (max_tile_count > GSR_SORT_LDS_MAX)
 		hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list,
 		                   GSR_SORT_LDS_MAX);
