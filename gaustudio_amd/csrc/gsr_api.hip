@@ -474,7 +474,6 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 		const int n[4] = {3, 0, 0, 0};
 		HIP_TRY(stage_small(src, dst, n, s));
 	}
-	HIP_TRY(hipMemsetAsync(rows, 0, sizeof(float) * GSR_ROW_STRIDE * (size_t)(R > 0 ? R : 1), s));
 
 	BwdArgs a;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;

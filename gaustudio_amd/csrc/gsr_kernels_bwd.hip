@@ -265,6 +265,18 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	__syncthreads();
 	const int bmax = max(s_max[0], s_max[1]);
 
+	// list entries at or beyond bmax contribute to no pixel of this tile: their rows are zero.  (Written here,
+	// under the shadow of the VALU-bound main loop, instead of by a 48 B x R memset in front of the kernel.)
+	for (int i = bmax + tid; i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
+		const uint32_t id = point_list[range.x + i];
+		const uint4 q3 = recs[id].q3;
+		const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
+		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx))) * GSR_ROW_STRIDE);
+		dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+
 	// walk positions pos = bmax-1 ... 0, staged GSR_BWD_BATCH at a time (one instance per thread: a small
 	// batch keeps the workgroup at 12 KiB of LDS so that 13 of them -- 26 waves -- fit a CU)
 	for (int top = bmax; top > 0; top -= GSR_BWD_BATCH) {
@@ -371,21 +383,17 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				}
 			}
 		}
-		// flush: one thread per staged instance stores its 48-B row (plain stores, no global atomics);
-		// rows nobody touched stay at the zero the host memset left
+		// flush: one thread per staged instance stores its 48-B row (plain stores, no global atomics), zeros
+		// included: every row of the scratch is written exactly once per backward, so nobody has to clear it
 		__syncthreads();
 #pragma unroll
 		for (int h = 0; h < GSR_BWD_BATCH / GSR_BWD_THREADS; h++) {
 			const int st = tid + h * GSR_BWD_THREADS;
 			if (st < cnt) {
 				float v[10];
-				bool any = false;
 #pragma unroll
-				for (int k = 0; k < 10; k++) {
-					v[k] = sG[st * GSR_SG_STRIDE + k];
-					any = any || v[k] != 0.f;
-				}
-				if (any) {
+				for (int k = 0; k < 10; k++) v[k] = sG[st * GSR_SG_STRIDE + k];
+				{
 					// moments -> gradients (once per (tile, Gaussian)): with q = G*dL_dalpha summed over pixels,
 					//   dL_dmean2D.x = -0.5W * op * (a*M10 + b*M01)      (backward.cu:593-599)
 					//   dL_dconic    = -0.5 * op * (M20, M11, M02)       (backward.cu:602-604)
