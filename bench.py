@@ -164,7 +164,7 @@ def main():
                                        cam.viewmatrix.to(dev), cam.projmatrix.to(dev), D, cam.campos.to(dev),
                                        False, False)
     rasterizer = GaussianRasterizer(rs)
-    bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()))
+    bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()), roles=params)
     state = {}
 
     def step():
@@ -177,6 +177,8 @@ def main():
         for p in params.values():
             p.grad = None
         means2D.grad = None
+        if world > 1:
+            bucket.arm()                                   # gradients are born in the flat all-reduce buffer
         color, radii, depth, median, opac = rasterizer(
             means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], shs=params["shs"],
             scales=params["scales"], rotations=params["rotations"])

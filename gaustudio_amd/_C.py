@@ -101,6 +101,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                                  geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug))
 
 
+def set_grad_arena(outs):
+    """One-shot destination tensors [dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations] for the next
+    rasterize_gaussians_backward (see gaustudio_amd/parallel.py); [] disarms."""
+    native().set_grad_arena(list(outs))
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible, rasterize_points.cu:212-231 -> torch_binding.cpp markVisible."""
     return native().mark_visible(means3D, viewmatrix, projmatrix)

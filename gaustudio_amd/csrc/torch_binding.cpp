@@ -12,6 +12,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "../../include/gsrast.h"
 
@@ -51,7 +52,31 @@ void require_device(const torch::Tensor& t, const char* name)
 
 void* current_stream(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
+// One-shot output arena for the NEXT backward (gaustudio_amd/parallel.py): five caller-owned tensors
+// [dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations], typically slices of one flat all-reduce buffer,
+// so that the gradients are born where the collective reads them (no pack copy).  Consumed by the first backward
+// whose shapes match; any later backward of the same step allocates as usual and autograd accumulates.
+std::vector<torch::Tensor> g_arena;
+
+torch::Tensor arena_or_empty(std::vector<torch::Tensor>& arena, size_t slot, at::IntArrayRef shape, const torch::TensorOptions& fo)
+{
+	if (arena.size() == 5) {
+		const torch::Tensor& t = arena[slot];
+		if (t.defined() && t.sizes() == shape && t.device() == fo.device() && t.scalar_type() == torch::kFloat32 &&
+		    t.is_contiguous())
+			return t;
+		arena.clear();   // mismatch: do not half-use it
+	}
+	return torch::empty(shape, fo);
+}
+
 }  // namespace
+
+void set_grad_arena(std::vector<torch::Tensor> outs)
+{
+	TORCH_CHECK(outs.empty() || outs.size() == 5, "set_grad_arena expects [means3D, sh, opacity, scales, rotations] gradients or []");
+	g_arena = std::move(outs);
+}
 
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor>
@@ -128,10 +153,12 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 
 	const auto fo = means3D.options().dtype(torch::kFloat32);
 	// torch::empty: the library writes every row (zeros for culled Gaussians); the reference needed torch::zeros
-	torch::Tensor dL_dmeans3D = torch::empty({P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
-	torch::Tensor dL_dcolors = torch::empty({P, 3}, fo), dL_dopacity = torch::empty({P, 1}, fo);
-	torch::Tensor dL_dcov3D = torch::empty({P, 6}, fo), dL_dsh = torch::empty({P, M, 3}, fo);
-	torch::Tensor dL_dscales = torch::empty({P, 3}, fo), dL_drotations = torch::empty({P, 4}, fo);
+	std::vector<torch::Tensor> arena;
+	arena.swap(g_arena);   // one-shot
+	torch::Tensor dL_dmeans3D = arena_or_empty(arena, 0, {P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
+	torch::Tensor dL_dcolors = torch::empty({P, 3}, fo), dL_dcov3D = torch::empty({P, 6}, fo);
+	torch::Tensor dL_dsh = arena_or_empty(arena, 1, {P, M, 3}, fo), dL_dopacity = arena_or_empty(arena, 2, {P, 1}, fo);
+	torch::Tensor dL_dscales = arena_or_empty(arena, 3, {P, 3}, fo), dL_drotations = arena_or_empty(arena, 4, {P, 4}, fo);
 	if (P != 0) {
 		const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
 		torch::Tensor scratch = torch::empty({(long long)gsr_backward_scratch_bytes(P, R)}, bo);
@@ -261,6 +288,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 	m.def("rasterize_gaussians", &RasterizeGaussians);
 	m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
 	m.def("mark_visible", &markVisible);
+	m.def("set_grad_arena", &set_grad_arena);
 	m.def("rasterize_gaussians_raw", &RasterizeGaussiansRaw);
 	m.def("rasterize_gaussians_raw_backward", &RasterizeGaussiansRawBackward);
 }

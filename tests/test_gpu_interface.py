@@ -164,3 +164,38 @@ def test_instance_count_beyond_int32_is_an_error_not_a_wraparound():
                                  cam.viewmatrix.cuda(), cam.projmatrix.cuda(), cam.tanfovx, cam.tanfovy, 2160, 3840, e, 0,
                                  cam.campos.cuda(), False, False)
     assert out[0] > 0
+
+
+def test_grad_arena_gradients_are_born_in_the_flat_bucket():
+    """parallel.FlatGradBucket.arm(): the next backward writes straight into the all-reduce buffer, autograd adopts
+    the slices as p.grad (no pack copy), values identical to the ordinary path; one-shot; refuses when a p.grad exists."""
+    from gaustudio_amd import parallel
+    cam = scenes.make_camera(160, 96)
+    sc = scenes.make_scene(3000, cam, seed=4)
+    rs = _settings(cam)
+    g = [x.cuda() for x in scenes.make_output_grads(cam, seed=2)]
+    (c, _, d, m, o), leaves, _ = _render(sc, cam, rs)
+    torch.autograd.backward([c, d, m, o], g)
+    want = {k: v.grad.clone() for k, v in leaves.items()}
+
+    (c, _, d, m, o), leaves2, _ = _render(sc, cam, rs)
+    bucket = parallel.FlatGradBucket(list(leaves2.values()), roles=leaves2)
+    bucket.flat.fill_(float("nan"))
+    assert bucket.arm()
+    torch.autograd.backward([c, d, m, o], g, retain_graph=True)
+    views = bucket.views()
+    aliased = [p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, views)]
+    assert all(aliased), aliased
+    bucket.pack()                                   # nothing to copy
+    for k, p in leaves2.items():
+        assert torch.equal(p.grad, want[k]), k
+    assert not torch.isnan(bucket.flat).any()
+    # a p.grad exists now: arming again is refused, and a second backward accumulates normally (2x)
+    assert not bucket.arm()
+    torch.autograd.backward([c, d, m, o], g)
+    for k, p in leaves2.items():
+        assert torch.allclose(p.grad, 2 * want[k], rtol=1e-6, atol=0), k
+    # one-shot: after being consumed the arena is gone
+    (c, _, d, m, o), leaves3, _ = _render(sc, cam, rs)
+    torch.autograd.backward([c, d, m, o], g)
+    assert all(p.grad.data_ptr() != v.data_ptr() for p, v in zip(leaves3.values(), views))
