@@ -46,47 +46,11 @@ __global__ __launch_bounds__(256) void depth_to_points_kernel(const float* __res
 
 // depth2normal (:342-380): five-tap cross product of the camera-space points, zero padding (so border pixels
 // are invalid), validity d_min < z < d_max on all five taps, normalise with eps 1e-12, invalid -> (-1,-1,-1).
-// The grid factors (i/(W-1))*(W-1) and (j/(H-1))*(H-1) of the taps are IEEE divisions that depend on the column /
-// row only: a block computes the 64+2k columns and 4+2k rows it needs once into LDS (ten divisions per pixel
-// made the kernel VALU-bound: 66 us at 4K; the remaining three are the normalisation).
-#define GSR_POST_KMAX 32
-__global__ __launch_bounds__(256) void depth_to_normals_kernel(const float* __restrict__ depth, int W, int H, PostCam c,
-                                                               int k, float d_min, float d_max,
-                                                               float* __restrict__ normals)
+__device__ __forceinline__ void normal_from_taps(float zc, float3 pt, float3 pb, float3 pl, float3 pr, float d_min,
+                                                 float d_max, const PostCam& c, float* __restrict__ out)
 {
-	__shared__ float s_col[64 + 2 * GSR_POST_KMAX], s_row[4 + 2 * GSR_POST_KMAX];
-	const int bx0 = blockIdx.x * 64 - k, by0 = blockIdx.y * 4 - k;
-	const float wx = (float)(W - 1), hy = (float)(H - 1);
-	const bool tab = k <= GSR_POST_KMAX;
-	if (tab) {
-		for (int t = threadIdx.x; t < 64 + 2 * k; t += 256) s_col[t] = ((float)(bx0 + t) / wx) * wx;
-		for (int t = threadIdx.x; t < 4 + 2 * k; t += 256) s_row[t] = ((float)(by0 + t) / hy) * hy;
-	}
-	__syncthreads();
-	const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-	if (x >= W || y >= H) return;
-	const size_t i = (size_t)y * W + x;
-	auto tap = [&](int tx, int ty, bool& valid) {
-		float3 p = {0.f, 0.f, 0.f};   // F.pad(..., value=0)
-		if (tx >= 0 && tx < W && ty >= 0 && ty < H) {
-			const float z = depth[(size_t)ty * W + tx];
-			if (tab) {
-				const float xs = s_col[tx - bx0] * z, ys = s_row[ty - by0] * z;   // same products as unproject()
-				p.x = FMA(c.kinv[2], z, FMA(c.kinv[1], ys, c.kinv[0] * xs));
-				p.y = FMA(c.kinv[5], z, FMA(c.kinv[4], ys, c.kinv[3] * xs));
-				p.z = FMA(c.kinv[8], z, FMA(c.kinv[7], ys, c.kinv[6] * xs));
-			} else {
-				p = unproject(tx, ty, z, W, H, c);
-			}
-		}
-		valid = valid && (p.z > d_min) && (p.z < d_max);
-		return p;
-	};
-	bool valid = true;
-	const float3 pc = tap(x, y, valid);
-	(void)pc;
-	const float3 pt = tap(x, y - k, valid), pb = tap(x, y + k, valid);
-	const float3 pl = tap(x - k, y, valid), pr = tap(x + k, y, valid);
+	const bool valid = (zc > d_min) & (zc < d_max) & (pt.z > d_min) & (pt.z < d_max) & (pb.z > d_min) & (pb.z < d_max) &
+	                   (pl.z > d_min) & (pl.z < d_max) & (pr.z > d_min) & (pr.z < d_max);
 	const float3 v = {pt.x - pb.x, pt.y - pb.y, pt.z - pb.z};   // vertical: top - bottom
 	const float3 h = {pl.x - pr.x, pl.y - pr.y, pl.z - pr.z};   // horizontal: left - right
 	float3 n = {-(v.y * h.z - v.z * h.y), -(v.z * h.x - v.x * h.z), -(v.x * h.y - v.y * h.x)};
@@ -99,7 +63,54 @@ __global__ __launch_bounds__(256) void depth_to_normals_kernel(const float* __re
 		n.z = FMA(c.c2w[10], q.z, FMA(c.c2w[9], q.y, c.c2w[8] * q.x));
 	}
 	if (!valid) n.x = n.y = n.z = -1.f;
-	normals[3 * i] = n.x; normals[3 * i + 1] = n.y; normals[3 * i + 2] = n.z;
+	out[0] = n.x; out[1] = n.y; out[2] = n.z;
+}
+
+// Default path (tap distance k <= GSR_POST_KH, the reference's default k=3 gives 1): a 64x8-pixel block unprojects
+// its (64+2k) x (8+2k) halo tile ONCE into LDS -- 1.3 unprojections per pixel instead of five -- and every pixel
+// takes its taps from there.  Same arithmetic per point, same results.
+#define GSR_POST_KH 2
+#define GSR_POST_BW 64
+#define GSR_POST_BH 8
+template <int k>
+__global__ __launch_bounds__(256) void depth_to_normals_tile_kernel(const float* __restrict__ depth, int W, int H, PostCam c,
+                                                                    float d_min, float d_max, float* __restrict__ normals)
+{
+	constexpr int tw = GSR_POST_BW + 2 * k, th = GSR_POST_BH + 2 * k;
+	__shared__ float s_x[th * tw], s_y[th * tw], s_z[th * tw];
+	const int ox = blockIdx.x * GSR_POST_BW - k, oy = blockIdx.y * GSR_POST_BH - k;
+	for (int t = threadIdx.x; t < tw * th; t += 256) {
+		const int lx = t % tw, ly = t / tw, gx = ox + lx, gy = oy + ly;   // tw is a compile-time constant
+		float3 p = {0.f, 0.f, 0.f};   // F.pad(..., value=0)
+		if (gx >= 0 && gx < W && gy >= 0 && gy < H) p = unproject(gx, gy, depth[(size_t)gy * W + gx], W, H, c);
+		s_x[t] = p.x; s_y[t] = p.y; s_z[t] = p.z;
+	}
+	__syncthreads();
+	const int lx = (threadIdx.x & 63) + k, x = ox + lx;
+#pragma unroll
+	for (int r = 0; r < GSR_POST_BH / 4; r++) {
+		const int ly = (threadIdx.x >> 6) + 4 * r + k, y = oy + ly;
+		if (x >= W || y >= H) continue;
+		auto at = [&](int ax, int ay) { const int t = ay * tw + ax; return float3{s_x[t], s_y[t], s_z[t]}; };
+		normal_from_taps(s_z[ly * tw + lx], at(lx, ly - k), at(lx, ly + k), at(lx - k, ly), at(lx + k, ly), d_min, d_max, c,
+		                 normals + 3 * ((size_t)y * W + x));
+	}
+}
+
+// any tap distance: every pixel unprojects its own five taps
+__global__ __launch_bounds__(256) void depth_to_normals_kernel(const float* __restrict__ depth, int W, int H, PostCam c,
+                                                               int k, float d_min, float d_max,
+                                                               float* __restrict__ normals)
+{
+	const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (x >= W || y >= H) return;
+	auto tap = [&](int tx, int ty) {
+		float3 p = {0.f, 0.f, 0.f};   // F.pad(..., value=0)
+		if (tx >= 0 && tx < W && ty >= 0 && ty < H) p = unproject(tx, ty, depth[(size_t)ty * W + tx], W, H, c);
+		return p;
+	};
+	normal_from_taps(tap(x, y).z, tap(x, y - k), tap(x, y + k), tap(x - k, y), tap(x + k, y), d_min, d_max, c,
+	                 normals + 3 * ((size_t)y * W + x));
 }
 
 bool invert3(const float* m, float* out)
@@ -160,8 +171,20 @@ int gsr_depth_to_normals(const float* depth, int width, int height, const float*
 	PostCam c;
 	const int rc = setup(intrinsics, world_to_camera, c);
 	if (rc != GSR_OK) return rc;
-	hipLaunchKernelGGL(depth_to_normals_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-	                   depth, width, height, c, (k - 1) / 2, d_min, d_max, normals);
+	const int kd = (k - 1) / 2;   // tap distance (depth2normal: k = (k - 1) // 2)
+	const dim3 tgrid((width + GSR_POST_BW - 1) / GSR_POST_BW, (height + GSR_POST_BH - 1) / GSR_POST_BH);
+	if (kd == 0)
+		hipLaunchKernelGGL(depth_to_normals_tile_kernel<0>, tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals);
+	else if (kd == 1)
+		hipLaunchKernelGGL(depth_to_normals_tile_kernel<1>, tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals);
+	else if (kd == 2)
+		hipLaunchKernelGGL(depth_to_normals_tile_kernel<2>, tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals);
+	else
+		hipLaunchKernelGGL(depth_to_normals_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+	                   depth, width, height, c, kd, d_min, d_max, normals);
 	return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }
 

@@ -45,6 +45,14 @@ def test_hip_epilogue_matches_reference_camera_fixture():
         ia, ib = _mask_eq(n, z[key])
         assert np.array_equal(ia, ib), key
         assert np.abs(n - z[key]).max() < 1e-4, key
+    # tap distances beyond the LDS halo-tile path (k=7, 11 -> 3, 5) use the per-pixel kernel: against the numpy restatement
+    from oracle import post_oracle as po
+    for k in (7, 11):
+        n = pp.depth_to_normals(d, K, k=k).cpu().numpy()
+        ref = po.depth2normal(z["depth"], z["intrinsics"], k=k)
+        ia, ib = _mask_eq(n, ref)
+        assert np.array_equal(ia, ib), k
+        assert np.abs(n - ref).max() < 1e-4, k
 
 
 @pytest.mark.gpu
