@@ -36,7 +36,7 @@ def lib():
         L.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
         L.gsr_backward_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.gsr_abi_version.restype = ctypes.c_int
-        if L.gsr_abi_version() != 3:
+        if L.gsr_abi_version() != 4:
             raise ImportError("libgsrast.so ABI version mismatch")
         _lib = L
     return _lib

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void inspect_image_kernel(int gx, int W, int H
 
 extern "C" {
 
-int gsr_abi_version(void) { return 3; }
+int gsr_abi_version(void) { return 4; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 

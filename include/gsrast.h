@@ -201,6 +201,41 @@ int gsr_depth_to_points(const float* depth, int width, int height, const float* 
 int gsr_depth_to_normals(const float* depth, int width, int height, const float* intrinsics, int k, float d_min,
                          float d_max, const float* world_to_camera, float* normals, void* stream);
 
+/* ---- TSDF fusion + iso-surface extraction: what gs-extract-mesh does with the rendered
+ * depth points (gaustudio/scripts/extract_mesh.py:86,115,145 -> vdbfusion.VDBVolume.integrate /
+ * .extract_triangle_mesh, a CPU library the reference pip-installs).  Stateless: the volume is caller-owned device
+ * memory --
+ *   block_keys[capacity] u64, all bits set = empty (capacity a power of two; 8x8x8-voxel blocks, open addressing);
+ *   voxels[capacity * 512] u64, zero-initialised: (sum_q << 24) | count with sum_q the sum of tsdf / sdf_trunc in
+ *       2^-20 fixed point (a block's voxels live at its hash slot);
+ *   status[1] u32, zero-initialised: bit 0 set when the hash table overflowed.
+ * Algorithm and parity status: gaustudio_amd/csrc/gsr_tsdf.hip, DESIGN.md s8. ---- */
+
+/* VDBVolume::Integrate(points, origin) with the default weighting (weight 1): points[num_points,3] device,
+ * origin[3] host. */
+int gsr_tsdf_integrate(const float* points, int num_points, const float origin[3], float voxel_size, float sdf_trunc,
+                       int space_carving, uint64_t* block_keys, uint64_t capacity, uint64_t* voxels, uint32_t* status,
+                       void* stream);
+
+/* Test / inspection: for the listed hash slots, per voxel (x fastest) the observation count, the mean tsdf
+ * (+sdf_trunc where the count is 0) and the raw fixed-point sum. */
+int gsr_tsdf_export_blocks(const uint64_t* voxels, const uint32_t* block_slots, int num_blocks, float sdf_trunc,
+                           uint32_t* counts, float* tsdf, int64_t* sums, void* stream);
+
+/* VDBVolume::ExtractTriangleMesh(fill_holes, min_weight) in two steps around a caller-side exclusive scan.
+ * block_slots[num_blocks]: the occupied hash slots in the order the mesh should be emitted; slot_to_block[capacity]:
+ * its inverse.  classify writes cases[num_blocks*512] (u8), edge_flags[num_blocks*512] (u32) and the per-block
+ * vertex / triangle counts; emit takes their exclusive scans and writes vertices[nv,3] (f32, world units),
+ * triangles[nt,3] (i32, outward winding: normals point towards positive tsdf) and vertex_base[num_blocks*512]. */
+int gsr_tsdf_mc_classify(const uint64_t* block_keys, uint64_t capacity, const uint64_t* voxels, const uint32_t* block_slots,
+                         int num_blocks, const uint32_t* slot_to_block, float sdf_trunc, float min_weight, int fill_holes,
+                         uint8_t* cases, uint32_t* edge_flags, uint32_t* block_num_vertices, uint32_t* block_num_triangles,
+                         void* stream);
+int gsr_tsdf_mc_emit(const uint64_t* block_keys, uint64_t capacity, const uint64_t* voxels, const uint32_t* block_slots,
+                     int num_blocks, const uint32_t* slot_to_block, float voxel_size, float sdf_trunc, const uint8_t* cases,
+                     const uint32_t* edge_flags, const uint32_t* block_vertex_offset, const uint32_t* block_triangle_offset,
+                     uint32_t* vertex_base, float* vertices, int* triangles, void* stream);
+
 /* Per-stage GPU time, averaged over every gsr_forward / gsr_backward call made on this thread since
  * gsr_set_profiling(1): milliseconds for {preprocess, scan(+readback), scatter, sort, composite} (forward)
  * or {composite_bwd, preprocess_bwd} (backward), measured with HIP events recorded on the launch stream.
