@@ -1,13 +1,17 @@
 // gsr_kernels_bwd.hip -- backward kernels of libgsrast for gfx950 (MI355X, wave64).
 //
-//   composite_bwd    one workgroup per tile, back-to-front; per (wave, instance) the ten gradient
-//                    components are reduced over the 64 lanes with a 6-step DPP network and issued as
-//                    ONE LDS atomic per component; the four waves of a tile meet in LDS and each
-//                    (tile, Gaussian) instance leaves one plain-stored 48-B row -- no global atomics
+//   composite_bwd    one workgroup of two wave64 per tile, two pixels per lane (packed FP32), back-to-front; per
+//                    (wave, instance) the ten gradient components are reduced over the lanes with lane swaps +
+//                    four DPP steps and added to the instance's LDS row; each (tile, Gaussian) instance leaves one
+//                    plain-stored 48-B row in Gaussian-major order -- no global atomics
 //                    (replaces backward.cu:415-610 renderCUDA: 11-12 atomicAdd per (pixel, Gaussian))
-//   preprocess_bwd   one lane per Gaussian: dL/dconic -> dL/dcov3D, dL/dmean (3 paths), SH backward,
-//                    cov3D -> scale / raw-quaternion backward, fused in one pass
+//   gaussian_scan    exclusive scan of tiles_touched -> row offsets (run by the FORWARD in its read-back bubble)
+//   preprocess_bwd   one lane per Gaussian: fixed-order sum of its rows (fetched wave-cooperatively through LDS),
+//                    dL/dconic -> dL/dcov3D, dL/dmean (projection + depth), cov3D -> scale / raw-quaternion
+//                    backward, activation chain rules of the raw interface
 //                    (replaces backward.cu:144-274 computeCov2DCUDA + :346-412 preprocessCUDA)
+//   preprocess_bwd_sh  SH backward (dL/dSH, dL/dmean through the view direction), rows staged through LDS
+//                    (replaces backward.cu:20-139 computeColorFromSH backward)
 #include "gsr_internal.h"
 
 namespace gsr {
@@ -194,9 +198,9 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 
 // composite_bwd: ONE workgroup of 2 wave64 per 16x16 tile; wave w owns the 8-wide, 16-tall half tile
 // (columns 8w..8w+7) and every lane owns TWO pixels of it, (x, y) and (x, y+8).  The cross-lane reduction
-// of the ten gradient components costs ~85 VALU instructions per (wave, instance) regardless of how many
-// pixels feed it, which was more than the per-pixel math of one pixel per lane; with two pixels per lane it
-// is paid once per 128 pixel evaluations (the culling box grows from 8x8 to 8x16, a smaller loss).
+// of the ten gradient components costs ~38 VALU instructions per (wave, instance) regardless of how many
+// pixels feed it; with two pixels per lane it is paid once per 128 pixel evaluations and the per-pixel math
+// issues as packed FP32 (the culling box grows from 8x8 to 8x16, a smaller loss).
 // Pixel state comes from the forward's tile-major arrays: index = (forward wave)*64 + (forward lane).
 #define GSR_BWD_THREADS 128
 #define GSR_BWD_BATCH 128

@@ -1,16 +1,19 @@
 // gsr_kernels_fwd.hip -- forward kernels of libgsrast for gfx950 (MI355X, wave64).
 //
 //   preprocess_fwd   one lane per Gaussian: cull, project, cov3D, EWA cov2D, conic, radius, tile rect,
-//                    SH->RGB; writes one 64-B record per visible Gaussian and counts instances per tile
-//                    (replaces forward.cu:155-256 preprocessCUDA + the tiles_touched scan input)
+//                    SH->RGB; writes one 64-B record per visible Gaussian and its tile count
+//                    (replaces forward.cu:155-256 preprocessCUDA)
+//   bin_chunk<hist>  per-chunk tile histograms in LDS, bin_colscan turns them into per-chunk offsets + tile totals
 //   tile_scan        exclusive scan of the per-tile counts -> per-tile [start,end) ranges, R
 //                    (replaces cub InclusiveSum over P + identifyTileRanges, rasterizer_impl.cu:280,116-138)
-//   bin_scatter      emits (depth bits<<32 | id) keys straight into each tile's segment
-//                    (replaces duplicateWithKeys, rasterizer_impl.cu:70-111)
-//   tile_sort        one workgroup per tile sorts its segment in LDS by (depth, id)
+//   bin_chunk<scat>  emits (depth bits<<32 | id) keys straight into each tile's segment, slots from LDS cursors
+//                    (replaces duplicateWithKeys, rasterizer_impl.cu:70-111; bin_scatter = global-atomic fallback
+//                    for tile grids too large for an LDS histogram)
+//   tile_sort        one WAVE per tile sorts its segment by (depth, id) in registers; tile_radix_sort for lists
+//                    longer than 1024 keys
 //                    (replaces the global 45..47-bit cub::DeviceRadixSort, rasterizer_impl.cu:306-311)
-//   composite_fwd    one workgroup (4 waves) per 16x16 tile, front-to-back alpha compositing
-//                    (replaces forward.cu:261-397 renderCUDA)
+//   composite_fwd    one workgroup (4 waves, one 8x8 pixel block each) per 16x16 tile, front-to-back alpha
+//                    compositing with per-wave ballot culling (replaces forward.cu:261-397 renderCUDA)
 #include "gsr_internal.h"
 
 namespace gsr {
