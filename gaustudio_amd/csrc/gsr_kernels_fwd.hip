@@ -749,8 +749,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 	float T_ = 1.0f;
 	uint32_t last_contributor = 0;
 	v2f acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};   // (R, G), (B, depth)
-	float median_D = 15.0f, median_weight = 0.f;
-	int median_id = 0;
+	// median candidate: list position (+1) and transmittance in front of the LAST applied instance that saw
+	// T > 0.5; whether it really crossed 0.5 -- and its depth / weight / id -- is settled once per pixel after
+	// the walk (two selects and one compare per pair instead of three and two)
+	uint32_t med_pos = 0;
+	float med_T = 0.f;
 
 	for (int base = 0; base < total; base += 256) {
 		if (__syncthreads_and(done)) break;
@@ -798,10 +801,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 				const float w = apply ? alpha * T_ : 0.f;
 				acc01 = vfma(v2f{Cc.x, Cc.y}, v2f{w, w}, acc01);
 				acc23 = vfma(v2f{Cc.z, Cc.w}, v2f{w, w}, acc23);
-				const bool med = apply & (T_ > 0.5f) & (test_T < 0.5f);              // forward.cu:368-373
-				median_D = med ? Cc.w : median_D;
-				median_weight = med ? w : median_weight;
-				median_id = med ? __float_as_int(B.z) : median_id;
+				const bool medc = apply & (T_ > 0.5f);                               // forward.cu:368 (first half)
+				med_pos = medc ? (uint32_t)(base + j + 1) : med_pos;
+				med_T = medc ? T_ : med_T;
 				T_ = apply ? test_T : T_;
 				last_contributor = apply ? (uint32_t)(base + j + 1) : last_contributor;
 				// (no per-pair "whole wave saturated" test: it cost two VALU and a scalar dependency per pair, 0.035 ms
@@ -812,6 +814,23 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 	final_T[(size_t)tile * GSR_TILE_PIX + tid] = T_;
 	n_contrib[(size_t)tile * GSR_TILE_PIX + tid] = last_contributor;
 	if (inside) {
+		// median depth / weight / id (forward.cu:368-373): the candidate crossed 0.5 iff its test_T < 0.5; alpha is
+		// recomputed with the very operations of the walk, so the result is the bit pattern the walk would have kept
+		float median_D = 15.0f, median_weight = 0.f;
+		int median_id = 0;
+		if (med_pos != 0) {
+			const uint32_t id = point_list[range.x + med_pos - 1];
+			const GsRec* r = recs + id;
+			const float4 A = r->q0, B = r->q1;
+			const float dx = A.x - pixfx, dy = A.y - pixfy;
+			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
+			const float alpha = fminf(0.99f, B.y * gs_exp(power));
+			if (med_T * (1 - alpha) < 0.5f) {
+				median_D = B.z;
+				median_weight = alpha * med_T;
+				median_id = (int)id;
+			}
+		}
 		const size_t HW = (size_t)H * W;
 		const size_t pix_id = (size_t)W * py + px;
 		out_color[pix_id] = acc01.x;
