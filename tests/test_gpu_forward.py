@@ -165,3 +165,20 @@ def test_forward_is_deterministic():
 def test_large_tile_grids_both_binning_paths(oracle, W, H, path):
     hs, os_ = _run(oracle, 30000, W, H, 1, seed=23, sigma_px=4.0)
     assert hs["num_rendered"] > 30000
+
+
+@pytest.mark.parametrize("P", [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1500])
+def test_single_tile_list_lengths_around_the_sort_size_classes(oracle, P):
+    """A 16x16 image is ONE tile; every Gaussian sits inside it, so the tile list has exactly P keys: the boundaries of
+    the register sort's size classes (1, 2, 4, 8, 16 keys per lane) and the hand-over to the radix path at 1024."""
+    cam = scenes.make_camera(16, 16)
+    sc = scenes.make_scene(P, cam, seed=100 + P, sigma_px_median=2.5)
+    means = sc.means3D.clone()
+    means[:, 0] *= 0.5
+    means[:, 1] *= 0.5                                       # well inside the frame
+    sc = sc._replace(means3D=means.contiguous())
+    kw = scene_kwargs(sc, True, False)
+    os_ = oracle_forward(oracle, sc, cam, 1, kw)
+    assert os_["num_rendered"] == P and os_["ranges"].shape[0] == 1
+    hs = hip_forward(sc, cam, 1, kw)
+    compare_forward_exact(hs, os_)
