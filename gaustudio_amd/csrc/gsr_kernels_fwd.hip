@@ -647,6 +647,95 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 	const int tid = threadIdx.x, wv = tid >> 6;
 	uint64_t* src = keys + range.x;
 	uint64_t* dst = keys2 + range.x;
+
+	// ---- fast path (sample-sort style): cut the list into B = 2^k depth buckets of equal key width (~<= 256 keys on
+	// average), scatter the keys bucket by bucket into `keys2`, then every wave sorts whole buckets in registers
+	// (gs_wave_sort_tile).  Two sweeps over the keys and one register sort instead of four counting passes; a bucket
+	// with more than 1024 keys (depths piled up on a few values) sends the tile down the radix path below.
+	{
+		constexpr uint32_t BMAX = 1024;
+		constexpr uint32_t GSR_BUCKET_AVG = 256;   // target keys per bucket (128 measured the same, 64 slower)
+		__shared__ uint32_t s_off[BMAX + 1], s_cur[BMAX];
+		__shared__ uint32_t s_min, s_max, s_over;
+		if (tid == 0) { s_min = 0xffffffffu; s_max = 0u; s_over = 0u; }
+		__syncthreads();
+		uint32_t mn = 0xffffffffu, mx = 0u;
+		for (uint32_t i = tid; i < n; i += 256) {
+			const uint32_t d = (uint32_t)(src[i] >> 32);
+			mn = min(mn, d); mx = max(mx, d);
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+			mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+		}
+		if ((tid & 63) == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+		__syncthreads();
+		const uint32_t dmin = s_min, span = s_max - s_min;
+		if (span > 0) {
+			uint32_t B = 2;
+			while (B < BMAX && B * GSR_BUCKET_AVG < n) B <<= 1;
+			const int span_bits = 32 - __clz((int)span), logB = 31 - __clz((int)B);
+			const int shift = max(0, span_bits - logB);            // (d - dmin) >> shift < B
+			for (uint32_t b = tid; b <= B; b += 256) s_off[b] = 0u;
+			__syncthreads();
+			for (uint32_t i = tid; i < n; i += 256) atomicAdd(&s_off[((uint32_t)(src[i] >> 32) - dmin) >> shift], 1u);
+			__syncthreads();
+			// exclusive scan of the B counts (4 per thread), and the largest count
+			{
+				uint32_t c[4], sum = 0, big = 0;
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const uint32_t b = 4 * tid + k;
+					c[k] = b < B ? s_off[b] : 0u;
+					sum += c[k];
+					big = max(big, c[k]);
+				}
+				uint32_t incl = sum;
+				const int lane = tid & 63;
+#pragma unroll
+				for (int o = 1; o < 64; o <<= 1) {
+					const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+					if (lane >= o) incl += t;
+				}
+				if (lane == 63) s_tot[wv] = incl;
+				if (big > GSR_SORT_LDS_MAX) s_over = 1u;
+				__syncthreads();
+				uint32_t run = incl - sum;
+				for (int w = 0; w < wv; w++) run += s_tot[w];
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const uint32_t b = 4 * tid + k;
+					if (b < B) { s_off[b] = run; s_cur[b] = run; }
+					run += c[k];
+				}
+				if (tid == 255) s_off[B] = n;
+			}
+			__syncthreads();
+			if (!s_over) {
+				for (uint32_t i = tid; i < n; i += 256) {
+					const uint64_t k = src[i];
+					dst[atomicAdd(&s_cur[((uint32_t)(k >> 32) - dmin) >> shift], 1u)] = k;
+				}
+				__threadfence_block();
+				__syncthreads();
+				const int lane = tid & 63;
+				for (uint32_t b = wv; b < B; b += 4) {
+					const uint32_t start = s_off[b], cnt = s_off[b + 1] - start;
+					const uint64_t* bs = dst + start;
+					uint32_t* bo = point_list + range.x + start;
+					if (cnt == 0) continue;
+					if (cnt <= 64) gs_wave_sort_tile<1>(bs, bo, cnt, lane);
+					else if (cnt <= 128) gs_wave_sort_tile<2>(bs, bo, cnt, lane);
+					else if (cnt <= 256) gs_wave_sort_tile<4>(bs, bo, cnt, lane);
+					else if (cnt <= 512) gs_wave_sort_tile<8>(bs, bo, cnt, lane);
+					else gs_wave_sort_tile<16>(bs, bo, cnt, lane);
+				}
+				return;
+			}
+		}
+		__syncthreads();
+	}
 	// wave w owns [wb, we): quarters rounded to multiples of 64 so that groups never straddle waves
 	const uint32_t per = ((n + 3) / 4 + 63) / 64 * 64;
 	const uint32_t wb = min(n, (uint32_t)wv * per), we = min(n, wb + per);
