@@ -13,9 +13,10 @@
 //   * block-sparse volume: 8^3-voxel blocks in an open-addressing hash (64-bit keys, atomicCAS insert); the voxel
 //     storage of a block lives AT its hash slot (vox[slot*512 + local]), so there is no allocator and no
 //     publish race -- HBM is sized for it (4 KiB per slot; the Python owner picks the capacity);
-//   * a voxel is ONE 64-bit word  (sum_q << 24) | count,  sum_q = sum of tsdf/sdf_trunc in 2^-20 fixed point:
+//   * a voxel is ONE 64-bit word  (sum_q << 24) | count,  sum_q = sum of tsdf/sdf_trunc in 2^-15 fixed point:
 //     one integer atomicAdd per update, order-independent => bit-deterministic fusion (a float running average is
-//     order dependent); mean tsdf = sum_q / count * sdf_trunc / 2^20;
+//     order dependent); mean tsdf = sum_q / count * sdf_trunc / 2^15.  Field widths: 24-bit count and 40-bit
+//     signed sum hold 2^24 - 1 observations of a voxel at full magnitude (|tsdf| = sdf_trunc) -- the limit of the format;
 //   * extraction: marching cubes with tables derived in gen_mc_tables.py, shared vertices (each voxel owns the
 //     three edges leaving its minimum corner), count -> scan -> emit, no atomics in the emit passes.
 // All state is caller-owned device memory (torch tensors in gaustudio_amd/tsdf.py); the entry points are stateless.
@@ -29,7 +30,7 @@ namespace {
 
 constexpr uint64_t EMPTY = ~0ull;
 constexpr int BLOCK_VOX = 512;
-constexpr float QSCALE = 1048576.0f;   // 2^20
+constexpr float QSCALE = 32768.0f;   // 2^15: 2^24 observations x 2^15 fit the 40-bit signed sum field
 
 __device__ __constant__ uint8_t d_ntris[256];
 __device__ __constant__ uint16_t d_edge_mask[256];

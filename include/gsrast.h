@@ -207,7 +207,8 @@ int gsr_depth_to_normals(const float* depth, int width, int height, const float*
  * memory --
  *   block_keys[capacity] u64, all bits set = empty (capacity a power of two; 8x8x8-voxel blocks, open addressing);
  *   voxels[capacity * 512] u64, zero-initialised: (sum_q << 24) | count with sum_q the sum of tsdf / sdf_trunc in
- *       2^-20 fixed point (a block's voxels live at its hash slot);
+ *       2^-15 fixed point (a block's voxels live at its hash slot; the fields hold up to 2^24 - 1 observations
+ *       of a voxel);
  *   status[1] u32, zero-initialised: bit 0 set when the hash table overflowed.
  * Algorithm and parity status: gaustudio_amd/csrc/gsr_tsdf.hip, DESIGN.md s8. ---- */
 

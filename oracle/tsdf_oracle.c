@@ -11,7 +11,7 @@
 //                      per voxel: sdf = sign(<voxel-origin, point-voxel>) * |point-voxel|;
 //                      if sdf > -trunc: tsdf = min(trunc, sdf); weight 1;
 //                      new_tsdf = (old_tsdf*old_w + tsdf*w) / (old_w + w)            (running average, in order)
-// Next to the float running average it keeps, per voxel, the observation count and the sum of tsdf/trunc in 2^-20
+// Next to the float running average it keeps, per voxel, the observation count and the sum of tsdf/trunc in 2^-15
 // fixed point: the quantities the HIP kernel accumulates with integer atomics (csrc/gsr_tsdf.hip), which must match
 // this file EXACTLY (same float operations, one rounding each: build with -ffp-contract=off).
 #include <math.h>
@@ -129,7 +129,7 @@ void tso_integrate(void* h, const float* points, int64_t N, const float* origin)
 		DDA_AXIS(dirz, posz, vz, sz, nz, ddz)
 #undef DDA_AXIS
 		const float half = voxel_size * 0.5f;
-		const float qs = 1048576.0f / sdf_trunc;
+		const float qs = 32768.0f / sdf_trunc;
 		for (int guard = 0; guard < (1 << 20); guard++) {
 			const float cx = (float)vx * voxel_size + half, cy = (float)vy * voxel_size + half, cz = (float)vz * voxel_size + half;
 			const float ax = cx - ox, ay = cy - oy, az = cz - oz;

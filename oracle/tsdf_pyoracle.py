@@ -76,13 +76,13 @@ def _tables():
 
 def extract_mesh(coords, weight, sum_q, voxel_size, sdf_trunc, min_weight=0.5, fill_holes=True, blocks=None):
     """Marching cubes over the observed voxels given as the fixed-point sums the GPU keeps (mean tsdf = sum_q / weight *
-    sdf_trunc / 2^20, evaluated in float32 like the kernel).  `blocks`: set of allocated 8^3 block coordinates (a
+    sdf_trunc / 2^15, evaluated in float32 like the kernel).  `blocks`: set of allocated 8^3 block coordinates (a
     corner in a block that was never allocated makes the cube non-extractable, as in the kernel); default: the
     blocks of the observed voxels.  Returns (vertices [nv,3] f32, triangles [nt,3] i32)."""
     g = _tables()
     table, _ = g.build()
     vs, tr = np.float32(voxel_size), np.float32(sdf_trunc)
-    scale = np.float32(tr / np.float32(1048576.0))
+    scale = np.float32(tr / np.float32(32768.0))
     vox = {}
     for c, w, s in zip(map(tuple, coords.tolist()), weight.tolist(), sum_q.tolist()):
         vox[c] = (w, np.float32(np.float32(s) / np.float32(w)) * scale)
