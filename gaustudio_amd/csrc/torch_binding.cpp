@@ -9,6 +9,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <algorithm>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -57,6 +58,7 @@ void* current_stream(const torch::Tensor& t) { return (void*)c10::hip::getCurren
 // so that the gradients are born where the collective reads them (no pack copy).  Consumed by the first backward
 // whose shapes match; any later backward of the same step allocates as usual and autograd accumulates.
 std::vector<torch::Tensor> g_arena;
+std::mutex g_arena_mutex;   // armed on the caller's thread, consumed on an autograd worker thread
 
 torch::Tensor arena_or_empty(std::vector<torch::Tensor>& arena, size_t slot, at::IntArrayRef shape, const torch::TensorOptions& fo)
 {
@@ -75,6 +77,7 @@ torch::Tensor arena_or_empty(std::vector<torch::Tensor>& arena, size_t slot, at:
 void set_grad_arena(std::vector<torch::Tensor> outs)
 {
 	TORCH_CHECK(outs.empty() || outs.size() == 5, "set_grad_arena expects [means3D, sh, opacity, scales, rotations] gradients or []");
+	std::lock_guard<std::mutex> lock(g_arena_mutex);
 	g_arena = std::move(outs);
 }
 
@@ -154,7 +157,10 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 	const auto fo = means3D.options().dtype(torch::kFloat32);
 	// torch::empty: the library writes every row (zeros for culled Gaussians); the reference needed torch::zeros
 	std::vector<torch::Tensor> arena;
-	arena.swap(g_arena);   // one-shot
+	{
+		std::lock_guard<std::mutex> lock(g_arena_mutex);
+		arena.swap(g_arena);   // one-shot
+	}
 	torch::Tensor dL_dmeans3D = arena_or_empty(arena, 0, {P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
 	torch::Tensor dL_dcolors = torch::empty({P, 3}, fo), dL_dcov3D = torch::empty({P, 6}, fo);
 	torch::Tensor dL_dsh = arena_or_empty(arena, 1, {P, M, 3}, fo), dL_dopacity = arena_or_empty(arena, 2, {P, 1}, fo);
