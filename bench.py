@@ -25,8 +25,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the host driver only supports dmabuf IPC: RCCL needs this for N > 1 (already exported on the GPU boxes; kept here so a
+# bare `torch.distributed.run bench.py` from another shell behaves the same)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
