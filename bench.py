@@ -116,8 +116,8 @@ def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--fwd-only", action="store_true", help="time the no_grad forward only (inference paths)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
