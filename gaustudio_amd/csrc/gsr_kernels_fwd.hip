@@ -659,10 +659,32 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 		__shared__ uint32_t s_min, s_max, s_over;
 		if (tid == 0) { s_min = 0xffffffffu; s_max = 0u; s_over = 0u; }
 		__syncthreads();
+		// lists of up to 256 * RK keys are held in registers (RK independent loads per thread in flight at once): the
+		// three sweeps below -- min/max, histogram, scatter -- then cost no further memory round trips
+		constexpr int RK = 32;
+		const bool in_regs = n <= 256u * RK;
+		uint64_t kreg[RK];
+		if (in_regs) {
+#pragma unroll
+			for (int r = 0; r < RK; r++) {
+				const uint32_t i = (uint32_t)tid + 256u * r;
+				kreg[r] = i < n ? src[i] : ~0ull;
+			}
+		}
 		uint32_t mn = 0xffffffffu, mx = 0u;
-		for (uint32_t i = tid; i < n; i += 256) {
-			const uint32_t d = (uint32_t)(src[i] >> 32);
-			mn = min(mn, d); mx = max(mx, d);
+		if (in_regs) {
+#pragma unroll
+			for (int r = 0; r < RK; r++) {
+				if ((uint32_t)tid + 256u * r < n) {
+					const uint32_t d = (uint32_t)(kreg[r] >> 32);
+					mn = min(mn, d); mx = max(mx, d);
+				}
+			}
+		} else {
+			for (uint32_t i = tid; i < n; i += 256) {
+				const uint32_t d = (uint32_t)(src[i] >> 32);
+				mn = min(mn, d); mx = max(mx, d);
+			}
 		}
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
@@ -679,7 +701,13 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 			const int shift = max(0, span_bits - logB);            // (d - dmin) >> shift < B
 			for (uint32_t b = tid; b <= B; b += 256) s_off[b] = 0u;
 			__syncthreads();
-			for (uint32_t i = tid; i < n; i += 256) atomicAdd(&s_off[((uint32_t)(src[i] >> 32) - dmin) >> shift], 1u);
+			if (in_regs) {
+#pragma unroll
+				for (int r = 0; r < RK; r++)
+					if ((uint32_t)tid + 256u * r < n) atomicAdd(&s_off[((uint32_t)(kreg[r] >> 32) - dmin) >> shift], 1u);
+			} else {
+				for (uint32_t i = tid; i < n; i += 256) atomicAdd(&s_off[((uint32_t)(src[i] >> 32) - dmin) >> shift], 1u);
+			}
 			__syncthreads();
 			// exclusive scan of the B counts (4 per thread), and the largest count
 			{
@@ -713,9 +741,19 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 			}
 			__syncthreads();
 			if (!s_over) {
-				for (uint32_t i = tid; i < n; i += 256) {
-					const uint64_t k = src[i];
-					dst[atomicAdd(&s_cur[((uint32_t)(k >> 32) - dmin) >> shift], 1u)] = k;
+				if (in_regs) {
+#pragma unroll
+					for (int r = 0; r < RK; r++) {
+						if ((uint32_t)tid + 256u * r < n) {
+							const uint64_t k = kreg[r];
+							dst[atomicAdd(&s_cur[((uint32_t)(k >> 32) - dmin) >> shift], 1u)] = k;
+						}
+					}
+				} else {
+					for (uint32_t i = tid; i < n; i += 256) {
+						const uint64_t k = src[i];
+						dst[atomicAdd(&s_cur[((uint32_t)(k >> 32) - dmin) >> shift], 1u)] = k;
+					}
 				}
 				__threadfence_block();
 				__syncthreads();
