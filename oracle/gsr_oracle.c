@@ -502,7 +502,7 @@ void orc_composite_bwd(int W, int H, const float* bg, const uint32_t* ranges, co
                        const float* depths, const float* final_Ts, const uint32_t* n_contrib,
                        const float* dL_dpixels, const float* dL_dpixel_depths,
                        const float* dL_dpixel_median_depths, const float* dL_dpixel_final_opacitys,
-                       double* acc, double* accabs, int tile_step)
+                       double* acc, double* accabs, double* flip9, int tile_step)
 {
 	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 	const size_t HW = (size_t)H * W;
@@ -567,6 +567,14 @@ void orc_composite_bwd(int W, int H, const float* bg, const uint32_t* ranges, co
 					dL_dalpha = FMA(c_d - accum_depth_rec, dL_dpixel_depth, dL_dalpha);
 					ACC(id, 9, w * dL_dpixel_depth);
 					if (test_T > 0.5f && T < 0.5f) ACC(id, 9, dL_dpixel_median_depth);
+					/* The median test runs on a T RECONSTRUCTED by division (backward.cu:536,566): when it lands within
+					 * rounding distance of 0.5 its outcome is ill-conditioned -- in the reference as well, whose backward can
+					 * disagree with its own forward there.  flip9[id] collects |dL_dmedian| of such events so that a
+					 * comparison can grant exactly that much slack to component 9 of the Gaussian. */
+					if (flip9 && (fabsf(test_T - 0.5f) < 2e-5f || fabsf(T - 0.5f) < 2e-5f)) {
+						const double v_ = fabs((double)dL_dpixel_median_depth);
+						_Pragma("omp atomic") flip9[id] += v_;
+					}
 					accum_final_opacity_rec = FMA(last_alpha, last_final_opacity, one_m_la * accum_final_opacity_rec);
 					last_final_opacity = 1.f;
 					dL_dalpha = FMA(1.f - accum_final_opacity_rec, dL_dpixel_final_opacity, dL_dalpha);

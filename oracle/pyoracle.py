@@ -137,7 +137,8 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
 def backward(st, grad_color, grad_depth, grad_median, grad_opacity, tile_step=1, want_abs=True):
     """Backward for a state returned by forward().  Returns the reference's 8 gradient tensors
     (rasterize_points.cu:209) plus the composite-stage accumulators in double ("acc") and the
-    sum of |contributions| ("accabs"), component order documented in gsr_oracle.c."""
+    sum of |contributions| ("accabs"), component order documented in gsr_oracle.c, and "flip9": per Gaussian the
+    |dL_dmedian| of ill-conditioned median-threshold events (slack for component 9)."""
     L = lib()
     inp = st["_inputs"]
     P, W, H, M, D = st["P"], st["W"], st["H"], st["M"], st["D"]
@@ -147,13 +148,15 @@ def backward(st, grad_color, grad_depth, grad_median, grad_opacity, tile_step=1,
     g_op = _f32(grad_opacity).reshape(H, W)
     acc = np.zeros((P, 10), np.float64)
     accabs = np.zeros((P, 10), np.float64) if want_abs else None
+    flip9 = np.zeros(P, np.float64) if want_abs else None
     L.orc_composite_bwd(int(W), int(H), _p(inp["bg"]), _p(st["ranges"]), _p(st["_pl_full"]), _p(st["means2D"]),
                         _p(st["conic_opacity"]), _p(st["features"]), _p(st["depths"]), _p(st["final_T"]),
                         _p(st["n_contrib"]), _p(g_color), _p(g_depth), _p(g_median), _p(g_op), _p(acc),
-                        _p(accabs), int(tile_step))
+                        _p(accabs), _p(flip9), int(tile_step))
     out = finish_backward(st, acc.astype(np.float32))
     out["acc"] = acc
     out["accabs"] = accabs
+    out["flip9"] = flip9        # |dL_dmedian| of median-threshold events within rounding distance of 0.5, per Gaussian
     return out
 
 

@@ -34,7 +34,10 @@ def _check(oracle, sc, cam, D, kw, scale_modifier=1.0, bg=None, seed=1):
     acc = to_np(hb["acc"]).astype(np.float64)
     err = np.abs(acc - ob["acc"])
     bound = 4e-5 * ob["accabs"] + 1e-30
-    worst = float((err / np.maximum(ob["accabs"], 1e-300)).max())
+    # the median-depth gradient goes to the Gaussian at which a T reconstructed by division crosses 0.5
+    # (backward.cu:566): events within rounding distance of the threshold may land on a neighbour (or nowhere)
+    bound[:, 9] += ob["flip9"]
+    worst = float((err / np.maximum(bound, 1e-300)).max() * 4e-5)
     assert (err <= bound).all(), f"composite_bwd sums outside the fp32 summation bound: worst err/S = {worst:.3e}"
     vis = os_["radii"] > 0
     assert not np.abs(acc[~vis]).any()
@@ -54,7 +57,8 @@ def _check(oracle, sc, cam, D, kw, scale_modifier=1.0, bg=None, seed=1):
         if b.size == 0:
             continue
         a = to_np(hb[k]).reshape(b.shape)
-        rel[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        keep = ob["flip9"] == 0                      # Gaussians without an ill-conditioned median event
+        rel[k] = float(np.abs(a - b)[keep].max() / max(np.abs(b).max(), 1e-30)) if keep.any() else 0.0
         assert rel[k] < 2e-4, (k, rel[k])
     return rel, worst
 
