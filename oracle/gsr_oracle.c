@@ -514,6 +514,14 @@ void orc_composite_bwd(int W, int H, const float* bg, const uint32_t* ranges, co
 		_Pragma("omp atomic") acc[10 * (size_t)(id) + (k)] += v_; \
 		if (accabs) { _Pragma("omp atomic") accabs[10 * (size_t)(id) + (k)] += fabs(v_); } \
 	} while (0)
+/* a term whose value v comes out of a cancellation: `m` is the magnitude of what was subtracted (>= |v|) and is
+ * what any differently-rounded evaluation is accurate relative to */
+#define ACCM(id, k, v, m)                                    \
+	do {                                                      \
+		double v_ = (double)(v);                              \
+		_Pragma("omp atomic") acc[10 * (size_t)(id) + (k)] += v_; \
+		if (accabs) { _Pragma("omp atomic") accabs[10 * (size_t)(id) + (k)] += fabs((double)(m)); } \
+	} while (0)
 #pragma omp parallel for schedule(dynamic, 1)
 	for (int tile = 0; tile < gx * gy; tile += tile_step) {
 		const int tx = tile % gx, ty = tile / gx;
@@ -552,6 +560,7 @@ void orc_composite_bwd(int W, int H, const float* bg, const uint32_t* ranges, co
 					const float test_T = T / (1.f - alpha);
 					const float w = alpha * test_T; /* dchannel_dcolor = dpixel_depth_ddepth = dpixel_opacity_dopacity */
 					float dL_dalpha = 0.0f;
+					double mag = 0.0; /* sum of the magnitudes dL_dalpha is a (possibly cancelling) combination of */
 					const float one_m_la = 1.f - last_alpha;
 					for (int ch = 0; ch < 3; ch++) {
 						const float c = colors[3 * (size_t)id + ch];
@@ -559,12 +568,14 @@ void orc_composite_bwd(int W, int H, const float* bg, const uint32_t* ranges, co
 						last_color[ch] = c;
 						const float dL_dchannel = dL_dpixel[ch];
 						dL_dalpha = FMA(c - accum_rec[ch], dL_dchannel, dL_dalpha);
+						mag += ((double)fabsf(c) + fabsf(accum_rec[ch])) * fabsf(dL_dchannel);
 						ACC(id, 6 + ch, w * dL_dchannel);
 					}
 					const float c_d = depths[id];
 					accum_depth_rec = FMA(last_alpha, last_depth, one_m_la * accum_depth_rec);
 					last_depth = c_d;
 					dL_dalpha = FMA(c_d - accum_depth_rec, dL_dpixel_depth, dL_dalpha);
+					mag += ((double)fabsf(c_d) + fabsf(accum_depth_rec)) * fabsf(dL_dpixel_depth);
 					ACC(id, 9, w * dL_dpixel_depth);
 					if (test_T > 0.5f && T < 0.5f) ACC(id, 9, dL_dpixel_median_depth);
 					/* The median test runs on a T RECONSTRUCTED by division (backward.cu:536,566): when it lands within
@@ -578,24 +589,31 @@ void orc_composite_bwd(int W, int H, const float* bg, const uint32_t* ranges, co
 					accum_final_opacity_rec = FMA(last_alpha, last_final_opacity, one_m_la * accum_final_opacity_rec);
 					last_final_opacity = 1.f;
 					dL_dalpha = FMA(1.f - accum_final_opacity_rec, dL_dpixel_final_opacity, dL_dalpha);
+					mag += (1.0 + fabsf(accum_final_opacity_rec)) * fabsf(dL_dpixel_final_opacity);
 					ACC(id, 5, w * dL_dpixel_final_opacity); /* Q14 extra opacity term */
 					dL_dalpha *= test_T;
+					mag *= test_T;
 					T = test_T;
 					last_alpha = alpha;
 					dL_dalpha = FMA(-T_final / (1.f - alpha), bg_dot_dpixel, dL_dalpha);
+					mag += fabs((double)(T_final / (1.f - alpha)) * bg_dot_dpixel);
 					const float dL_dG = co[3] * dL_dalpha;
+					const double mG = fabsf(co[3]) * mag; /* magnitude behind dL_dG */
 					const float gdx = G * dx, gdy = G * dy;
 					const float dG_ddelx = FMA(-gdy, co[1], -gdx * co[0]);
 					const float dG_ddely = FMA(-gdx, co[1], -gdy * co[2]);
-					ACC(id, 0, dL_dG * dG_ddelx * ddelx_dx);
-					ACC(id, 1, dL_dG * dG_ddely * ddely_dy);
-					ACC(id, 2, -0.5f * gdx * dx * dL_dG);
-					ACC(id, 3, -0.5f * gdx * dy * dL_dG);
-					ACC(id, 4, -0.5f * gdy * dy * dL_dG);
-					ACC(id, 5, G * dL_dalpha);
+					const double mx_ = (fabs((double)gdy * co[1]) + fabs((double)gdx * co[0])) * ddelx_dx;
+					const double my_ = (fabs((double)gdx * co[1]) + fabs((double)gdy * co[2])) * ddely_dy;
+					ACCM(id, 0, dL_dG * dG_ddelx * ddelx_dx, mG * mx_);
+					ACCM(id, 1, dL_dG * dG_ddely * ddely_dy, mG * my_);
+					ACCM(id, 2, -0.5f * gdx * dx * dL_dG, 0.5 * fabs((double)gdx * dx) * mG);
+					ACCM(id, 3, -0.5f * gdx * dy * dL_dG, 0.5 * fabs((double)gdx * dy) * mG);
+					ACCM(id, 4, -0.5f * gdy * dy * dL_dG, 0.5 * fabs((double)gdy * dy) * mG);
+					ACCM(id, 5, G * dL_dalpha, G * mag);
 				}
 			}
 	}
+#undef ACCM
 #undef ACC
 }
 

@@ -137,7 +137,8 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
 def backward(st, grad_color, grad_depth, grad_median, grad_opacity, tile_step=1, want_abs=True):
     """Backward for a state returned by forward().  Returns the reference's 8 gradient tensors
     (rasterize_points.cu:209) plus the composite-stage accumulators in double ("acc") and the
-    sum of |contributions| ("accabs"), component order documented in gsr_oracle.c, and "flip9": per Gaussian the
+    sum of the contributions' magnitudes ("accabs": for cancelling terms the magnitude of the operands), component
+    order documented in gsr_oracle.c, and "flip9": per Gaussian the
     |dL_dmedian| of ill-conditioned median-threshold events (slack for component 9)."""
     L = lib()
     inp = st["_inputs"]

@@ -3,10 +3,13 @@
 Two checks, both rigorous:
   (1) composite stage.  The reference sums per-Gaussian contributions with float atomicAdd in an
       unspecified order (backward.cu:559-607); our kernel reduces each wave with a fixed DPP network and
-      then uses float atomics across waves/tiles.  The oracle sums the SAME fp32 contributions in double
-      and also returns S = sum |contribution|.  Any-order fp32 summation of n terms differs from the
-      exact sum by at most (n-1)*2^-24*S, so we require |hip - oracle| <= 4e-5*S + 1e-30 (n <~ 600 per
-      Gaussian here); typical observed error is ~1e-7*S.
+      then adds the two waves of a tile and the tiles of a Gaussian in fixed order.  The oracle sums the SAME
+      fp32 contributions in double and also returns S = sum of their magnitudes -- for the terms that come out
+      of a cancellation (dL_dalpha = <colour - accumulated colour, dL_dpixel> ...), the magnitude of what was
+      subtracted, because a differently rounded evaluation (one scalar recurrence instead of five, v_rcp instead
+      of a division) is accurate relative to THAT, not to the cancelled result.  Any-order fp32 evaluation of n
+      such terms differs from the exact sum by at most ~n*2^-24*S, so we require |hip - oracle| <= 4e-5*S + 1e-30
+      (n <~ 600 per Gaussian here); typical observed error is ~1e-7*S.
   (2) per-Gaussian stage (cov2D / projection / SH / cov3D backward).  Fed with the HIP accumulator
       rows, the oracle's restatement of backward.cu:144-412 must reproduce the HIP outputs BIT-EXACTLY.
 """
