@@ -94,3 +94,31 @@ def test_epilogue_rejects_cpu_tensors():
         pp.depth_to_points(torch.zeros(4, 4), torch.eye(3))
     with pytest.raises(ValueError, match="Invalid coordinate"):
         pp.depth_to_points(torch.zeros(4, 4), torch.eye(3), coordinate="ndc")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(2, 3), (63, 7), (64, 8), (65, 9), (130, 17), (257, 33)])
+def test_epilogue_at_block_boundaries_against_numpy_restatement(W, H):
+    """Image sizes around the 64x8 (normals, LDS halo tile) and 64x4 (points) block shapes, tap distances on both
+    kernels' paths, camera and world coordinates -- against oracle/post_oracle.py."""
+    from oracle import post_oracle as po
+    from gaustudio_amd import postprocess as pp
+    rng = np.random.default_rng(W * 1000 + H)
+    depth = (2.0 + rng.random((H, W))).astype(np.float32)
+    depth[rng.random((H, W)) < 0.1] = 0.0
+    K = np.array([[W * 0.9, 0, W / 2], [0, W * 0.9, H / 2], [0, 0, 1]], np.float32)
+    a = 0.4
+    E = np.eye(4, dtype=np.float32)
+    E[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    E[:3, 3] = [0.3, -0.2, 1.0]
+    d = torch.from_numpy(depth).cuda()
+    Kt, Et = torch.from_numpy(K), torch.from_numpy(E)
+    assert np.abs(pp.depth_to_points(d, Kt).cpu().numpy() - po.depth2point(depth, K)).max() < 1e-5
+    assert np.abs(pp.depth_to_points(d, Kt, Et, "world").cpu().numpy() - po.depth2point(depth, K, E)).max() < 1e-5
+    for k in (1, 3, 5, 7):
+        for w2c, kw in ((None, {}), (E, dict(extrinsics=Et, coordinate="world"))):
+            n = pp.depth_to_normals(d, Kt, k=k, **kw).cpu().numpy()
+            ref = po.depth2normal(depth, K, w2c, k=k)
+            ia, ib = _mask_eq(n, ref)
+            assert np.array_equal(ia, ib), (k, w2c is not None)
+            assert np.abs(n - ref)[~ia].max(initial=0.0) < 2e-4, (k, w2c is not None)
