@@ -273,3 +273,29 @@ def test_render_to_mesh_pipeline_stays_on_the_gpu():
     assert len(T) > 20000
     r = np.linalg.norm(V, axis=1)
     assert abs(np.median(r) - 1.0) < 0.03 and (np.abs(r - 1.0) < 0.1).mean() > 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,vs,tr,carve", [(0, 0.013, 0.05, False), (1, 0.1, 0.3, False), (2, 0.05, 0.11, True), (3, 0.02, 0.02, False)])
+def test_integrate_random_clouds_negative_coordinates_and_degenerate_points(seed, vs, tr, carve):
+    """Unstructured points around the origin (all eight octants of voxel / block coordinates), several origins, plus
+    degenerate inputs -- a point equal to the origin, axis-parallel rays, NaN / inf points -- bit-exact integer state."""
+    rng = np.random.default_rng(seed)
+    scans = []
+    for _ in range(3):
+        o = rng.normal(size=3).astype(np.float32) * 0.7
+        pts = (rng.random((3000, 3)) * 2 - 1).astype(np.float32)
+        pts[0] = o                                            # zero-length ray: skipped
+        pts[1] = o + np.array([0.5, 0, 0], np.float32)        # axis-parallel: two DDA axes never step
+        pts[2] = o + np.array([0, 0, -0.37], np.float32)
+        pts[3] = np.array([np.nan, 0, 0], np.float32)
+        pts[4] = np.array([np.inf, 1, 1], np.float32)
+        scans.append((pts, o))
+    ov = to.Volume(vs, tr, carve)
+    for pts, o in scans:
+        ov.integrate(pts, o)
+    oc, ot, ow, os_ = ov.export()
+    vol = _gpu_volume(vs, tr, scans, capacity=1 << 16, space_carving=carve)
+    c, t, w, s = [x.cpu().numpy() for x in vol.export_voxels()]
+    assert (c < 0).any() and (c > 0).any()
+    assert np.array_equal(c, oc) and np.array_equal(w, ow) and np.array_equal(s, os_)
