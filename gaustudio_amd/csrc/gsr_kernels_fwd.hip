@@ -445,13 +445,16 @@ __global__ __launch_bounds__(64 * GSR_COLSCAN_Q) void bin_colscan_kernel(int G, 
 	const int per = (G + GSR_COLSCAN_Q - 1) / GSR_COLSCAN_Q;
 	const int g0 = min(G, q * per), g1 = min(G, g0 + per);
 	uint32_t sum = 0;
-	if (t < T)
+	if (t < T) {
+#pragma unroll 8
 		for (int g = g0; g < g1; g++) sum += Hm[(size_t)g * T + t];
+	}
 	s_q[q][tl] = sum;
 	__syncthreads();
 	uint32_t run = 0;
 	for (int k = 0; k < q; k++) run += s_q[k][tl];
 	if (t < T) {
+#pragma unroll 8
 		for (int g = g0; g < g1; g++) {
 			const uint32_t v = Hm[(size_t)g * T + t];
 			Hm[(size_t)g * T + t] = run;
