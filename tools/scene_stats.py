@@ -24,7 +24,7 @@ print("sum over tiles of max n_contrib / R:", float(tmax.sum()) / hs["num_render
 g = torch.Generator().manual_seed(0)
 tiles = torch.randperm(L.numel(), generator=g)[:200]
 xy = hs["means2D"]; co = hs["conic_opacity"]; pl = hs["point_list"].long()
-tot_inst = tot_blockhit = tot_pairs = tot_live = 0
+tot_inst = tot_blockhit = tot_pairs = tot_live = tot_tilehit = 0
 for t in tiles.tolist():
     a, b = int(r[t, 0]), int(r[t, 1])
     if b <= a: continue
@@ -39,7 +39,9 @@ for t in tiles.tolist():
     live = (power <= 0) & (alpha >= 1 / 255)
     blk = ((ys // 8) * 2 + xs // 8).reshape(-1)
     bh = torch.stack([live[blk == k].any(0) for k in range(4)])
+    tot_tilehit += int(live.any(0).sum())
     tot_inst += ids.numel(); tot_blockhit += int(bh.sum()); tot_pairs += live.numel(); tot_live += int(live.sum())
+print(f"(tile,instance) with any live pixel in the 16x16 tile: {tot_tilehit / tot_inst:.3f}")
 print(f"sampled {len(tiles)} tiles: instances {tot_inst}; (block,instance) with any live pixel: {tot_blockhit / (4 * tot_inst):.3f}; live (pixel,instance) pairs: {tot_live / tot_pairs:.4f}")
 
 # ---- how tight is the kernel's conservative box test (gs_box_may_touch) compared with the exact "any live pixel"? ----
