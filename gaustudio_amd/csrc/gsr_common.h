@@ -68,14 +68,19 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 // gs_exp on two values at once: the same IEEE operations per element as gs_exp (bit-identical results),
 // issued as packed FP32 instructions.  Arguments far below -80 give garbage that callers mask.
-__device__ __forceinline__ v2f gs_exp2(v2f p)
+// A packed instruction takes at most one scalar (SGPR / literal) source, so two of the constants have to sit in VGPRs;
+// a caller with a hot loop passes them in as loop-invariant registers (GS_EXP2_CONSTANTS) instead of having them
+// re-materialised by two v_mov per evaluation.
+#define GS_EXP2_CONSTANTS(magic, c5)                                                   \
+	v2f magic = {12582912.0f, 12582912.0f}, c5 = {0x1.5c08e6p-10f, 0x1.5c08e6p-10f};   \
+	asm volatile("" : "+v"(magic), "+v"(c5))
+__device__ __forceinline__ v2f gs_exp2(v2f p, v2f MAGIC, v2f C5)
 {
 	const v2f LOG2E = {0x1.715476p+0f, 0x1.715476p+0f};
-	const v2f MAGIC = {12582912.0f, 12582912.0f};
 	const v2f tm = vfma(p, LOG2E, MAGIC);
 	const v2f nf = tm - MAGIC;
 	const v2f f = vfma(p, LOG2E, -nf);
-	v2f y = {0x1.5c08e6p-10f, 0x1.5c08e6p-10f};
+	v2f y = C5;
 	y = vfma(y, f, v2f{0x1.3d0c52p-7f, 0x1.3d0c52p-7f});
 	y = vfma(y, f, v2f{0x1.c6b6e4p-5f, 0x1.c6b6e4p-5f});
 	y = vfma(y, f, v2f{0x1.ebf918p-3f, 0x1.ebf918p-3f});
@@ -83,6 +88,10 @@ __device__ __forceinline__ v2f gs_exp2(v2f p)
 	y = vfma(y, f, v2f{0x1.000002p+0f, 0x1.000002p+0f});
 	const v2i r = __builtin_bit_cast(v2i, y) + (__builtin_bit_cast(v2i, tm) << 23);
 	return __builtin_bit_cast(v2f, r);
+}
+__device__ __forceinline__ v2f gs_exp2(v2f p)
+{
+	return gs_exp2(p, v2f{12582912.0f, 12582912.0f}, v2f{0x1.5c08e6p-10f, 0x1.5c08e6p-10f});
 }
 
 struct M3 { float m[3][3]; };   // m[col][row]

@@ -283,6 +283,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 
 	// walk positions pos = bmax-1 ... 0, staged GSR_BWD_BATCH at a time (one instance per thread: a small
 	// batch keeps the workgroup at 12 KiB of LDS so that 13 of them -- 26 waves -- fit a CU)
+	GS_EXP2_CONSTANTS(k_magic, k_c5);
 	for (int top = bmax; top > 0; top -= GSR_BWD_BATCH) {
 		const int cnt = min(GSR_BWD_BATCH, top);
 		uint32_t my_row[GSR_BWD_BATCH / GSR_BWD_THREADS] = {0u};
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				const v2f dy = v2f{A.y, A.y} - pixfy;
 				const float ax = (A.z * dx) * dx, bxd = A.w * dx;
 				const v2f power = vfma(v2f{bxd, bxd}, dy, vfma(B.x * dy, dy, v2f{ax, ax}));
-				const v2f G = gs_exp2(power);
+				const v2f G = gs_exp2(power, k_magic, k_c5);
 				const v2f alpha = v2f{fminf(0.99f, B.y * G.x), fminf(0.99f, B.y * G.y)};
 				// per-pixel predicates stay scalar bools (SGPR lane masks): a select is then ONE v_cndmask
 				// (no short-circuit evaluation: `&` keeps the body free of exec-mask branches)
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				const float r4 = half_swap_sum(g8v.x + g8v.y, g9v.x + g9v.y);  // [g8  | g9 ]
 				float s0 = row_swap_sum(r0, r1), s1 = row_swap_sum(r2, r3), s2 = row_swap_sum(r4, 0.f);
 				row_sum16x3(s0, s1, s2);
+				asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2));   // keep the last DPP step a fused v_add_f32_dpp (it was split into mov_dpp + add and sunk into the branch)
 				if ((lane & 15) == 0) {
 					// LDS float atomics (ds_add_f32), one lane per row = four components per instruction: the two
 					// waves of the tile meet here; global memory sees one row per (tile, instance) in the flush
