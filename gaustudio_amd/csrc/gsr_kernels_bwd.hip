@@ -254,7 +254,10 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		bg_dot[k] = FMA(bg[2], dLp2[k], FMA(bg[1], dLp1[k], FMA(bg[0], dLp0[k], 0.f)));
 	}
 	T_ = T_final;
-	const bool any_bg = bg_dot.x != 0.f || bg_dot.y != 0.f;
+	// wave-uniform: with a black background (the common case) the term is skipped by a scalar branch; a per-lane
+	// condition had the compiler evaluate it always and select (4 VALU per pair).  fma(x, 0, y) == y keeps lanes
+	// without a contribution exact when another lane of the wave has one.
+	const bool any_bg = __ballot(bg_dot.x != 0.f || bg_dot.y != 0.f) != 0ull;
 
 	// The reference carries five back-to-front recurrences accum_rec[ch] (3 colours, depth, opacity;
 	// backward.cu:541-573) but dL_dalpha only needs their dot product with this pixel's upstream
@@ -351,7 +354,10 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				                    vfma(v2f{Cc.z, Cc.z}, dLp2, vfma(v2f{B.z, B.z}, dLd, dLo))));
 				const v2f Sn = vfma(last_alpha, last_cd - S, S);
 				v2f dL_dalpha = (cd - Sn) * test_T;
-				if (any_bg) dL_dalpha = vfma(-(T_final * rinv), bg_dot, dL_dalpha);   // backward.cu:584-587
+				if (any_bg) {                                                         // backward.cu:584-587
+					asm volatile("");   // not speculated: keeps this a scalar branch instead of compute-always + select
+					dL_dalpha = vfma(-(T_final * rinv), bg_dot, dL_dalpha);
+				}
 				const v2f gq = G * dL_dalpha;
 				const v2f qa = SEL2(live0, live1, gq, zero2);                         // dL_dG * G / opacity
 				// median-depth gradient (backward.cu:566-569)
