@@ -485,7 +485,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	tm.mark();
 	if (R > 0) {
 		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, goff, final_T, n_contrib, dL_dpix,
-		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, s);
+		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, (size_t)R, s);
 		STAGE_CHECK("composite_bwd", debug, s);
 	}
 	tm.mark();

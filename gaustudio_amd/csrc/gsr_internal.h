@@ -123,6 +123,7 @@ struct BwdArgs {
 // contiguous read and a fixed summation order.
 //   row: 0,1 dL_dmean2D.xy | 2,3,4 dL_dconic a,b,c | 5 dL_dopacity | 6,7,8 dL_dcolor | 9 dL_ddepth | 10,11 unused
 #define GSR_ROW_STRIDE 12
+#define GSR_BWD_MEMSET_AVG 1024   // average tile list length above which the rows are cleared by a memset
 #define GSR_SUM_SLAB 160   // rows per LDS slab of preprocess_bwd's cooperative row fetch (7.5 KiB per wave)
 // scratch: [bg f32 x 4][rows f32 x R*12]
 struct BwdLayout {
@@ -139,7 +140,7 @@ void launch_gaussian_scan(int P, const uint32_t* tiles_touched, uint32_t* goff, 
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, hipStream_t s);
+                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, size_t R, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
                            const float* rows, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,

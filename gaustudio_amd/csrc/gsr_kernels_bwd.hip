@@ -209,7 +209,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
-    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows)
+    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, int zero_tail)
 {
 	__shared__ float4 sA[GSR_BWD_BATCH];
 	__shared__ float4 sB[GSR_BWD_BATCH];
@@ -272,9 +272,11 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	__syncthreads();
 	const int bmax = max(s_max[0], s_max[1]);
 
-	// list entries at or beyond bmax contribute to no pixel of this tile: their rows are zero.  (Written here,
-	// under the shadow of the VALU-bound main loop, instead of by a 48 B x R memset in front of the kernel.)
-	for (int i = bmax + tid; i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
+	// list entries at or beyond bmax contribute to no pixel of this tile: their rows are zero.  Short lists (most of
+	// a list is walked): written here, under the shadow of the VALU-bound main loop, instead of by a 48 B x R memset
+	// in front of the kernel.  Long lists (real scenes: a few thousand entries of which ~15 % are reached): the
+	// launcher clears the rows with one memset instead -- a per-entry gather of record + offset costs more than 48 B.
+	for (int i = bmax + tid; zero_tail && i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
 		const uint32_t id = point_list[range.x + i];
 		const uint4 q3 = recs[id].q3;
 		const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
@@ -428,12 +430,15 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, hipStream_t s)
+                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, size_t R, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
+	// average list length decides who clears the rows of entries no pixel reaches (see the kernel)
+	const bool long_lists = R > (size_t)il.T * GSR_BWD_MEMSET_AVG;
+	if (long_lists) (void)hipMemsetAsync(rows, 0, sizeof(float) * GSR_ROW_STRIDE * R, s);
 	hipLaunchKernelGGL(composite_bwd_kernel, dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg, ranges,
 	                   point_list, recs, goff, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
-	                   dL_dpix_opacity, rows);
+	                   dL_dpix_opacity, rows, long_lists ? 0 : 1);
 }
 
 // ------------------------------------------------------------------------------------------------
