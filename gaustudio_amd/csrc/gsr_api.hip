@@ -464,6 +464,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	const uint32_t* goff = reinterpret_cast<const uint32_t*>(geom_buffer + gl.goff);   // scanned by the forward
 	float* bg_dev = reinterpret_cast<float*>(scratch + wl.bg);
 	float* rows = reinterpret_cast<float*>(scratch + wl.rows);
+	uint8_t* row_flags = reinterpret_cast<uint8_t*>(scratch + wl.flags);
 
 	// The background is re-staged here because the reference reads the backward's own `background`
 	// argument (backward.cu:584-587), which the forward never dereferences.
@@ -474,6 +475,15 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 		const int n[4] = {3, 0, 0, 0};
 		HIP_TRY(stage_small(src, dst, n, s));
 	}
+	// long lists (average > GSR_FLAG_AVG entries per tile): one validity byte per instance row, set by composite_bwd for the
+	// rows it writes; short lists: no flags, composite_bwd zeroes the rows of the entries its walk does not reach
+	const bool flagged = (size_t)(R > 0 ? R : 0) > (size_t)il.T * GSR_FLAG_AVG;
+	if (flagged)
+		HIP_TRY(hipMemsetAsync(row_flags, 0, (size_t)R, s));
+	else
+		row_flags = nullptr;
+	// the regime is recorded next to the staged background for gsr_inspect_backward_sums (word 8 of the bg block)
+	HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bg_dev + 8), flagged ? 1 : 0, 1, s));
 
 	BwdArgs a;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
@@ -485,11 +495,11 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	tm.mark();
 	if (R > 0) {
 		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, goff, final_T, n_contrib, dL_dpix,
-		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, (size_t)R, s);
+		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags, s);
 		STAGE_CHECK("composite_bwd", debug, s);
 	}
 	tm.mark();
-	launch_preprocess_bwd(a, cam, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+	launch_preprocess_bwd(a, cam, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
 	                      dL_dsh_rest, dL_dscale, dL_drot, s);
 	STAGE_CHECK("preprocess_bwd", debug, s);
 	tm.mark();
@@ -558,9 +568,13 @@ int gsr_inspect_backward_sums(const char* geom_buffer, const char* scratch, int 
 		return fail(GSR_ERR_ARG, "gsr_inspect_backward_sums: NULL argument", __FILE__, __LINE__);
 	const GeomLayout gl((size_t)P);
 	const BwdLayout wl((size_t)P, (size_t)(R > 0 ? R : 0));
+	uint32_t flagged = 0;   // regime the backward ran in (see backward_impl)
+	HIP_TRY(hipMemcpyAsync(&flagged, scratch + wl.bg + 8 * sizeof(float), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
 	launch_inspect_sums(P, radii, reinterpret_cast<const GsRec*>(geom_buffer + gl.recs),
 	                    reinterpret_cast<const uint32_t*>(geom_buffer + gl.goff),
-	                    reinterpret_cast<const float*>(scratch + wl.rows), sums, s);
+	                    reinterpret_cast<const float*>(scratch + wl.rows), flagged ? reinterpret_cast<const uint8_t*>(scratch + wl.flags) : nullptr,
+	                    sums, s);
 	STAGE_CHECK("inspect_backward_sums", 0, s);
 	return GSR_OK;
 }

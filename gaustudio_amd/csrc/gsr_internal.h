@@ -123,16 +123,17 @@ struct BwdArgs {
 // contiguous read and a fixed summation order.
 //   row: 0,1 dL_dmean2D.xy | 2,3,4 dL_dconic a,b,c | 5 dL_dopacity | 6,7,8 dL_dcolor | 9 dL_ddepth | 10,11 unused
 #define GSR_ROW_STRIDE 12
-#define GSR_BWD_MEMSET_AVG 1024   // average tile list length above which the rows are cleared by a memset
+#define GSR_FLAG_AVG 1024   // average tile list length above which the backward uses per-row validity flags
 #define GSR_SUM_SLAB 160   // rows per LDS slab of preprocess_bwd's cooperative row fetch (7.5 KiB per wave)
 // scratch: [bg f32 x 4][rows f32 x R*12]
 struct BwdLayout {
-	size_t bg, rows, total;
+	size_t bg, flags, rows, total;
 	BwdLayout(size_t P, size_t R)
 	{
 		(void)P;
 		bg = 0;
-		rows = bg + 256;
+		flags = bg + 256;                                           // u8 x R: 1 = the row was written by composite_bwd
+		rows = flags + align_up(R > 0 ? R : 1);
 		total = rows + align_up(sizeof(float) * GSR_ROW_STRIDE * (R > 0 ? R : 1));
 	}
 };
@@ -140,12 +141,14 @@ void launch_gaussian_scan(int P, const uint32_t* tiles_touched, uint32_t* goff, 
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, size_t R, hipStream_t s);
+                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
+                          hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
-                           const float* rows, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                           const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
                            float* dL_drot, hipStream_t s);
 void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint32_t* goff, const float* rows,
+                         const uint8_t* row_flags,
                          float* sums10, hipStream_t s);
 
 }  // namespace gsr

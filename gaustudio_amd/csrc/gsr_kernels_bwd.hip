@@ -71,13 +71,14 @@ __device__ __forceinline__ float row_swap_sum(float p, float q)
 // not depend on scheduling).  Used by preprocess_bwd and by the test-only inspection kernel.
 __device__ __forceinline__ void gs_sum_rows(bool vis, int idx, const GsRec* __restrict__ recs,
                                             const uint32_t* __restrict__ goff, const float* __restrict__ rows,
-                                            float* a_)
+                                            const uint8_t* __restrict__ row_flags, float* a_)
 {
 #pragma unroll
 	for (int i = 0; i < GSR_ROW_STRIDE; i++) a_[i] = 0.f;
 	if (!vis) return;
 	const uint32_t b = goff[idx], e = goff[idx + 1];
 	for (uint32_t r = b; r < e; r++) {
+		if (row_flags != nullptr && !row_flags[r]) continue;   // flags mode: not written (never reached by the walk)
 		const float4* ar = reinterpret_cast<const float4*>(rows + (size_t)r * GSR_ROW_STRIDE);
 		const float4 v0 = ar[0], v1 = ar[1], v2 = ar[2];
 		a_[0] += v0.x; a_[1] += v0.y; a_[2] += v0.z; a_[3] += v0.w; a_[4] += v1.x; a_[5] += v1.y;
@@ -178,20 +179,22 @@ void launch_gaussian_scan(int P, const uint32_t* tiles_touched, uint32_t* goff, 
 __global__ __launch_bounds__(256) void inspect_sums_kernel(int P, const int* __restrict__ radii,
                                                            const GsRec* __restrict__ recs,
                                                            const uint32_t* __restrict__ goff,
-                                                           const float* __restrict__ rows, float* __restrict__ out)
+                                                           const float* __restrict__ rows,
+                                                           const uint8_t* __restrict__ row_flags, float* __restrict__ out)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
 	float a_[GSR_ROW_STRIDE];
-	gs_sum_rows(radii[idx] > 0, idx, recs, goff, rows, a_);
+	gs_sum_rows(radii[idx] > 0, idx, recs, goff, rows, row_flags, a_);
 #pragma unroll
 	for (int i = 0; i < 10; i++) out[10 * (size_t)idx + i] = a_[i];
 }
 
 void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint32_t* goff, const float* rows,
-                         float* sums10, hipStream_t s)
+                         const uint8_t* row_flags, float* sums10, hipStream_t s)
 {
-	hipLaunchKernelGGL(inspect_sums_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, recs, goff, rows, sums10);
+	hipLaunchKernelGGL(inspect_sums_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, recs, goff, rows, row_flags,
+	                   sums10);
 }
 
 #define GSR_SG_STRIDE 11
@@ -204,12 +207,14 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 // Pixel state comes from the forward's tile-major arrays: index = (forward wave)*64 + (forward lane).
 #define GSR_BWD_THREADS 128
 #define GSR_BWD_BATCH 128
+// FLAGS: long-list regime (per-row validity bytes); compile-time so that the short-list kernel carries none of it
+template <bool FLAGS>
 __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
     int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
-    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, int zero_tail)
+    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags)
 {
 	__shared__ float4 sA[GSR_BWD_BATCH];
 	__shared__ float4 sB[GSR_BWD_BATCH];
@@ -272,11 +277,14 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	__syncthreads();
 	const int bmax = max(s_max[0], s_max[1]);
 
-	// list entries at or beyond bmax contribute to no pixel of this tile: their rows are zero.  Short lists (most of
-	// a list is walked): written here, under the shadow of the VALU-bound main loop, instead of by a 48 B x R memset
-	// in front of the kernel.  Long lists (real scenes: a few thousand entries of which ~15 % are reached): the
-	// launcher clears the rows with one memset instead -- a per-entry gather of record + offset costs more than 48 B.
-	for (int i = bmax + tid; zero_tail && i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
+	// List entries at or beyond bmax contribute to no pixel of this tile.  Two regimes, chosen by the launcher from
+	// the average list length:
+	//   short lists (most of a list is walked): their rows are zeroed here, under the shadow of the VALU-bound main
+	//     loop, and preprocess_bwd adds every row unconditionally;
+	//   long lists (real scenes: a few thousand entries of which ~15 % are reached): row_flags != nullptr -- written
+	//     rows set a validity byte, unreached entries are left alone and preprocess_bwd skips them WITHOUT reading
+	//     them (clearing + re-reading 48 B per unreached entry was the larger cost: C4 share 1.42 -> 0.59 ms here).
+	for (int i = bmax + tid; !FLAGS && i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
 		const uint32_t id = point_list[range.x + i];
 		const uint4 q3 = recs[id].q3;
 		const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
@@ -285,7 +293,6 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
-
 	// walk positions pos = bmax-1 ... 0, staged GSR_BWD_BATCH at a time (one instance per thread: a small
 	// batch keeps the workgroup at 12 KiB of LDS so that 13 of them -- 26 waves -- fit a CU)
 	GS_EXP2_CONSTANTS(k_magic, k_c5);
@@ -421,6 +428,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 					                     -0.5f * op * M20, -0.5f * op * M11);
 					dst[1] = make_float4(-0.5f * op * M02, v[5], v[6], v[7]);
 					dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
+					if (FLAGS) row_flags[my_row[h]] = 1;
 				}
 			}
 		}
@@ -430,25 +438,28 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, size_t R, hipStream_t s)
+                          const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
+                          hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
-	// average list length decides who clears the rows of entries no pixel reaches (see the kernel)
-	const bool long_lists = R > (size_t)il.T * GSR_BWD_MEMSET_AVG;
-	if (long_lists) (void)hipMemsetAsync(rows, 0, sizeof(float) * GSR_ROW_STRIDE * R, s);
-	hipLaunchKernelGGL(composite_bwd_kernel, dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg, ranges,
-	                   point_list, recs, goff, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
-	                   dL_dpix_opacity, rows, long_lists ? 0 : 1);
+	if (row_flags != nullptr)
+		hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg,
+		                   ranges, point_list, recs, goff, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
+		                   dL_dpix_opacity, rows, row_flags);
+	else
+		hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg,
+		                   ranges, point_list, recs, goff, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
+		                   dL_dpix_opacity, rows, row_flags);
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool FLAGS>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
     const float* __restrict__ cov3D_precomp, const GsCam* __restrict__ cam, int W, int H, float tan_fovx,
     float tan_fovy, float h_x, float h_y, int sh_vec4, int act, const GsRec* __restrict__ recs,
-    const uint32_t* __restrict__ goff, const float* __restrict__ rows,
+    const uint32_t* __restrict__ goff, const float* __restrict__ rows, const uint8_t* __restrict__ row_flags,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
@@ -462,6 +473,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 		// its own rows out of the slab in ascending order.  (Per-lane gathers touched 64 cache lines per
 		// instruction: 130 us at C3.)
 		__shared__ float4 s_rows[4][GSR_SUM_SLAB * 3];
+		__shared__ uint8_t s_flag[4][(GSR_SUM_SLAB + 63) / 64 * 64];   // validity bytes of the slab's rows
 		const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 		const int g0 = blockIdx.x * 256 + wv * 64;
 		if (g0 >= P) return;   // wave-uniform
@@ -473,14 +485,25 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 		for (uint32_t base = wb; base < we; base += GSR_SUM_SLAB) {
 			const uint32_t cnt = min((uint32_t)GSR_SUM_SLAB, we - base);
 			const float4* src = reinterpret_cast<const float4*>(rows + (size_t)base * GSR_ROW_STRIDE);
+			uint8_t* fl = s_flag[wv];
+			constexpr bool flagged = FLAGS;   // long-list regime (see composite_bwd)
+			if (flagged) {
+#pragma unroll
+				for (int it = 0; it < (GSR_SUM_SLAB + 63) / 64; it++) {
+					const uint32_t r = it * 64 + lane;
+					fl[r] = r < cnt ? row_flags[base + r] : (uint8_t)0;
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
 #pragma unroll
 			for (int it = 0; it < (GSR_SUM_SLAB * 3 + 63) / 64; it++) {
 				const uint32_t j = it * 64 + lane;
-				if (j < cnt * 3) slab[j] = src[j];
+				if (j < cnt * 3 && (!flagged || fl[j / 3])) slab[j] = src[j];   // unwritten rows are not fetched
 			}
 			__builtin_amdgcn_wave_barrier();
 			const uint32_t lo = max(b, base), hi = min(e, base + cnt);
 			for (uint32_t r = lo; r < hi; r++) {
+				if (flagged && !fl[r - base]) continue;
 				const float4* ar = slab + (r - base) * 3;
 				const float4 v0 = ar[0], v1 = ar[1], v2 = ar[2];
 				a_[0] += v0.x; a_[1] += v0.y; a_[2] += v0.z; a_[3] += v0.w; a_[4] += v1.x; a_[5] += v1.y;
@@ -873,7 +896,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 }
 
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
-                           const float* rows, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
+                           const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
                            float* dL_drot, hipStream_t s)
 {
@@ -883,12 +906,12 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	const int sh_vec4 = (a.shs != nullptr && a.shs_rest == nullptr && dL_dsh != nullptr && ((uintptr_t)a.shs % 16 == 0) &&
 	                     ((uintptr_t)dL_dsh % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0;
 	dim3 grid((a.P + 255) / 256), block(256);
-#define GSR_LAUNCH_PB(DEG)                                                                                         \
-	hipLaunchKernelGGL(preprocess_bwd_kernel<DEG>, grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, a.scales, \
+#define GSR_LAUNCH_PB(DEG, FL)                                                                                     \
+	hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, FL>), grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, a.scales, \
 	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
-	                   h_y, sh_vec4, a.act, recs, goff, rows, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
+	                   h_y, sh_vec4, a.act, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
 	                   dL_drot)
-	GSR_LAUNCH_PB(0);
+	if (row_flags != nullptr) { GSR_LAUNCH_PB(0, true); } else { GSR_LAUNCH_PB(0, false); }
 #undef GSR_LAUNCH_PB
 	if (a.shs != nullptr) {
 #define GSR_LAUNCH_SH(DEG)                                                                                       \

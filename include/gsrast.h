@@ -90,8 +90,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx,
                 void* stream);
 
 /* Bytes of device scratch gsr_backward needs for P Gaussians and R = num_rendered instances
- * (48 B per instance: the per-instance partial-gradient rows that replace the reference's float
- * atomics, backward.cu:559-607; the per-Gaussian row offsets live in the geometry buffer). */
+ * (49 B per instance: the per-instance partial-gradient rows that replace the reference's float
+ * atomics, backward.cu:559-607, plus one validity byte each; the per-Gaussian row offsets live in the
+ * geometry buffer). */
 size_t gsr_backward_scratch_bytes(int P, int R);
 
 /* Replaces Rasterizer::backward (rasterizer.h:61-91; rasterizer_impl.cu:347-452).
