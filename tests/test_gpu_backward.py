@@ -148,3 +148,17 @@ def test_backward_is_run_to_run_deterministic():
     c = hip_backward_raw(hs2, sc, cam, 3, kw, grads)
     for k in GRAD_KEYS:
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+
+
+@pytest.mark.parametrize("P,sigma", [(8000, 6.0), (30000, 3.0)])
+def test_backward_long_lists_row_flag_regime(oracle, P, sigma):
+    """Average tile list > 1024 entries: the backward runs with per-row validity bytes (rows of entries the walk never
+    reaches are neither cleared nor read) and the bucketed long-list sort; same two checks as everywhere else."""
+    cam = scenes.make_camera(64, 48)
+    sc = scenes.make_scene(P, cam, seed=21, sigma_px_median=sigma)
+    kw = scene_kwargs(sc, True, False)
+    os_ = oracle_forward(oracle, sc, cam, 2, kw)
+    r = os_["ranges"]
+    assert os_["num_rendered"] > 1024 * r.shape[0] and int((r[:, 1] - r[:, 0]).max()) > 1024
+    assert int(os_["n_contrib"].max()) < int((r[:, 1] - r[:, 0]).max())          # some entries are never reached
+    _check(oracle, sc, cam, 2, kw, seed=3)
