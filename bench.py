@@ -41,6 +41,8 @@ WORKLOADS = {
     "C2": (300_000, 800, 800, 3, "C2: 300k synthetic Gaussians (lego stand-in), 800x800, SH degree 3, fwd+bwd"),
     "C3": (1_000_000, 1920, 1080, 3,
            "C3: 1M synthetic Gaussians, 1920x1080, SH degree 3, fwd+bwd (colour+depth+median+opacity consumed)"),
+    "C3D0": (1_000_000, 1920, 1080, 0,
+             "C3 at SH degree 0: 1M synthetic Gaussians, 1920x1080, fwd+bwd (SURVEY s8d names D = 0 and D = 3)"),
     # per-GPU shares of the multi-GPU configurations (one view per GPU)
     "C4": (5_000_000, 1297, 840, 3, "C4 share: 5M synthetic Gaussians (garden stand-in), one 1297x840 view, SH degree 3, fwd+bwd"),
     "C5": (2_500_000, 3840, 2160, 3, "C5 share: 2.5M synthetic Gaussians (Truck stand-in), one 3840x2160 view, SH degree 3, fwd+bwd"),
@@ -89,7 +91,7 @@ def cpu_baseline(sc, cam, D, grads, budget_s=20.0):
 
 def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
     """Achieved algorithmic GB/s of every stage against the 8 TB/s HBM roofline (BASELINE.md s4 byte counts; the
-    records are 64 B here instead of the reference's 48 B of SoA fields, counted as written)."""
+    records are 64 B here instead of the reference's 48 B of SoA fields, counted as written).  R = instances binned."""
     sh = 12 * (D + 1) ** 2
     HW = H * W
     stages = {}
@@ -113,6 +115,85 @@ def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
     return stages
 
 
+def committed_counters(workload):
+    """Per-kernel PMC measurements committed under profiles/ (newest round first): HBM traffic and VALU instruction
+    counts per launch.  PMC counters cannot be read in-process; they are recaptured with rocprofv3 whenever a kernel
+    changes (tools/profile_session.sh) and the file records the commit-time kernel durations they belong to."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        t = json.load(open(f))
+        if t.get("workload") == workload:
+            t["_file"] = os.path.relpath(f, ROOT)
+            return t
+    return None
+
+
+def valu_issue(counters, kernel, ms):
+    """VALU issue fraction of a kernel: (wave64 VALU instructions per launch from the committed SQ_INSTS_VALU pass) x
+    (mean cycles per instruction of that kernel's instruction mix, from the issue-rate probe: profiles/r01_issue_rates.txt,
+    DESIGN.md s4) / (SIMD-cycles available in the measured duration: 1024 SIMDs x ~2.3 GHz sustained)."""
+    if not counters or kernel not in counters or not ms or "valu_insts" not in counters[kernel]:
+        return None
+    k = counters[kernel]
+    cpi = k.get("valu_cycles_per_inst_model", 3.0)
+    avail = ms * 1e-3 * 2.3e9 * 1024
+    return {"valu_insts": k["valu_insts"], "cycles_per_inst_model": cpi, "issue_frac": round(k["valu_insts"] * cpi / avail, 3),
+            "source": counters.get("_file")}
+
+
+def list_histogram(ranges):
+    n = (ranges[:, 1] - ranges[:, 0]).float()
+    q = torch.quantile(n, torch.tensor([0.5, 0.9, 0.99], device=n.device)).tolist()
+    return {"mean": round(float(n.mean()), 1), "p50": int(q[0]), "p90": int(q[1]), "p99": int(q[2]), "max": int(n.max()),
+            "empty_tiles": int((n == 0).sum())}
+
+
+def reference_ab(sc, cam, D, grads_cpu, dev, steps=5):
+    """Optional GPU A/B: the reference's OWN kernels (hipified test-only into oracle/_ref/libgsref.so by
+    oracle/build_ref.sh; checker infrastructure, never part of the product) timed on the same inputs, including the
+    zero-fills the reference's torch glue performs (rasterize_points.cu:68-81,160-169)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import ref_util
+        if not ref_util.available():
+            return None
+        import ctypes
+        L = ref_util.lib()
+        h = ctypes.c_void_p(L.ref_create())
+        p, cf = ref_util._p, ctypes.c_float
+        P, W, H = sc.means3D.shape[0], cam.width, cam.height
+        t = {k: getattr(sc, k).to(dev).contiguous() for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        view, proj, cpos = cam.viewmatrix.to(dev).contiguous(), cam.projmatrix.to(dev).contiguous(), cam.campos.to(dev)
+        bgd = torch.zeros(3, device=dev)
+        grads = [g.to(dev) for g in grads_cpu]
+        fo = dict(dtype=torch.float32, device=dev)
+
+        def step():
+            out = [torch.empty((3, H, W), **fo), torch.empty((1, H, W), **fo), torch.empty((3, H, W), **fo), torch.empty((1, H, W), **fo)]
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            R = L.ref_forward(h, P, D, 16, p(bgd), W, H, p(t["means3D"]), p(t["shs"]), p(None), p(t["opacities"]), p(t["scales"]),
+                              cf(1.0), p(t["rotations"]), p(None), p(view), p(proj), p(cpos), cf(cam.tanfovx), cf(cam.tanfovy), 0,
+                              *[p(o) for o in out], p(radii))
+            z = lambda *s: torch.zeros(*s, **fo)
+            G = [z(P, 3), z(P, 4), z(P, 1), z(P, 3), z(P), z(P, 3), z(P, 6), z(P, 16, 3), z(P, 3), z(P, 4)]
+            rc = L.ref_backward(h, P, D, 16, p(bgd), W, H, p(t["means3D"]), p(t["shs"]), p(None), p(t["scales"]), cf(1.0),
+                                p(t["rotations"]), p(None), p(view), p(proj), p(cpos), cf(cam.tanfovx), cf(cam.tanfovy), p(radii),
+                                *[p(g) for g in grads], *[p(g) for g in G])
+            assert R > 0 and rc == 0
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        L.ref_destroy(h)
+        return round(ms, 3)
+    except Exception as e:  # the A/B is optional: never let it break the benchmark line
+        return f"unavailable: {type(e).__name__}: {e}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +202,9 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--fwd-only", action="store_true", help="time the no_grad forward only (inference paths)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-ab", action="store_true", help="skip timing the hipified reference kernels (optional A/B)")
+    ap.add_argument("--overlap-chunks", type=int, default=4,
+                    help="N > 1: SH-gradient ranges reduced from inside the backward (0/1 = one all-reduce after it)")
     ap.add_argument("--traffic", type=float, default=None,
                     help="measured HBM bytes per composite_fwd launch from a rocprofv3 --pmc pass; default: the "
                          "committed measurement in profiles/r*_traffic.json for this workload, else null")
@@ -171,7 +255,9 @@ def main():
     bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()), roles=params)
     state = {}
 
-    def step():
+    comm_ev = []       # (backward enqueued, reduction finished) events of the timed steps, N > 1 only
+
+    def step(timed=False):
         if a.fwd_only:
             with torch.no_grad():
                 out = rasterizer(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
@@ -182,12 +268,18 @@ def main():
             p.grad = None
         means2D.grad = None
         if world > 1:
-            bucket.arm()                                   # gradients are born in the flat all-reduce buffer
+            # gradients are born in the flat all-reduce buffer; the SH ranges are reduced while the backward runs
+            bucket.arm(a.overlap_chunks)
         color, radii, depth, median, opac = rasterizer(
             means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], shs=params["shs"],
             scales=params["scales"], rotations=params["rotations"])
         torch.autograd.backward([color, depth, median, opac], grads)
-        parallel.allreduce_gaussian_grads(bucket)          # one flat all-reduce (no-op collective at N=1)
+        if world > 1 and timed:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+        parallel.allreduce_gaussian_grads(bucket)          # the tail of the one logical reduction (no-op at N=1)
+        if world > 1 and timed:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            comm_ev.append((e0, e1))
         state["out"] = (color, radii, depth, median, opac)
 
     def barrier():
@@ -202,7 +294,7 @@ def main():
     _C.set_profiling(True)                                   # HIP events on the launch stream, no host syncs
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        step(timed=True)
     barrier()
     dt = time.perf_counter() - t0
     fwd_ms = _C.last_forward_ms()
@@ -213,12 +305,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # instance count R of this rank's view (drives every composite-stage byte count)
+    # instance counts of this rank's view (they drive every composite-stage byte count): the reference-defined
+    # num_rendered and the instances actually binned; per-tile list lengths
     with torch.no_grad():
-        R = _C.rasterize_gaussians(rs.bg, params["means3D"], torch.Tensor([]), params["opacities"], params["scales"],
-                                   params["rotations"], 1.0, torch.Tensor([]), rs.viewmatrix, rs.projmatrix,
-                                   rs.tanfovx, rs.tanfovy, H, W, params["shs"], D, rs.campos, False, False)[0]
+        out = _C.rasterize_gaussians(rs.bg, params["means3D"], torch.Tensor([]), params["opacities"], params["scales"],
+                                     params["rotations"], 1.0, torch.Tensor([]), rs.viewmatrix, rs.projmatrix,
+                                     rs.tanfovx, rs.tanfovy, H, W, params["shs"], D, rs.campos, False, False)
+        R_ref = out[0]
+        counts = _C.inspect_counts(out[8], W, H)
+        R = counts["num_binned"]
+        _, ranges = _C.inspect_binning(out[7], out[8], R, W, H)
+        lists = list_histogram(ranges)
         vis = int((state["out"][1] > 0).sum().item())
+        del out
 
     if rank == 0:
         T = ((W + 15) // 16) * ((H + 15) // 16)
@@ -226,21 +325,21 @@ def main():
         value = world * H * W / (dt / a.steps) / 1e6
         comp_ms = fwd_ms["composite"] if fwd_ms else None
         alg_bytes = R * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8)
+        counters = committed_counters(a.workload)
         traffic = a.traffic
-        if traffic is None:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
-                t = json.load(open(f))
-                if t.get("workload") == a.workload and "composite_fwd" in t:
-                    traffic = t["composite_fwd"]["traffic_bytes"]      # PMC counters cannot be read in-process
-                    break
+        if traffic is None and counters and "composite_fwd" in counters:
+            traffic = counters["composite_fwd"].get("traffic_bytes")
         roof = None
         if comp_ms:
             achieved = alg_bytes / (comp_ms * 1e-3) / 1e9
             roof = {"kernel": "composite_fwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                     "algorithmic_bytes": alg_bytes, "avg_ms": round(comp_ms, 4),
-                    "note": "composite is VALU-bound (256 pixel evaluations per staged 48-B record), see DESIGN.md s5"}
+                    "algorithmic_bytes_with_reference_R": R_ref * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8),
+                    "valu": valu_issue(counters, "composite_fwd", comp_ms),
+                    "note": "algorithmic bytes use the instances actually staged (tight binning); the kernel is VALU-issue "
+                            "bound (256 pixel evaluations per staged 48-B record): `valu.issue_frac` is the fraction of the "
+                            "SIMDs' issue cycles its VALU instructions fill, see DESIGN.md s4"}
         line = {
             "metric": "Mpixels/s fwd+bwd @1M Gaussians 1920x1080" if a.workload == "C3" and not a.fwd_only
                       else f"Mpixels/s {'fwd' if a.fwd_only else 'fwd+bwd'} @{a.workload}",
@@ -248,17 +347,35 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "gaussians": P, "visible": vis, "width": W, "height": H, "sh_degree": D,
-                       "num_rendered": R, "tiles": T, "views_per_step": world,
-                       "parallelism": f"one camera per GPU x{world}, 1 flat RCCL all-reduce of "
-                                      f"{0 if bucket is None else bucket.nbytes} B/rank" if world > 1 else "single GPU"},
+                       "num_rendered": R_ref, "instances_binned": R, "tiles": T, "tile_list_length": lists,
+                       "views_per_step": world,
+                       "parallelism": f"one camera per GPU x{world}, 1 logical RCCL all-reduce of "
+                                      f"{0 if bucket is None else bucket.nbytes} B/rank "
+                                      f"({a.overlap_chunks if a.overlap_chunks > 1 else 1} chunk(s) overlapped with the backward)"
+                                      if world > 1 else "single GPU"},
             "stage_ms": {"forward": fwd_ms, "backward": bwd_ms},
             "stage_roofline": stage_roofline(P, vis, R, T, H, W, D, fwd_ms, bwd_ms, a.fwd_only),
             "roofline": roof,
         }
+        if bwd_ms:
+            line["valu_composite_bwd"] = valu_issue(counters, "composite_bwd", bwd_ms.get("composite_bwd"))
+        if world > 1 and comm_ev:
+            torch.cuda.synchronize()
+            exposed = sum(e0.elapsed_time(e1) for e0, e1 in comm_ev) / len(comm_ev)
+            comp_total = sum(v for k, v in (fwd_ms or {}).items() if k != "calls") + sum(v for k, v in (bwd_ms or {}).items() if k != "calls")
+            line["comm"] = {"payload_bytes_per_rank": bucket.nbytes, "chunks_per_step": bucket.stats["chunks"] / max(1, a.steps + a.warmup),
+                            "chunk_bytes_per_step": bucket.stats["chunk_bytes"] / max(1, a.steps + a.warmup),
+                            "tail_bytes_per_step": bucket.stats["tail_bytes"] / max(1, a.steps + a.warmup),
+                            "compute_ms": round(comp_total, 4), "comm_exposed_ms": round(exposed, 4),
+                            "note": "compute_ms = sum of the operator's kernel stages (HIP events); comm_exposed_ms = time from the "
+                                    "end of the backward's enqueue to the end of the reduction on rank 0's stream (what the "
+                                    "collective adds to the step after overlap)"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, cam, D, grads_cpu)
         else:
             line["cpu_baseline"] = None
+        if world == 1 and not a.no_ref_ab and not a.fwd_only:
+            line["reference_hipified_ms"] = reference_ab(sc, cam, D, grads_cpu, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -36,7 +36,7 @@ def lib():
         L.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
         L.gsr_backward_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.gsr_abi_version.restype = ctypes.c_int
-        if L.gsr_abi_version() != 4:
+        if L.gsr_abi_version() != 5:
             raise ImportError("libgsrast.so ABI version mismatch")
         _lib = L
     return _lib
@@ -101,10 +101,48 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                                  geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug))
 
 
-def set_grad_arena(outs):
+def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None):
     """One-shot destination tensors [dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations] for the next
-    rasterize_gaussians_backward (see gaustudio_amd/parallel.py); [] disarms."""
-    native().set_grad_arena(list(outs))
+    rasterize_gaussians_backward whose inputs [means3D, sh, scales, rotations] have the data pointers `keys`
+    (0 / empty = any); see gaustudio_amd/parallel.py.  With sh_chunks > 1 and a hook, the SH stage of that backward
+    runs in Gaussian ranges and hook(c, g0, g1) is called after range c has been enqueued.  [] disarms."""
+    native().set_grad_arena(list(outs), [int(k) for k in keys], int(sh_chunks), hook)
+
+
+def set_option(name, value):
+    """Process-wide tunables of libgsrast.so (include/gsrast.h gsr_set_option); none changes a result bit."""
+    L = lib()
+    rc = L.gsr_set_option(name.encode(), ctypes.c_int(int(value)))
+    if rc < 0:
+        raise _err(L, rc)
+
+
+def get_option(name):
+    return int(lib().gsr_get_option(name.encode()))
+
+
+def selftest(device=None):
+    """Bit mask of the device arithmetic identities composite_bwd relies on (3 = all hold)."""
+    L = lib()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        rc = L.gsr_selftest(_stream(dev))
+    if rc < 0:
+        raise _err(L, rc)
+    return rc
+
+
+def inspect_counts(imgBuffer, width, height):
+    """{'num_binned': instances actually binned (length of point_list), 'max_tile': longest tile list,
+    'num_rendered': the reference-defined count rasterize_gaussians returned}."""
+    L = lib()
+    dev = imgBuffer.device
+    out = (ctypes.c_uint32 * 4)()
+    with torch.cuda.device(dev):
+        rc = L.gsr_inspect_counts(_ptr(imgBuffer), ctypes.c_int(width), ctypes.c_int(height), out, _stream(dev))
+    if rc < 0:
+        raise _err(L, rc)
+    return dict(num_binned=int(out[0]), max_tile=int(out[1]), num_rendered=int(out[2]), overflow=int(out[3]))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

@@ -3,7 +3,9 @@
 #include "../../include/gsrast.h"
 #include "gsr_internal.h"
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -93,7 +95,7 @@ int fail(int code, const char* what, const char* file, int line, hipError_t e = 
 		}                                                                                      \
 	} while (0)
 
-bool is_device_ptr(const void* p)
+bool query_device_ptr(const void* p)
 {
 	hipPointerAttribute_t attr;
 	hipError_t e = hipPointerGetAttributes(&attr, p);
@@ -102,6 +104,49 @@ bool is_device_ptr(const void* p)
 		return false;
 	}
 	return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// hipPointerGetAttributes is a driver query of several microseconds and sits on the hot path (camera matrices and
+// background of every call): the classification of the last few pointers is remembered per thread.  A training
+// loop passes the same few tensors every iteration; torch's caching allocator never hands a device address back
+// to the host heap, so a cached answer cannot go stale in a way that matters (a wrong "host" answer would read
+// the pointer on the host and fault loudly, never silently).
+bool is_device_ptr(const void* p)
+{
+	struct Entry { const void* p; bool dev; };
+	thread_local Entry cache[8] = {};
+	thread_local int next = 0;
+	for (const Entry& e : cache)
+		if (e.p == p && p != nullptr) return e.dev;
+	const bool dev = query_device_ptr(p);
+	cache[next] = Entry{p, dev};
+	next = (next + 1) & 7;
+	return dev;
+}
+
+// ---- tunables (gsr_set_option / environment), process-wide ----
+int env_int(const char* name, int dflt)
+{
+	const char* v = getenv(name);
+	return (v && *v) ? atoi(v) : dflt;
+}
+std::atomic<int> g_opt_tight{env_int("GSR_TIGHT_BINNING", 1)};     // bin into gs_tight_rect (0: the reference's squares)
+std::atomic<int> g_opt_cull{env_int("GSR_CULL", 1)};               // composite_fwd wave culling + pcut pre-test
+std::atomic<int> g_opt_bwd_variant{env_int("GSR_BWD_VARIANT", -1)};   // -1: from gsr_selftest; bit 0: select on T
+std::atomic<int> g_opt_speculative{env_int("GSR_SPECULATIVE", 1)}; // launch binning + compositing before R is known
+// per device: capacity (instances) the binning buffer is allocated with while R is still in flight, and whether
+// the last frame had a tile list long enough for the radix path (which needs the second key buffer)
+struct DevState {
+	std::atomic<uint32_t> cap{0};
+	std::atomic<int> long_lists{0};
+	std::atomic<int> selftest{-1};
+};
+DevState g_dev[16];
+DevState& dev_state()
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+	return g_dev[dev];
 }
 
 // Camera staging: the four small inputs (view 16, proj 16, campos 3, bg 3 floats) may each live in host or
@@ -144,11 +189,12 @@ hipEvent_t readback_event()
 	return ev[dev];
 }
 
-uint32_t* pinned_words()
+// pinned, device-mapped host block tile_scan_kernel mirrors the control words into (one per host thread)
+GsCtl* pinned_ctl()
 {
-	thread_local uint32_t* p = nullptr;
+	thread_local GsCtl* p = nullptr;
 	if (!p) {
-		if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+		if (hipHostMalloc((void**)&p, 256, hipHostMallocDefault) != hipSuccess) p = nullptr;
 	}
 	return p;
 }
@@ -166,18 +212,19 @@ struct Timer {
 __global__ __launch_bounds__(256) void fill_empty_outputs_kernel(size_t HW, float* out_color, float* out_depth,
                                                                  float* out_median, float* out_opacity)
 {
-	// image of an empty scene: C = 0, depth = 0, median = (15, 0, 0), opacity = 0 (forward.cu:306-312,385-396)
+	// P == 0: the reference launches nothing and returns its torch::full(0.0) images (rasterize_points.cu:67-84);
+	// the 15.0 median sentinel only appears when the render kernel runs (P > 0 with empty tiles)
 	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= HW) return;
 	out_color[i] = 0.f; out_color[HW + i] = 0.f; out_color[2 * HW + i] = 0.f;
 	out_depth[i] = 0.f;
-	out_median[i] = 15.0f; out_median[HW + i] = 0.f; out_median[2 * HW + i] = 0.f;
+	out_median[i] = 0.f; out_median[HW + i] = 0.f; out_median[2 * HW + i] = 0.f;
 	out_opacity[i] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void inspect_geometry_kernel(int P, const int* radii, const GsRec* recs,
-                                                               float* means2D, float* depths, float* conic_opacity,
-                                                               float* rgb, unsigned char* clamped,
+                                                               const uint32_t* tt, float* means2D, float* depths,
+                                                               float* conic_opacity, float* rgb, unsigned char* clamped,
                                                                uint32_t* tiles_touched)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -197,7 +244,7 @@ __global__ __launch_bounds__(256) void inspect_geometry_kernel(int P, const int*
 	if (clamped) {
 		for (int ch = 0; ch < 3; ch++) clamped[3 * idx + ch] = vis ? (unsigned char)((r.q3.z >> ch) & 1u) : 0;
 	}
-	if (tiles_touched) tiles_touched[idx] = vis ? r.q3.w : 0u;
+	if (tiles_touched) tiles_touched[idx] = vis ? tt[idx] : 0u;
 }
 
 __global__ __launch_bounds__(256) void inspect_image_kernel(int gx, int W, int H, const float* tT, const uint32_t* tN,
@@ -217,7 +264,7 @@ __global__ __launch_bounds__(256) void inspect_image_kernel(int gx, int W, int H
 
 extern "C" {
 
-int gsr_abi_version(void) { return 4; }
+int gsr_abi_version(void) { return 5; }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -329,67 +376,93 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
 	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.prefiltered = prefiltered;
 	a.shs_rest = shs_rest; a.act = activation_flags;
+	a.tight = g_opt_tight.load() != 0;
 
 	tm.mark();
 	uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + gl.tiles_touched);
+	uint32_t* bsums = reinterpret_cast<uint32_t*>(geom + gl.bsums);
+	uint32_t* refsums = reinterpret_cast<uint32_t*>(geom + gl.refsums);
 	uint32_t* Hm = reinterpret_cast<uint32_t*>(img + hm_off);
-	launch_preprocess_fwd(a, cam, il, radii, recs, tiles_touched, lds_bin ? nullptr : tile_count, ctl, s);
+	launch_preprocess_fwd(a, cam, il, radii, recs, tiles_touched, bsums, refsums, lds_bin ? nullptr : tile_count, ctl, s);
 	STAGE_CHECK("preprocess_fwd", debug, s);
 	tm.mark();
 	if (lds_bin) {
 		launch_bin_hist(P, il.gx, il.T, tiles_touched, recs, Hm, tile_count, s);
 		STAGE_CHECK("bin_hist", debug, s);
 	}
-	launch_tile_scan(il.T, tile_count, ranges, ctl, s);
-	STAGE_CHECK("tile_scan", debug, s);
-
-	// the one host sync of the forward pass: R sizes the binning buffer and is returned to the caller
-	uint32_t* host = pinned_words();
+	GsCtl* host = pinned_ctl();
 	if (!host) return fail(GSR_ERR_HIP, "hipHostMalloc", __FILE__, __LINE__);
-	HIP_TRY(hipMemcpyAsync(host, ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
+	launch_tile_scan(il.T, tile_count, ranges, (int)gl.nblk, bsums, refsums, ctl, host, s);
+	STAGE_CHECK("tile_scan", debug, s);
+	// The instance counts are now in pinned host memory (written by the kernel itself: no copy command in the
+	// stream).  The host needs them to return num_rendered and to check that the binning buffer is large enough --
+	// but the DEVICE does not have to wait for the host: everything below is enqueued against a buffer of the
+	// remembered capacity before the event is waited on, so the GPU never idles across the read-back (the reference
+	// blocks mid-forward, rasterizer_impl.cu:283-284).  The kernels leave without touching memory if the capacity
+	// turns out too small; the host then allocates the real size and enqueues them again (rare: the capacity only
+	// grows).
 	hipEvent_t ev = readback_event();
 	if (ev) HIP_TRY(hipEventRecord(ev, s));
-	// While the host waits for R (and then sizes the binning buffer and launches the rest), the device computes
-	// goff = exclusive scan of tiles_touched, which only the backward needs: it fills the bubble instead of
-	// costing the backward three launches.
-	launch_gaussian_scan(P, tiles_touched, reinterpret_cast<uint32_t*>(geom + gl.goff),
-	                     reinterpret_cast<uint32_t*>(geom + gl.bsums), s);
+	launch_goff_apply(P, tiles_touched, bsums, reinterpret_cast<uint32_t*>(geom + gl.goff), recs, s);
+	STAGE_CHECK("goff_apply", debug, s);
+	tm.mark();
+
+	DevState& ds = dev_state();
+	const bool nocull = g_opt_cull.load() == 0;
+	auto launch_rest = [&](uint32_t cap, bool with_long) -> int {
+		const BinLayout bl((size_t)cap, with_long);
+		char* bin = binning_alloc(binning_ctx, bl.total);
+		if (!bin) return fail(GSR_ERR_ALLOC, "gsr_forward: binning allocator returned NULL", __FILE__, __LINE__);
+		uint64_t* keys = reinterpret_cast<uint64_t*>(bin + bl.keys);
+		uint64_t* keys2 = reinterpret_cast<uint64_t*>(bin + bl.keys2);
+		uint32_t* point_list = reinterpret_cast<uint32_t*>(bin + bl.point_list);
+		if (cap > 0) {
+			if (lds_bin)
+				launch_bin_scatter2(P, il.gx, il.T, tiles_touched, recs, Hm, ranges, keys, ctl, cap, s);
+			else
+				launch_bin_scatter(P, il.gx, radii, tiles_touched, recs, ranges, tile_count, keys, ctl, cap, s);
+			STAGE_CHECK("bin_scatter", debug, s);
+		}
+		tm.mark();
+		if (cap > 0) {
+			launch_tile_sort(il.T, true, with_long, ranges, keys, keys2, point_list, ctl, cap, s);
+			STAGE_CHECK("tile_sort", debug, s);
+		}
+		tm.mark();
+		launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
+		                     out_opacity, final_T, n_contrib, ctl, cap, with_long ? 0xffffffffu : GSR_SORT_LDS_MAX, nocull, s);
+		STAGE_CHECK("composite_fwd", debug, s);
+		tm.mark();
+		return 0;
+	};
+
+	const uint32_t cap0 = ds.cap.load();
+	const bool long0 = ds.long_lists.load() != 0;
+	const bool speculate = !debug && g_opt_speculative.load() != 0 && cap0 > 0;
+	if (speculate) {
+		const int rc = launch_rest(cap0, long0);
+		if (rc < 0) return rc;
+	}
 	if (ev) HIP_TRY(hipEventSynchronize(ev));
 	else HIP_TRY(hipStreamSynchronize(s));
-	STAGE_CHECK("gaussian_scan", debug, s);
-	const uint32_t R = host[0], max_tile = host[1], err_pref = host[2];
-	if (err_pref)
+	const uint32_t Rb = host->num_binned, max_tile = host->max_tile_count;
+	if (host->err_prefiltered)
 		return fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!",
 		            __FILE__, __LINE__);
-	if (host[3] || R > 0x7fffffffu)
+	if (host->err_overflow || host->ref_rendered > 0x7fffffffu || Rb > 0x7fffffffu)
 		return fail(GSR_ERR_ARG, "gsr_forward: more than 2^31 - 1 (tile, Gaussian) instances", __FILE__, __LINE__);
-
-	const BinLayout bl((size_t)R, max_tile > GSR_SORT_LDS_MAX);
-	char* bin = binning_alloc(binning_ctx, bl.total);
-	if (!bin) return fail(GSR_ERR_ALLOC, "gsr_forward: binning allocator returned NULL", __FILE__, __LINE__);
-	uint64_t* keys = reinterpret_cast<uint64_t*>(bin + bl.keys);
-	uint64_t* keys2 = reinterpret_cast<uint64_t*>(bin + bl.keys2);
-	uint32_t* point_list = reinterpret_cast<uint32_t*>(bin + bl.point_list);
-
-	tm.mark();
-	if (R > 0) {
-		if (lds_bin)
-			launch_bin_scatter2(P, il.gx, il.T, tiles_touched, recs, Hm, ranges, keys, s);
-		else
-			launch_bin_scatter(P, il.gx, radii, recs, ranges, tile_count, keys, s);
-		STAGE_CHECK("bin_scatter", debug, s);
+	const bool need_long = max_tile > GSR_SORT_LDS_MAX;
+	if (!speculate || Rb > cap0 || (need_long && !long0)) {
+		// first call on this device, debug mode, or the speculation missed: exact size, launched now
+		const int rc = launch_rest(Rb, need_long);
+		if (rc < 0) return rc;
 	}
-	tm.mark();
-	if (R > 0) {
-		launch_tile_sort(il.T, max_tile, ranges, keys, keys2, point_list, s);
-		STAGE_CHECK("tile_sort", debug, s);
-	}
-	tm.mark();
-	launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
-	                     out_opacity, final_T, n_contrib, s);
-	STAGE_CHECK("composite_fwd", debug, s);
-	tm.mark();
-	return (int)R;
+	// grow-only capacity with 25 % headroom for the next frame
+	const uint32_t want = Rb + Rb / 4 + 4096u;
+	uint32_t cur = ds.cap.load();
+	while (cur < want && !ds.cap.compare_exchange_weak(cur, want)) {}
+	ds.long_lists.store(need_long ? 1 : 0);
+	return (int)host->ref_rendered;
 }
 
 int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
@@ -423,12 +496,30 @@ int gsr_forward_raw(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_f
 	                    stream);
 }
 
+size_t gsr_geometry_bytes(int P) { return GeomLayout((size_t)(P > 0 ? P : 0)).total; }
+size_t gsr_image_bytes(int width, int height) { return (width > 0 && height > 0) ? ImgLayout(width, height).total : 0; }
+
 size_t gsr_backward_scratch_bytes(int P, int R)
 {
 	return BwdLayout((size_t)(P > 0 ? P : 0), (size_t)(R > 0 ? R : 0)).total;
 }
 
-static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height,
+// composite_bwd variant: bit 0 = keep a select on T (devices where v_rcp_f32(1.0) != 1.0)
+static int bwd_variant(hipStream_t s)
+{
+	const int opt = g_opt_bwd_variant.load();
+	if (opt >= 0) return opt;
+	DevState& ds = dev_state();
+	int st = ds.selftest.load();
+	if (st < 0) {
+		st = gsr_selftest((void*)s);
+		if (st < 0) st = 0;
+		ds.selftest.store(st);
+	}
+	return (st & 3) == 3 ? 0 : 1;
+}
+
+static int backward_impl(int parts, int sh_g0, int sh_g1, int P, int D, int M, int R, const float* background, int width, int height,
                          const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
                          const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                          int activation_flags, float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
@@ -466,6 +557,21 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	float* rows = reinterpret_cast<float*>(scratch + wl.rows);
 	uint8_t* row_flags = reinterpret_cast<uint8_t*>(scratch + wl.flags);
 
+	BwdArgs a;
+	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
+	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
+	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
+	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.radii = radii;
+	a.shs_rest = shs_rest; a.act = activation_flags;
+
+	if (!(parts & GSR_BWD_PART_MAIN)) {
+		// SH stage alone over a Gaussian range (the caller interleaves a collective per chunk, gaustudio_amd/parallel.py)
+		launch_preprocess_bwd(a, cam, recs, goff, rows, nullptr, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+		                      dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_SH, sh_g0, sh_g1, s);
+		STAGE_CHECK("preprocess_bwd_sh", debug, s);
+		return GSR_OK;
+	}
+
 	// The background is re-staged here because the reference reads the backward's own `background`
 	// argument (backward.cu:584-587), which the forward never dereferences.
 	Timer tm(prof_next(g_bwd_log), s);
@@ -485,22 +591,16 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	// the regime is recorded next to the staged background for gsr_inspect_backward_sums (word 8 of the bg block)
 	HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bg_dev + 8), flagged ? 1 : 0, 1, s));
 
-	BwdArgs a;
-	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
-	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
-	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
-	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.radii = radii;
-	a.shs_rest = shs_rest; a.act = activation_flags;
-
 	tm.mark();
 	if (R > 0) {
-		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, goff, final_T, n_contrib, dL_dpix,
-		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags, s);
+		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, final_T, n_contrib, dL_dpix,
+		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags, bwd_variant(s), s);
 		STAGE_CHECK("composite_bwd", debug, s);
 	}
 	tm.mark();
 	launch_preprocess_bwd(a, cam, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-	                      dL_dsh_rest, dL_dscale, dL_drot, s);
+	                      dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_GEOM | ((parts & GSR_BWD_PART_SH) ? GSR_PART_SH : 0),
+	                      sh_g0, sh_g1, s);
 	STAGE_CHECK("preprocess_bwd", debug, s);
 	tm.mark();
 	return GSR_OK;
@@ -517,11 +617,93 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                  char* scratch, int debug, void* stream)
 {
 	(void)viewmatrix; (void)projmatrix; (void)campos;   // the device copies made by gsr_forward are used
-	return backward_impl(P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp, scales,
+	return backward_impl(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P, P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp, scales,
 	                     scale_modifier, rotations, cov3D_precomp, 0, tan_fovx, tan_fovy, radii, geom_buffer,
 	                     binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
 	                     dL_dpix_final_opacity, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
 	                     nullptr, dL_dscale, dL_drot, scratch, debug, stream);
+}
+
+int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int R, const float* background, int width,
+                       int height, const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp, float tan_fovx,
+                       float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
+                       const char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth,
+                       const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D,
+                       float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                       float* dL_dscale, float* dL_drot, char* scratch, int debug, void* stream)
+{
+	if (!(parts & (GSR_BWD_PART_MAIN | GSR_BWD_PART_SH)))
+		return fail(GSR_ERR_ARG, "gsr_backward_parts: nothing to do", __FILE__, __LINE__);
+	if ((parts & GSR_BWD_PART_SH) && sh_g0 % 256 != 0)
+		return fail(GSR_ERR_ARG, "gsr_backward_parts: sh_g0 must be a multiple of 256", __FILE__, __LINE__);
+	return backward_impl(parts, sh_g0, sh_g1, P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp,
+	                     scales, scale_modifier, rotations, cov3D_precomp, 0, tan_fovx, tan_fovy, radii, geom_buffer,
+	                     binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
+	                     dL_dpix_final_opacity, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+	                     nullptr, dL_dscale, dL_drot, scratch, debug, stream);
+}
+
+int gsr_set_option(const char* name, int value)
+{
+	g_err.clear();
+	if (!name) return fail(GSR_ERR_ARG, "gsr_set_option: NULL name", __FILE__, __LINE__);
+	const std::string n(name);
+	if (n == "tight_binning") g_opt_tight.store(value);
+	else if (n == "cull") g_opt_cull.store(value);
+	else if (n == "bwd_variant") g_opt_bwd_variant.store(value);
+	else if (n == "speculative") g_opt_speculative.store(value);
+	else if (n == "bin_capacity") {   // capacity assumed for the NEXT forward on the current device (tests: force the re-launch path)
+		DevState& ds = dev_state();
+		ds.cap.store(value > 0 ? (uint32_t)value : 0u);
+		if (value <= 0) ds.long_lists.store(0);
+	} else return fail(GSR_ERR_ARG, "gsr_set_option: unknown option", __FILE__, __LINE__);
+	return GSR_OK;
+}
+
+int gsr_get_option(const char* name)
+{
+	if (!name) return -1;
+	const std::string n(name);
+	if (n == "tight_binning") return g_opt_tight.load();
+	if (n == "cull") return g_opt_cull.load();
+	if (n == "bwd_variant") return g_opt_bwd_variant.load();
+	if (n == "speculative") return g_opt_speculative.load();
+	if (n == "bin_capacity") return (int)dev_state().cap.load();
+	return -1;
+}
+
+int gsr_selftest(void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	float* in = nullptr;
+	HIP_TRY(hipMalloc((void**)&in, 64));
+	const float h_in[2] = {1.0f, 0.0f};
+	uint32_t h_out[2] = {0u, 0u};
+	hipError_t e = hipMemcpyAsync(in, h_in, sizeof(h_in), hipMemcpyHostToDevice, s);
+	if (e == hipSuccess) {
+		launch_bwd_selftest(in, reinterpret_cast<uint32_t*>(in + 4), s);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(h_out, in + 4, sizeof(h_out), hipMemcpyDeviceToHost, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	(void)hipFree(in);
+	if (e != hipSuccess) return fail(GSR_ERR_HIP, "gsr_selftest", __FILE__, __LINE__, e);
+	return (int)h_out[0];
+}
+
+int gsr_inspect_counts(const char* image_buffer, int width, int height, uint32_t out[4], void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	if (!image_buffer || !out) return fail(GSR_ERR_ARG, "gsr_inspect_counts: NULL argument", __FILE__, __LINE__);
+	const ImgLayout il(width, height);
+	GsCtl c;
+	HIP_TRY(hipMemcpyAsync(&c, image_buffer + il.ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	out[0] = c.num_binned; out[1] = c.max_tile_count; out[2] = c.ref_rendered; out[3] = c.err_overflow;
+	return GSR_OK;
 }
 
 int gsr_backward_raw(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -535,7 +717,7 @@ int gsr_backward_raw(int P, int D, int M, int R, const float* background, int wi
 {
 	if (P > 0 && (!f_dc || (M > 1 && (!f_rest || !dL_df_rest)) || !dL_df_dc))
 		return fail(GSR_ERR_ARG, "gsr_backward_raw: f_dc / f_rest and their gradient outputs are required", __FILE__, __LINE__);
-	return backward_impl(P, D, M, R, background, width, height, means3D, f_dc, M > 1 ? f_rest : nullptr, nullptr, raw_scales,
+	return backward_impl(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P, P, D, M, R, background, width, height, means3D, f_dc, M > 1 ? f_rest : nullptr, nullptr, raw_scales,
 	                     scale_modifier, raw_rotations, nullptr, activation_flags, tan_fovx, tan_fovy, radii, geom_buffer,
 	                     binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
 	                     dL_dpix_final_opacity, dL_dmean2D, dL_draw_opacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_df_dc,
@@ -552,7 +734,8 @@ int gsr_inspect_geometry(const char* geom_buffer, int P, const int* radii, float
 	if (!geom_buffer || !radii) return fail(GSR_ERR_ARG, "gsr_inspect_geometry: NULL buffer", __FILE__, __LINE__);
 	const GeomLayout gl((size_t)P);
 	hipLaunchKernelGGL(inspect_geometry_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii,
-	                   reinterpret_cast<const GsRec*>(geom_buffer + gl.recs), means2D, depths, conic_opacity, rgb,
+	                   reinterpret_cast<const GsRec*>(geom_buffer + gl.recs),
+	                   reinterpret_cast<const uint32_t*>(geom_buffer + gl.tiles_touched), means2D, depths, conic_opacity, rgb,
 	                   clamped, tiles_touched);
 	STAGE_CHECK("inspect_geometry", 0, s);
 	return GSR_OK;

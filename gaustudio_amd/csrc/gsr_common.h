@@ -20,7 +20,10 @@
 //   q0 = { px, py, -0.5*conic_a, -conic_b }          (pre-scaled: exact power-of-two / sign changes)
 //   q1 = { -0.5*conic_c, opacity, depth, pcut }
 //   q2 = { r, g, b, radius(int bits) }
-//   q3 = { rect_min (x | y<<16), rect_max (x | y<<16), clamped bits, tiles_touched }   (uint bits)
+//   q3 = { rect_min (x | y<<16), rect_max (x | y<<16), clamped bits, goff }   (uint bits)
+// rect = the TIGHT tile rect the Gaussian is binned into (gs_tight_rect below; a sub-rect of the reference's
+// getRect square), goff = first row of the Gaussian in the backward's Gaussian-major row array (exclusive scan of
+// tiles_touched, patched in by goff_apply_kernel).
 // pcut: conservative lower bound on `power` below which alpha < 1/255 is certain, see preprocess.
 // ---------------------------------------------------------------------------------------------
 struct __attribute__((aligned(64))) GsRec {
@@ -37,12 +40,14 @@ struct GsCam {
 	float bg[4];
 };
 
-// Control words living in the image buffer.
+// Control words living in the image buffer (mirrored into pinned host memory by tile_scan_kernel).
 struct GsCtl {
-	uint32_t num_rendered;   // R
+	uint32_t num_binned;     // instances actually binned (tight rects): sizes every per-instance buffer
 	uint32_t max_tile_count; // longest per-tile list
 	uint32_t err_prefiltered;
-	uint32_t err_overflow;   // R does not fit the reference's int num_rendered
+	uint32_t err_overflow;   // the reference-defined count does not fit the reference's int num_rendered
+	uint32_t ref_rendered;   // the reference's num_rendered: sum of getRect areas (rasterizer_impl.cu:280-284)
+	uint32_t pad[3];
 };
 
 __device__ __forceinline__ float gs_exp(float p)
@@ -61,6 +66,61 @@ __device__ __forceinline__ float gs_exp(float p)
 	y = FMA(y, f, 0x1.62e428p-1f);
 	y = FMA(y, f, 0x1.000002p+0f);
 	return __int_as_float(__float_as_int(y) + (__float_as_int(tm) << 23));
+}
+
+// Reproducible natural logarithm (positive normal x): x = m * 2^e, m in [1, 2), ln x = e ln2 + 2 atanh((m-1)/(m+1))
+// with the series cut after s^9 (|error| < 1.5e-6 + rounding).  Only IEEE +,*,/,fma: the CPU oracle evaluates the
+// same operations and gets the same bits (the tight tile rects must agree exactly between the two).
+__device__ __forceinline__ float gs_log(float x)
+{
+	const int xb = __float_as_int(x);
+	const int e = ((xb >> 23) & 0xff) - 127;
+	const float m = __int_as_float((xb & 0x007fffff) | 0x3f800000);
+	const float s = (m - 1.0f) / (m + 1.0f);
+	const float s2 = s * s;
+	float p = 0.11111111f;
+	p = FMA(p, s2, 0.14285715f);
+	p = FMA(p, s2, 0.2f);
+	p = FMA(p, s2, 0.33333334f);
+	p = FMA(p, s2, 1.0f);
+	return FMA((float)e, 0.69314718f, (2.0f * s) * p);
+}
+
+// Tight tile rect (SnugBox-style, opacity-aware).  The reference bins a Gaussian into every tile of the square
+// of side 2*ceil(3 sigma_max) around its centre (auxiliary.h:46-56); a pixel can only pass `alpha >= 1/255`
+// (forward.cu:346) inside the ellipse  a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 opacity),  whose axis-aligned
+// bounding box is |dx| <= sqrt(2 t c / det), |dy| <= sqrt(2 t a / det).  Tiles of the reference rect that hold no
+// pixel centre of that box cannot contribute and are not binned: images, radii and every gradient are unchanged,
+// the lists get ~23 % shorter at C3.  Conservative by construction: t carries +0.01 (exp polynomial, thresholds),
+// a slack proportional to a*c/det (rounding of the per-pixel `power`, which cancels for elongated conics) and
+// +0.05; the box another 0.01 px.  Degenerate / non-positive-definite / NaN inputs keep the reference rect.
+// In/out: the reference rect; returns false when no tile can hold a live pixel.  Mirrored bit for bit by
+// oracle/gsr_oracle.c:orc_tight_rects (explicit ternaries instead of fmin/fmax so that NaN behaves identically).
+__device__ __forceinline__ bool gs_tight_rect(float px, float py, float ca, float cb, float cc, float op, int gx, int gy,
+                                              int& rminx, int& rminy, int& rmaxx, int& rmaxy)
+{
+	if (op <= 0.0f) return false;                       // alpha = min(0.99, op * G) <= 0 < 1/255 everywhere
+	const float t = gs_log(255.0f * op) + 0.01f;
+	if (t <= 0.0f) return false;                        // 255 * op <= 0.99: alpha < 1/255 everywhere
+	const float det = FMA(-cb, cb, ca * cc);
+	if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return true;
+	const float rel = (ca * cc) / det;
+	if (!(rel < 1.0e5f)) return true;
+	const float teff = FMA(t * 4.0e-5f, rel, t) + 0.05f;
+	if (!(teff > 0.0f)) return true;
+	const float ex = sqrtf((2.0f * teff) * (cc / det)) + 0.01f;
+	const float ey = sqrtf((2.0f * teff) * (ca / det)) + 0.01f;
+	// tile column k holds pixel centres 16k .. 16k+15
+	float fx0 = ceilf((px - ex - 15.0f) * 0.0625f), fx1 = floorf((px + ex) * 0.0625f) + 1.0f;
+	float fy0 = ceilf((py - ey - 15.0f) * 0.0625f), fy1 = floorf((py + ey) * 0.0625f) + 1.0f;
+	const float fgx = (float)gx, fgy = (float)gy;
+	fx0 = fx0 > 0.0f ? fx0 : 0.0f; fx0 = fx0 < fgx ? fx0 : fgx;
+	fx1 = fx1 > 0.0f ? fx1 : 0.0f; fx1 = fx1 < fgx ? fx1 : fgx;
+	fy0 = fy0 > 0.0f ? fy0 : 0.0f; fy0 = fy0 < fgy ? fy0 : fgy;
+	fy1 = fy1 > 0.0f ? fy1 : 0.0f; fy1 = fy1 < fgy ? fy1 : fgy;
+	rminx = max(rminx, (int)fx0); rmaxx = min(rmaxx, (int)fx1);
+	rminy = max(rminy, (int)fy0); rmaxy = min(rmaxy, (int)fy1);
+	return rmaxx > rminx && rmaxy > rminy;
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));

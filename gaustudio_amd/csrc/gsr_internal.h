@@ -7,23 +7,27 @@ namespace gsr {
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-// geometry buffer: [GsCam][GsRec x P][tiles_touched u32 x P][goff u32 x (P+1)][scan block sums]
+// geometry buffer: [GsCam][GsRec x P][tiles_touched u32 x P][goff u32 x (P+1)][block sums][reference block sums]
 // (replaces GeometryState, rasterizer_impl.h:33-48: depths/clamped/radii/means2D/cov3D/conic_opacity/rgb/
 // point_offsets/tiles_touched/scan space = 79 B/Gaussian in 9 arrays; here one 64-B record, cov3D is recomputed
 // in backward instead of stored).  goff = exclusive scan of tiles_touched (the reference's point_offsets, shifted):
-// the backward's Gaussian-major row index; computed by the forward while the host waits for num_rendered.
-#define GSR_SCAN_BLOCK 2048
+// the backward's Gaussian-major row index.  preprocess_fwd leaves one partial sum per 256-Gaussian block (bsums:
+// binned tiles, refsums: tiles of the reference's getRect squares), tile_scan's second workgroup scans them and
+// goff_apply finishes the scan inside each block -- no separate multi-kernel scan.
+#define GSR_PRE_BLOCK 256
 struct GeomLayout {
-	size_t cam, recs, tiles_touched, goff, bsums, total;
+	size_t cam, recs, tiles_touched, goff, bsums, refsums, total;
+	size_t nblk;
 	explicit GeomLayout(size_t P)
 	{
-		const size_t nb = (P + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
+		nblk = (P + GSR_PRE_BLOCK - 1) / GSR_PRE_BLOCK;
 		cam = 0;
 		recs = align_up(sizeof(GsCam));
 		tiles_touched = recs + align_up(sizeof(GsRec) * P);          // compact u32[P] (0 for culled)
 		goff = tiles_touched + align_up(sizeof(uint32_t) * P);
 		bsums = goff + align_up(sizeof(uint32_t) * (P + 1));
-		total = bsums + align_up(sizeof(uint32_t) * (nb + 1));
+		refsums = bsums + align_up(sizeof(uint32_t) * (nblk + 1));
+		total = refsums + align_up(sizeof(uint32_t) * (nblk + 1));
 	}
 };
 
@@ -78,15 +82,24 @@ struct FwdArgs {
 	int prefiltered;
 	const float* shs_rest;   // f1: SH given as [P,1,3] (shs) + [P,M-1,3] (shs_rest); nullptr = shs holds all M
 	int act;                 // f1: GSR_ACT_* flags
+	int tight;               // 1: bin into the tight rect (gs_tight_rect); 0: the reference's square (A/B, debugging)
 };
 
 // --- launchers (gsr_kernels_fwd.hip) ---
+// `cap`: capacity (instances) of the binning buffer the kernels were launched against; they are enqueued BEFORE the
+// host knows the instance count and leave without touching memory when ctl->num_binned exceeds it (the host then
+// re-allocates and re-launches; gsr_api.hip forward_impl).
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
 void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs,
-                           uint32_t* tiles_touched, uint32_t* tile_count, GsCtl* ctl, hipStream_t s);
-void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, GsCtl* ctl, hipStream_t s);
-void launch_bin_scatter(int P, int gx, const int* radii, const GsRec* recs, const uint2* ranges,
-                        uint32_t* cursor, uint64_t* keys, hipStream_t s);
+                           uint32_t* tiles_touched, uint32_t* bsums, uint32_t* refsums, uint32_t* tile_count,
+                           GsCtl* ctl, hipStream_t s);
+void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, int nblk, uint32_t* bsums, const uint32_t* refsums,
+                      GsCtl* ctl, GsCtl* host_ctl, hipStream_t s);
+void launch_goff_apply(int P, const uint32_t* tiles_touched, const uint32_t* bsums, uint32_t* goff, GsRec* recs,
+                       hipStream_t s);
+void launch_bin_scatter(int P, int gx, const int* radii, const uint32_t* tiles_touched, const GsRec* recs,
+                        const uint2* ranges, uint32_t* cursor, uint64_t* keys, const GsCtl* ctl, uint32_t cap,
+                        hipStream_t s);
 // binning without global atomics (default when the tile grid fits an LDS histogram)
 int bin_chunks(int P);
 size_t bin_hist_bytes(int P, int T);
@@ -94,12 +107,14 @@ bool bin_lds_path_ok(int T);
 void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
                      uint32_t* tile_count, hipStream_t s);
 void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
-                         const uint2* ranges, uint64_t* keys, hipStream_t s);
-void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
-                      uint32_t* point_list, hipStream_t s);
+                         const uint2* ranges, uint64_t* keys, const GsCtl* ctl, uint32_t cap, hipStream_t s);
+// with_long: also launch the long-list (> GSR_SORT_LDS_MAX keys) kernel, which needs the keys2 buffer
+void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
+                      uint32_t* point_list, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, hipStream_t s);
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, const GsCtl* ctl, uint32_t cap,
+                          uint32_t max_sorted, bool nocull, hipStream_t s);
 
 // --- launchers (gsr_kernels_bwd.hip) ---
 struct BwdArgs {
@@ -137,16 +152,21 @@ struct BwdLayout {
 		total = rows + align_up(sizeof(float) * GSR_ROW_STRIDE * (R > 0 ? R : 1));
 	}
 };
-void launch_gaussian_scan(int P, const uint32_t* tiles_touched, uint32_t* goff, uint32_t* bsums, hipStream_t s);
+// variant: 0 = default; other values select A/B variants of the kernel (gsr_set_option("bwd_variant", v))
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
-                          const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
+                          const uint32_t* point_list, const GsRec* recs, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
-                          hipStream_t s);
+                          int variant, hipStream_t s);
+// parts: GSR_PART_GEOM = the per-Gaussian geometry kernel (all P Gaussians); GSR_PART_SH = the SH kernel over
+// the Gaussians [sh_g0, sh_g1) (a multiple-of-256 start; lets a caller interleave a collective per chunk)
+#define GSR_PART_GEOM 1
+#define GSR_PART_SH 2
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
                            const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
-                           float* dL_drot, hipStream_t s);
+                           float* dL_drot, int parts, int sh_g0, int sh_g1, hipStream_t s);
+void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s);
 void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint32_t* goff, const float* rows,
                          const uint8_t* row_flags,
                          float* sums10, hipStream_t s);

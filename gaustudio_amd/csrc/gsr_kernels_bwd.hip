@@ -86,96 +86,6 @@ __device__ __forceinline__ void gs_sum_rows(bool vis, int idx, const GsRec* __re
 	}
 }
 
-// ---- exclusive scan of tiles_touched over Gaussians -> goff[P+1] (goff[P] = R) ----
-// pass 1: block totals; pass 2: one workgroup scans the totals; pass 3: block-local scan + offset.
-__global__ __launch_bounds__(256) void gscan_block_sums_kernel(int P, const uint32_t* __restrict__ v,
-                                                              uint32_t* __restrict__ bsums)
-{
-	__shared__ uint32_t s_w[4];
-	const int base = blockIdx.x * GSR_SCAN_BLOCK;
-	uint32_t sum = 0;
-	for (int i = threadIdx.x; i < GSR_SCAN_BLOCK; i += 256) {
-		const int g = base + i;
-		if (g < P) sum += v[g];
-	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
-	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
-	__syncthreads();
-	if (threadIdx.x == 0) bsums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-__global__ __launch_bounds__(1024) void gscan_top_kernel(int nb, uint32_t* __restrict__ bsums)
-{
-	__shared__ uint32_t s_wave[16];
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const int chunk = (nb + 1023) / 1024;
-	const int b = tid * chunk, e = min(nb, b + chunk);
-	uint32_t sum = 0;
-	for (int i = b; i < e; i++) sum += bsums[i];
-	uint32_t incl = sum;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-		if (lane >= o) incl += t;
-	}
-	if (lane == 63) s_wave[wv] = incl;
-	__syncthreads();
-	uint32_t basev = 0, total = 0;
-	for (int w = 0; w < 16; w++) {
-		if (w < wv) basev += s_wave[w];
-		total += s_wave[w];
-	}
-	uint32_t run = basev + incl - sum;
-	for (int i = b; i < e; i++) {
-		const uint32_t c = bsums[i];
-		bsums[i] = run;
-		run += c;
-	}
-	if (tid == 0) bsums[nb] = total;
-}
-
-__global__ __launch_bounds__(256) void gscan_apply_kernel(int P, const uint32_t* __restrict__ v,
-                                                          const uint32_t* __restrict__ bsums,
-                                                          uint32_t* __restrict__ goff)
-{
-	// each thread owns 8 consecutive elements of the 2048-element block
-	__shared__ uint32_t s_w[4];
-	const int base = blockIdx.x * GSR_SCAN_BLOCK + threadIdx.x * 8;
-	uint32_t x[8];
-	uint32_t sum = 0;
-#pragma unroll
-	for (int i = 0; i < 8; i++) {
-		x[i] = (base + i < P) ? v[base + i] : 0u;
-		sum += x[i];
-	}
-	uint32_t incl = sum;
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-		if (lane >= o) incl += t;
-	}
-	if (lane == 63) s_w[wv] = incl;
-	__syncthreads();
-	uint32_t run = bsums[blockIdx.x] + incl - sum;
-	for (int w = 0; w < wv; w++) run += s_w[w];
-#pragma unroll
-	for (int i = 0; i < 8; i++) {
-		if (base + i < P) goff[base + i] = run;
-		run += x[i];
-	}
-	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) goff[P] = bsums[gridDim.x];
-}
-
-void launch_gaussian_scan(int P, const uint32_t* tiles_touched, uint32_t* goff, uint32_t* bsums, hipStream_t s)
-{
-	const int nb = (P + GSR_SCAN_BLOCK - 1) / GSR_SCAN_BLOCK;
-	hipLaunchKernelGGL(gscan_block_sums_kernel, dim3(nb), dim3(256), 0, s, P, tiles_touched, bsums);
-	hipLaunchKernelGGL(gscan_top_kernel, dim3(1), dim3(1024), 0, s, nb, bsums);
-	hipLaunchKernelGGL(gscan_apply_kernel, dim3(nb), dim3(256), 0, s, P, tiles_touched, bsums, goff);
-}
-
 __global__ __launch_bounds__(256) void inspect_sums_kernel(int P, const int* __restrict__ radii,
                                                            const GsRec* __restrict__ recs,
                                                            const uint32_t* __restrict__ goff,
@@ -200,18 +110,139 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 #define GSR_SG_STRIDE 11
 
 // composite_bwd: ONE workgroup of 2 wave64 per 16x16 tile; wave w owns the 8-wide, 16-tall half tile
-// (columns 8w..8w+7) and every lane owns TWO pixels of it, (x, y) and (x, y+8).  The cross-lane reduction
-// of the ten gradient components costs ~38 VALU instructions per (wave, instance) regardless of how many
-// pixels feed it; with two pixels per lane it is paid once per 128 pixel evaluations and the per-pixel math
-// issues as packed FP32 (the culling box grows from 8x8 to 8x16, a smaller loss).
+// (columns 8w..8w+7) and every lane owns TWO pixels of it, (x, y) and (x, y+8) -- one in each of the wave's two 8x8
+// pixel blocks.  The cross-lane reduction of the ten gradient components costs ~130 VALU cycles per (wave, instance)
+// regardless of how many pixels feed it; with two pixels per lane it is paid once per 128 pixel evaluations and the
+// per-pixel math issues as packed FP32.  Culling is per 8x8 BLOCK (box test + the block's own last-contributor
+// bound): an instance that can only touch one of the wave's two blocks -- half of the surviving pairs at C3 -- is
+// evaluated for that block's 64 pixels alone, with plain FP32 instructions (half the arithmetic of the packed body,
+// the same IEEE operations per pixel, so the result does not depend on which body ran).
 // Pixel state comes from the forward's tile-major arrays: index = (forward wave)*64 + (forward lane).
 #define GSR_BWD_THREADS 128
 #define GSR_BWD_BATCH 128
+
+// ---- arithmetic on one pixel (float) or both pixels of a lane (v2f) with the same source text ----
+struct GsM2 { bool a, b; };
+template <int K> struct GsPix;   // K = 0 / 1: only pixel 0 / 1 of the lane, K = 2: both
+template <> struct GsPix<2> {
+	typedef v2f V;
+	typedef GsM2 M;
+	static __device__ __forceinline__ V get(v2f x) { return x; }
+	static __device__ __forceinline__ void put(v2f& d, V x) { d = x; }
+	static __device__ __forceinline__ V splat(float a) { return v2f{a, a}; }
+	static __device__ __forceinline__ M live(int pos, v2i lc, V power, float pcut, V a0)
+	{
+		// per-pixel predicates stay scalar bools (SGPR lane masks): a select is then ONE v_cndmask
+		// (no short-circuit evaluation: `&` keeps the body free of exec-mask branches)
+		const bool a = (pos < lc.x) & (power.x <= 0.0f) & (power.x >= pcut) & (!(a0.x < 1.0f / 255.0f));
+		const bool b = (pos < lc.y) & (power.y <= 0.0f) & (power.y >= pcut) & (!(a0.y < 1.0f / 255.0f));
+		return GsM2{a, b};
+	}
+	static __device__ __forceinline__ M med(M l, V tT, V T)
+	{
+		const bool a = l.a & (tT.x > 0.5f) & (T.x < 0.5f), b = l.b & (tT.y > 0.5f) & (T.y < 0.5f);
+		return GsM2{a, b};
+	}
+	static __device__ __forceinline__ bool any(M m) { return __ballot(m.a | m.b) != 0ull; }
+	static __device__ __forceinline__ V sel(M m, V a, V b) { return v2f{m.a ? a.x : b.x, m.b ? a.y : b.y}; }
+	static __device__ __forceinline__ float hsum(V a) { return a.x + a.y; }
+	static __device__ __forceinline__ V exp(V p, v2f magic, v2f c5) { return gs_exp2(p, magic, c5); }
+	static __device__ __forceinline__ V min99(V a) { return v2f{fminf(0.99f, a.x), fminf(0.99f, a.y)}; }
+	static __device__ __forceinline__ V rcp(V a) { return v2f{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+	static __device__ __forceinline__ V fma(V a, V b, V c) { return vfma(a, b, c); }
+};
+template <int K> struct GsPix {
+	typedef float V;
+	typedef bool M;
+	static __device__ __forceinline__ V get(v2f x) { return K == 0 ? x.x : x.y; }
+	static __device__ __forceinline__ void put(v2f& d, V x) { if (K == 0) d.x = x; else d.y = x; }
+	static __device__ __forceinline__ V splat(float a) { return a; }
+	static __device__ __forceinline__ M live(int pos, v2i lc, V power, float pcut, V a0)
+	{
+		return (pos < (K == 0 ? lc.x : lc.y)) & (power <= 0.0f) & (power >= pcut) & (!(a0 < 1.0f / 255.0f));
+	}
+	static __device__ __forceinline__ M med(M l, V tT, V T) { return l & (tT > 0.5f) & (T < 0.5f); }
+	static __device__ __forceinline__ bool any(M m) { return __ballot(m) != 0ull; }
+	static __device__ __forceinline__ V sel(M m, V a, V b) { return m ? a : b; }
+	static __device__ __forceinline__ float hsum(V a) { return a; }
+	static __device__ __forceinline__ V exp(V p, v2f, v2f) { return gs_exp(p); }   // the same IEEE operations as one element of gs_exp2
+	static __device__ __forceinline__ V min99(V a) { return fminf(0.99f, a); }
+	static __device__ __forceinline__ V rcp(V a) { return __builtin_amdgcn_rcpf(a); }
+	static __device__ __forceinline__ V fma(V a, V b, V c) { return FMA(a, b, c); }
+};
+
+// per-lane pixel state of composite_bwd (two pixels)
+struct GsBwdPix {
+	v2f T_, S, dLp0, dLp1, dLp2, dLd, dLm, dLo, bg_dot, T_final, pixfy;
+	v2i lc;          // last_contributor (n_contrib of the forward)
+	float pixfx;
+};
+
+// One (wave, instance) pair for the pixels selected by K.  Returns false when no selected pixel is live; otherwise
+// q[0..9] = this lane's contribution to {M10, M01, M20, M11, M02, g5, g6, g7, g8, g9} (see the flush for their meaning).
+// The body is straight-line: a dead pixel is carried through with G masked to 0, which makes every quantity derived
+// from it exactly neutral -- alpha = 0, 1/(1-alpha) = 1 (v_rcp_f32(1.0) == 1.0, checked by gsr_selftest; TSEL keeps
+// a select on T for hardware where it is not), w = 0, q = 0, and S <- fma(0, ., S) = S -- so the only selects left are
+// the two on G (and the median's).  The reference's five back-to-front recurrences accum_rec[ch] (3 colours, depth,
+// opacity; backward.cu:541-573) enter dL_dalpha only through their dot product with the pixel's upstream gradients,
+// and the recurrence is linear: one scalar S = <accum_rec, dL_dpixel> is carried, updated EAGERLY with this
+// Gaussian's alpha (the reference folds `last_alpha`, `last_color` in at the next contributor: the same fma on the
+// same operands one step later, bit-identical).
+template <int K, bool TSEL>
+__device__ __forceinline__ bool gs_bwd_pair(const float4 A, const float4 B, const float4 Cc, const int pos, GsBwdPix& ps,
+                                            const bool any_bg, const v2f k_magic, const v2f k_c5, float* q)
+{
+	typedef GsPix<K> P;
+	typedef typename P::V V;
+	const float dx = A.x - ps.pixfx;
+	const V dy = P::splat(A.y) - P::get(ps.pixfy);
+	const float ax = (A.z * dx) * dx, bxd = A.w * dx;
+	const V power = P::fma(P::splat(bxd), dy, P::fma(P::splat(B.x) * dy, dy, P::splat(ax)));
+	const V G = P::exp(power, k_magic, k_c5);
+	const V a0 = P::splat(B.y) * G;
+	const typename P::M live = P::live(pos, ps.lc, power, B.w, a0);
+	if (!P::any(live)) return false;
+	const V zero = P::splat(0.0f);
+	const V Gm = P::sel(live, G, zero);
+	const V alpha = P::min99(P::splat(B.y) * Gm);
+	// 1/(1-alpha) once, by v_rcp_f32 (1 ulp) instead of two IEEE divisions (backward.cu:536,587): the backward is
+	// tolerance-checked (its sums are order-dependent in the reference as well)
+	const V om = P::splat(1.0f) - alpha;
+	const V rinv = P::rcp(om);
+	const V Told = P::get(ps.T_);
+	const V test_T = Told * rinv;
+	const V w = alpha * test_T;   // dchannel_dcolor = dpixel_depth_ddepth = dpixel_opacity_dopacity
+	// <colour of this Gaussian, dL_dpixel> over the 5 blended channels (rgb, depth, opacity == 1)
+	const V cd = P::fma(P::splat(Cc.x), P::get(ps.dLp0), P::fma(P::splat(Cc.y), P::get(ps.dLp1),
+	             P::fma(P::splat(Cc.z), P::get(ps.dLp2), P::fma(P::splat(B.z), P::get(ps.dLd), P::get(ps.dLo)))));
+	const V Sold = P::get(ps.S);
+	const V diff = cd - Sold;
+	V dL_dalpha = diff * test_T;
+	if (any_bg) {                                                         // backward.cu:584-587
+		asm volatile("");   // not speculated: keeps this a scalar branch instead of compute-always + select
+		dL_dalpha = P::fma(-(P::get(ps.T_final) * rinv), P::get(ps.bg_dot), dL_dalpha);
+	}
+	const V qa = Gm * dL_dalpha;                                          // dL_dG * G / opacity
+	// median-depth gradient (backward.cu:566-569)
+	const typename P::M med = P::med(live, test_T, Told);
+	const V g6v = w * P::get(ps.dLp0), g7v = w * P::get(ps.dLp1), g8v = w * P::get(ps.dLp2);
+	const V g9v = P::fma(w, P::get(ps.dLd), P::sel(med, P::get(ps.dLm), zero));
+	const V g5v = P::fma(w, P::get(ps.dLo), qa);                          // backward.cu:575 + :607
+	// moments of qa over the pixels; the conic / opacity factors are applied once per instance in the flush
+	const V qx = qa * P::splat(dx), qy = qa * dy;
+	const V m20 = qx * P::splat(dx), m11 = qx * dy, m02 = qy * dy;
+	P::put(ps.S, P::fma(alpha, diff, Sold));
+	P::put(ps.T_, TSEL ? P::sel(live, test_T, Told) : test_T);
+	q[0] = P::hsum(qx); q[1] = P::hsum(qy); q[2] = P::hsum(m20); q[3] = P::hsum(m11); q[4] = P::hsum(m02);
+	q[5] = P::hsum(g5v); q[6] = P::hsum(g6v); q[7] = P::hsum(g7v); q[8] = P::hsum(g8v); q[9] = P::hsum(g9v);
+	return true;
+}
+
 // FLAGS: long-list regime (per-row validity bytes); compile-time so that the short-list kernel carries none of it
-template <bool FLAGS>
+template <bool FLAGS, bool TSEL>
 __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
     int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
+    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
     const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags)
@@ -230,50 +261,52 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	const int tx = tile % gx, ty = tile / gx;
 	const int px = tx * GSR_BLOCK_X + (wv << 3) + (lane & 7);
 	const int pyk[2] = {ty * GSR_BLOCK_Y + (lane >> 3), ty * GSR_BLOCK_Y + (lane >> 3) + 8};
-	const float pixfx = (float)px;
-	const v2f pixfy = {(float)pyk[0], (float)pyk[1]};
-	const float bx0 = (float)(tx * GSR_BLOCK_X + (wv << 3)), by0 = (float)(ty * GSR_BLOCK_Y);
-	const float bx1 = fminf(bx0 + 7.f, (float)(W - 1)), by1 = fminf(by0 + 15.f, (float)(H - 1));
+	// the wave's two 8x8 pixel blocks (pixel centres), clipped to the image
+	const float bx0 = (float)(tx * GSR_BLOCK_X + (wv << 3)), bx1 = fminf(bx0 + 7.f, (float)(W - 1));
+	const float by0a = (float)(ty * GSR_BLOCK_Y), by1a = fminf(by0a + 7.f, (float)(H - 1));
+	const float by0b = by0a + 8.f, by1b = fminf(by0a + 15.f, (float)(H - 1));
 	const uint2 range = ranges[tile];
 
-	v2f T_final, T_, dLp0, dLp1, dLp2, dLd, dLm, dLo, bg_dot;
-	v2i last_contributor;
+	GsBwdPix ps;
+	ps.pixfx = (float)px;
+	ps.pixfy = v2f{(float)pyk[0], (float)pyk[1]};
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		const bool inside = px < W && pyk[k] < H;
 		const size_t sidx = (size_t)tile * GSR_TILE_PIX + (size_t)((2 * k + wv) * 64 + lane);   // forward's thread id
-		T_final[k] = inside ? final_T[sidx] : 0.f;
-		last_contributor[k] = inside ? (int)n_contrib[sidx] : 0;
-		dLp0[k] = dLp1[k] = dLp2[k] = dLd[k] = dLm[k] = dLo[k] = 0.f;
+		ps.T_final[k] = inside ? final_T[sidx] : 0.f;
+		ps.lc[k] = inside ? (int)n_contrib[sidx] : 0;
+		ps.dLp0[k] = ps.dLp1[k] = ps.dLp2[k] = ps.dLd[k] = ps.dLm[k] = ps.dLo[k] = 0.f;
 		if (inside) {
 			const size_t HW = (size_t)H * W;
 			const size_t pix_id = (size_t)W * pyk[k] + px;
-			dLp0[k] = dL_dpix[pix_id];
-			dLp1[k] = dL_dpix[HW + pix_id];
-			dLp2[k] = dL_dpix[2 * HW + pix_id];
-			dLd[k] = dL_dpix_depth[pix_id];
-			dLm[k] = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
-			dLo[k] = dL_dpix_opacity[pix_id];
+			ps.dLp0[k] = dL_dpix[pix_id];
+			ps.dLp1[k] = dL_dpix[HW + pix_id];
+			ps.dLp2[k] = dL_dpix[2 * HW + pix_id];
+			ps.dLd[k] = dL_dpix_depth[pix_id];
+			ps.dLm[k] = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
+			ps.dLo[k] = dL_dpix_opacity[pix_id];
 		}
 		// bg . dL_dpixel (backward.cu:584-586), loop invariant
-		bg_dot[k] = FMA(bg[2], dLp2[k], FMA(bg[1], dLp1[k], FMA(bg[0], dLp0[k], 0.f)));
+		ps.bg_dot[k] = FMA(bg[2], ps.dLp2[k], FMA(bg[1], ps.dLp1[k], FMA(bg[0], ps.dLp0[k], 0.f)));
 	}
-	T_ = T_final;
+	ps.T_ = ps.T_final;
+	ps.S = v2f{0.f, 0.f};
 	// wave-uniform: with a black background (the common case) the term is skipped by a scalar branch; a per-lane
 	// condition had the compiler evaluate it always and select (4 VALU per pair).  fma(x, 0, y) == y keeps lanes
 	// without a contribution exact when another lane of the wave has one.
-	const bool any_bg = __ballot(bg_dot.x != 0.f || bg_dot.y != 0.f) != 0ull;
+	const bool any_bg = __ballot(ps.bg_dot.x != 0.f || ps.bg_dot.y != 0.f) != 0ull;
 
-	// The reference carries five back-to-front recurrences accum_rec[ch] (3 colours, depth, opacity;
-	// backward.cu:541-573) but dL_dalpha only needs their dot product with this pixel's upstream
-	// gradients, and the recurrence is linear: we carry that one scalar, S = <accum_rec, dL_dpixel>.
-	v2f S = {0.f, 0.f}, last_cd = {0.f, 0.f}, last_alpha = {0.f, 0.f};
-
-	// wave / workgroup max of last_contributor: list entries at or beyond it are dead for every pixel
-	int wmax = max(last_contributor.x, last_contributor.y);
+	// per 8x8 block: max of last_contributor -- list entries at or beyond it are dead for every pixel of the block
+	int wmax0 = ps.lc.x, wmax1 = ps.lc.y;
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
-	if (lane == 0) s_max[wv] = wmax;
+	for (int o = 32; o > 0; o >>= 1) {
+		wmax0 = max(wmax0, __shfl_xor(wmax0, o, 64));
+		wmax1 = max(wmax1, __shfl_xor(wmax1, o, 64));
+	}
+	wmax0 = __builtin_amdgcn_readfirstlane(wmax0);
+	wmax1 = __builtin_amdgcn_readfirstlane(wmax1);
+	if (lane == 0) s_max[wv] = max(wmax0, wmax1);
 	__syncthreads();
 	const int bmax = max(s_max[0], s_max[1]);
 
@@ -288,7 +321,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		const uint32_t id = point_list[range.x + i];
 		const uint4 q3 = recs[id].q3;
 		const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
-		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx))) * GSR_ROW_STRIDE);
+		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(q3.w + (uint32_t)((ty - rminy) * rw + (tx - rminx))) * GSR_ROW_STRIDE);
 		dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -298,11 +331,10 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	GS_EXP2_CONSTANTS(k_magic, k_c5);
 	for (int top = bmax; top > 0; top -= GSR_BWD_BATCH) {
 		const int cnt = min(GSR_BWD_BATCH, top);
-		uint32_t my_row[GSR_BWD_BATCH / GSR_BWD_THREADS] = {0u};
+		uint32_t my_row = 0u;
 		__syncthreads();
-#pragma unroll
-		for (int h = 0; h < GSR_BWD_BATCH / GSR_BWD_THREADS; h++) {
-			const int st = tid + h * GSR_BWD_THREADS;
+		{
+			const int st = tid;
 			if (st < cnt) {
 				const uint32_t id = point_list[range.x + (top - 1 - st)];
 				const GsRec* r = recs + id;
@@ -311,85 +343,50 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				float4 c = r->q2;
 				c.w = __int_as_float((int)id);
 				sC[st] = c;
-				// Gaussian-major row of this (tile, Gaussian) instance: goff[g] + raster index of the tile
-				// inside the Gaussian's tile rect (same 64-B record, no extra sector)
+				// Gaussian-major row of this (tile, Gaussian) instance: goff[g] (carried in the record) + raster index
+				// of the tile inside the Gaussian's tile rect -- the 64-B record is the only thing gathered
 				const uint4 q3 = r->q3;
 				const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
-				my_row[h] = goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx));
+				my_row = q3.w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
 			}
 #pragma unroll
 			for (int k = 0; k < 10; k++) sG[st * GSR_SG_STRIDE + k] = 0.f;
 		}
 		__syncthreads();
-		// per-wave cull of the staged batch, 64 instances per ballot (see composite_fwd)
+		// per-wave, per-block cull of the staged batch, 64 instances per ballot (see composite_fwd)
 		for (int sub = 0; sub < cnt; sub += 64) {
 			const int jl = sub + lane;
-			bool hit = false;
-			if ((jl < cnt) & (top - 1 - jl < wmax)) hit = gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
-			unsigned long long m = __ballot(hit);
+			bool hit0 = false, hit1 = false;
+			if (jl < cnt) {
+				const int p = top - 1 - jl;
+				const float4 a = sA[jl], b = sB[jl];
+				if (p < wmax0) hit0 = gs_box_may_touch(a, b, bx0, by0a, bx1, by1a);
+				if (p < wmax1) hit1 = gs_box_may_touch(a, b, bx0, by0b, bx1, by1b);
+			}
+			const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+			unsigned long long m = m0 | m1;
 			while (m) {
-				const int j = sub + __ffsll((long long)m) - 1;
+				const int bit = __ffsll((long long)m) - 1;
 				m &= m - 1;
+				const int j = sub + bit;
 				const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
 				const float4 A = sA[j];
 				const float4 B = sB[j];
 				const float4 Cc = sC[j];
-				// Both pixels of the lane are evaluated together as 2-vectors so that the arithmetic maps onto
-				// packed FP32 instructions (v_pk_fma/mul/add_f32: two results per 4-cycle VALU slot), and the
-				// body is straight-line: dead pixels are masked by zeroing their weights (w, qa), not by
-				// branching -- in a hit block about half of the pixels are live, a branch would never be skipped.
-				const float dx = A.x - pixfx;
-				const v2f dy = v2f{A.y, A.y} - pixfy;
-				const float ax = (A.z * dx) * dx, bxd = A.w * dx;
-				const v2f power = vfma(v2f{bxd, bxd}, dy, vfma(B.x * dy, dy, v2f{ax, ax}));
-				const v2f G = gs_exp2(power, k_magic, k_c5);
-				const v2f alpha = v2f{fminf(0.99f, B.y * G.x), fminf(0.99f, B.y * G.y)};
-				// per-pixel predicates stay scalar bools (SGPR lane masks): a select is then ONE v_cndmask
-				// (no short-circuit evaluation: `&` keeps the body free of exec-mask branches)
-				const bool live0 = (pos < last_contributor.x) & (power.x <= 0.0f) & (power.x >= B.w) & (!(alpha.x < 1.0f / 255.0f));
-				const bool live1 = (pos < last_contributor.y) & (power.y <= 0.0f) & (power.y >= B.w) & (!(alpha.y < 1.0f / 255.0f));
-				if (__ballot(live0 | live1) == 0ull) continue;
-#define SEL2(c0, c1, a, b) v2f{(c0) ? (a).x : (b).x, (c1) ? (a).y : (b).y}
-				const v2f zero2 = {0.f, 0.f};
-				// 1/(1-alpha) once, by v_rcp_f32 (1 ulp) instead of two IEEE divisions (backward.cu:536,587): the
-				// backward is tolerance-checked (its sums are order-dependent in the reference as well)
-				const v2f om = 1.f - alpha;
-				const v2f rinv = v2f{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-				const v2f test_T = T_ * rinv;
-				const v2f aT = alpha * test_T;
-				const v2f w = SEL2(live0, live1, aT, zero2);   // dchannel_dcolor = dpixel_depth_ddepth = ...
-				// <colour of this Gaussian, dL_dpixel> over the 5 blended channels (rgb, depth, opacity == 1)
-				const v2f cd = vfma(v2f{Cc.x, Cc.x}, dLp0, vfma(v2f{Cc.y, Cc.y}, dLp1,
-				                    vfma(v2f{Cc.z, Cc.z}, dLp2, vfma(v2f{B.z, B.z}, dLd, dLo))));
-				const v2f Sn = vfma(last_alpha, last_cd - S, S);
-				v2f dL_dalpha = (cd - Sn) * test_T;
-				if (any_bg) {                                                         // backward.cu:584-587
-					asm volatile("");   // not speculated: keeps this a scalar branch instead of compute-always + select
-					dL_dalpha = vfma(-(T_final * rinv), bg_dot, dL_dalpha);
-				}
-				const v2f gq = G * dL_dalpha;
-				const v2f qa = SEL2(live0, live1, gq, zero2);                         // dL_dG * G / opacity
-				// median-depth gradient (backward.cu:566-569)
-				const bool med0 = live0 & (test_T.x > 0.5f) & (T_.x < 0.5f), med1 = live1 & (test_T.y > 0.5f) & (T_.y < 0.5f);
-				const v2f g6v = w * dLp0, g7v = w * dLp1, g8v = w * dLp2;
-				const v2f g9v = vfma(w, dLd, SEL2(med0, med1, dLm, zero2));
-				const v2f g5v = vfma(w, dLo, qa);                                     // backward.cu:575 + :607
-				// moments of qa over the pixels; the conic / opacity factors are applied once per instance in the flush
-				const v2f qx = qa * dx, qy = qa * dy;
-				const v2f m20 = qx * dx, m11 = qx * dy, m02 = qy * dy;
-				S = SEL2(live0, live1, Sn, S);
-				last_cd = SEL2(live0, live1, cd, last_cd);
-				T_ = SEL2(live0, live1, test_T, T_);
-				last_alpha = SEL2(live0, live1, alpha, last_alpha);
-#undef SEL2
-				// ten per-lane quantities (two pixels each) -> three registers whose 16-lane rows carry different
-				// quantities -> within-row sums.  Row r of s0 / s1 / s2 holds component {0,2,1,3}[r] / 4+{0,2,1,3}[r] /
-				// {8,-,9,-}[r].
-				const float r0 = half_swap_sum(qx.x + qx.y, qy.x + qy.y);      // [M10 | M01]
-				const float r1 = half_swap_sum(m20.x + m20.y, m11.x + m11.y);  // [M20 | M11]
-				const float r2 = half_swap_sum(m02.x + m02.y, g5v.x + g5v.y);  // [M02 | g5 ]
-				const float r3 = half_swap_sum(g6v.x + g6v.y, g7v.x + g7v.y);  // [g6  | g7 ]
-				const float r4 = half_swap_sum(g8v.x + g8v.y, g9v.x + g9v.y);  // [g8  | g9 ]
+				const bool in0 = (m0 >> bit) & 1ull, in1 = (m1 >> bit) & 1ull;   // wave-uniform
+				float q[10];
+				bool any_live;
+				if (in0 && in1) any_live = gs_bwd_pair<2, TSEL>(A, B, Cc, pos, ps, any_bg, k_magic, k_c5, q);
+				else if (in0) any_live = gs_bwd_pair<0, TSEL>(A, B, Cc, pos, ps, any_bg, k_magic, k_c5, q);
+				else any_live = gs_bwd_pair<1, TSEL>(A, B, Cc, pos, ps, any_bg, k_magic, k_c5, q);
+				if (!any_live) continue;
+				// ten per-lane quantities -> three registers whose 16-lane rows carry different quantities ->
+				// within-row sums.  Row r of s0 / s1 / s2 holds component {0,2,1,3}[r] / 4+{0,2,1,3}[r] / {8,-,9,-}[r].
+				const float r0 = half_swap_sum(q[0], q[1]);   // [M10 | M01]
+				const float r1 = half_swap_sum(q[2], q[3]);   // [M20 | M11]
+				const float r2 = half_swap_sum(q[4], q[5]);   // [M02 | g5 ]
+				const float r3 = half_swap_sum(q[6], q[7]);   // [g6  | g7 ]
+				const float r4 = half_swap_sum(q[8], q[9]);   // [g8  | g9 ]
 				float s0 = row_swap_sum(r0, r1), s1 = row_swap_sum(r2, r3), s2 = row_swap_sum(r4, 0.f);
 				row_sum16x3(s0, s1, s2);
 				asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2));   // keep the last DPP step a fused v_add_f32_dpp (it was split into mov_dpp + add and sunk into the branch)
@@ -407,49 +404,66 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		// flush: one thread per staged instance stores its 48-B row (plain stores, no global atomics), zeros
 		// included: every row of the scratch is written exactly once per backward, so nobody has to clear it
 		__syncthreads();
-#pragma unroll
-		for (int h = 0; h < GSR_BWD_BATCH / GSR_BWD_THREADS; h++) {
-			const int st = tid + h * GSR_BWD_THREADS;
+		{
+			const int st = tid;
 			if (st < cnt) {
 				float v[10];
 #pragma unroll
 				for (int k = 0; k < 10; k++) v[k] = sG[st * GSR_SG_STRIDE + k];
-				{
-					// moments -> gradients (once per (tile, Gaussian)): with q = G*dL_dalpha summed over pixels,
-					//   dL_dmean2D.x = -0.5W * op * (a*M10 + b*M01)      (backward.cu:593-599)
-					//   dL_dconic    = -0.5 * op * (M20, M11, M02)       (backward.cu:602-604)
-					// where conic (a, b, c) = (-2*q0.z, -q0.w, -2*q1.x), op = q1.y
-					const float4 A = sA[st], B = sB[st];
-					const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x, op = B.y;
-					const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[4];
-					const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
-					float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row[h] * GSR_ROW_STRIDE);
-					dst[0] = make_float4(-(op * FMA(cb, M01, ca * M10)) * ddelx_dx, -(op * FMA(cb, M10, cc * M01)) * ddely_dy,
-					                     -0.5f * op * M20, -0.5f * op * M11);
-					dst[1] = make_float4(-0.5f * op * M02, v[5], v[6], v[7]);
-					dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
-					if (FLAGS) row_flags[my_row[h]] = 1;
-				}
+				// moments -> gradients (once per (tile, Gaussian)): with q = G*dL_dalpha summed over pixels,
+				//   dL_dmean2D.x = -0.5W * op * (a*M10 + b*M01)      (backward.cu:593-599)
+				//   dL_dconic    = -0.5 * op * (M20, M11, M02)       (backward.cu:602-604)
+				// where conic (a, b, c) = (-2*q0.z, -q0.w, -2*q1.x), op = q1.y
+				const float4 A = sA[st], B = sB[st];
+				const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x, op = B.y;
+				const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[4];
+				const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
+				float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row * GSR_ROW_STRIDE);
+				dst[0] = make_float4(-(op * FMA(cb, M01, ca * M10)) * ddelx_dx, -(op * FMA(cb, M10, cc * M01)) * ddely_dy,
+				                     -0.5f * op * M20, -0.5f * op * M11);
+				dst[1] = make_float4(-0.5f * op * M02, v[5], v[6], v[7]);
+				dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
+				if (FLAGS) row_flags[my_row] = 1;
 			}
 		}
 	}
 }
 
+// v_rcp_f32(1.0) == 1.0 (and a few neighbours behave): composite_bwd relies on it to carry dead pixels through
+// without a select on T (TSEL = false).  Checked once per process by gsr_selftest; a failing device gets TSEL = true.
+__global__ void bwd_selftest_kernel(const float* __restrict__ in, uint32_t* __restrict__ out)
+{
+	const float one = in[0];                       // runtime 1.0f: not folded by the compiler
+	const float r = __builtin_amdgcn_rcpf(one - in[1]);   // in[1] = 0.0f
+	uint32_t ok = (__float_as_uint(r) == 0x3f800000u) ? 1u : 0u;
+	const float t = 0.37f * in[0];
+	if (t * r == t) ok |= 2u;
+	out[0] = ok;
+	out[1] = __float_as_uint(r);
+}
+void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s)
+{
+	hipLaunchKernelGGL(bwd_selftest_kernel, dim3(1), dim3(1), 0, s, in, out);
+}
+
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
-                          const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
+                          const uint32_t* point_list, const GsRec* recs, const float* final_T,
                           const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
-                          hipStream_t s)
+                          int variant, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
-	if (row_flags != nullptr)
-		hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg,
-		                   ranges, point_list, recs, goff, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
-		                   dL_dpix_opacity, rows, row_flags);
-	else
-		hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg,
-		                   ranges, point_list, recs, goff, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,
-		                   dL_dpix_opacity, rows, row_flags);
+	const bool tsel = (variant & 1) != 0;
+#define GSR_LAUNCH_CB(FL, TS)                                                                                      \
+	hipLaunchKernelGGL((composite_bwd_kernel<FL, TS>), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, \
+	                   bg, ranges, point_list, recs, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,      \
+	                   dL_dpix_opacity, rows, row_flags)
+	if (row_flags != nullptr) {
+		if (tsel) GSR_LAUNCH_CB(true, true); else GSR_LAUNCH_CB(true, false);
+	} else {
+		if (tsel) GSR_LAUNCH_CB(false, true); else GSR_LAUNCH_CB(false, false);
+	}
+#undef GSR_LAUNCH_CB
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,7 +775,7 @@ __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __re
 // 16-B aligned; every global access is then a full 1 KiB-per-instruction stream.  Same arithmetic, same results.
 template <int D, bool SPLIT>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
-    int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
+    int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, const GsRec* __restrict__ recs,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_rest)
@@ -770,9 +784,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 	constexpr int NC = (D + 1) * (D + 1);
 	constexpr int RF = SPLIT ? (NC - 1) * 3 : NC * 3;   // floats per staged row
 	constexpr int RFA = RF > 0 ? RF : 1;
-	const int idx = blockIdx.x * 256 + threadIdx.x;
+	// this launch covers the Gaussians [g_base, P): g_base is a multiple of 256 (16-B aligned row chunks)
+	const int idx = g_base + blockIdx.x * 256 + threadIdx.x;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const int g0 = blockIdx.x * 256 + wv * 64;
+	const int g0 = g_base + blockIdx.x * 256 + wv * 64;
 	const int nrows = min(64, P - g0);
 	if (nrows <= 0) return;   // wave-uniform
 	const bool vis = idx < P && radii[idx] > 0;
@@ -827,12 +842,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 
 template <int D, bool SPLIT>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
-    int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
+    int g_base, int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_rest)
 {
-	const int idx = blockIdx.x * 256 + threadIdx.x;
+	const int idx = g_base + blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
 	constexpr int NC = (D + 1) * (D + 1);
 	const bool vis = radii[idx] > 0;
@@ -898,7 +913,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
                            const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
-                           float* dL_drot, hipStream_t s)
+                           float* dL_drot, int parts, int sh_g0, int sh_g1, hipStream_t s)
 {
 	const float h_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:391-392
 	const float h_x = a.W / (2.0f * a.tan_fovx);
@@ -911,11 +926,20 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
 	                   h_y, sh_vec4, a.act, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
 	                   dL_drot)
-	if (row_flags != nullptr) { GSR_LAUNCH_PB(0, true); } else { GSR_LAUNCH_PB(0, false); }
+	if (parts & GSR_PART_GEOM) {
+		if (row_flags != nullptr) { GSR_LAUNCH_PB(0, true); } else { GSR_LAUNCH_PB(0, false); }
+	}
 #undef GSR_LAUNCH_PB
+	if (!(parts & GSR_PART_SH)) return;
+	// the SH part over the Gaussians [sh_g0, sh_g1)
+	sh_g0 = max(0, sh_g0);
+	sh_g1 = min(a.P, sh_g1);
+	if (sh_g1 <= sh_g0) return;
+	const int sh_end = sh_g1;
+	grid = dim3((sh_g1 - sh_g0 + 255) / 256);
 	if (a.shs != nullptr) {
 #define GSR_LAUNCH_SH(DEG)                                                                                       \
-	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT>), grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, \
+	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT>), grid, block, 0, s, sh_g0, sh_end, a.M, a.means3D, a.radii, a.shs, \
 	                   a.shs_rest, cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
 #define GSR_LAUNCH_SH_D()                        \
 		switch (a.D) {                            \
@@ -929,11 +953,11 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 		const int NCd = (a.D + 1) * (a.D + 1);
 		const float* stream_in = split ? a.shs_rest : a.shs;
 		const float* stream_out = split ? dL_dsh_rest : dL_dsh;
-		const bool coop = a.M == NCd && ((uintptr_t)stream_in % 16 == 0) && ((uintptr_t)stream_out % 16 == 0) &&
+		const bool coop = a.M == NCd && (sh_g0 % 256 == 0) && ((uintptr_t)stream_in % 16 == 0) && ((uintptr_t)stream_out % 16 == 0) &&
 		                  (!split || NCd == 1 || (stream_in != nullptr && stream_out != nullptr));
 #define GSR_LAUNCH_SHC(DEG, SPL)                                                                                  \
 	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL>), grid, block,                                       \
-	                   sizeof(float) * 256 * (SPL ? ((DEG + 1) * (DEG + 1) - 1) * 3 : (DEG + 1) * (DEG + 1) * 3), s, a.P, \
+	                   sizeof(float) * 256 * (SPL ? ((DEG + 1) * (DEG + 1) - 1) * 3 : (DEG + 1) * (DEG + 1) * 3), s, sh_g0, sh_end, \
 	                   a.means3D, a.radii, a.shs, a.shs_rest, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
 		if (coop && split) {
 			switch (a.D) {
@@ -960,7 +984,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 #undef GSR_LAUNCH_SH_D
 #undef GSR_LAUNCH_SH
 	} else if (dL_dsh != nullptr && a.M > 0) {
-		(void)hipMemsetAsync(dL_dsh, 0, sizeof(float) * 3 * (size_t)a.M * (size_t)a.P, s);
+		(void)hipMemsetAsync(dL_dsh + (size_t)sh_g0 * 3 * a.M, 0, sizeof(float) * 3 * (size_t)a.M * (size_t)(sh_g1 - sh_g0), s);
 	}
 }
 

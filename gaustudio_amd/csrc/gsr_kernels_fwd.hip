@@ -132,14 +132,16 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, int act_arg, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const GsCam* __restrict__ cam, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-    int gx, int gy, int prefiltered, int sh_vec4, int* __restrict__ radii, GsRec* __restrict__ recs,
-    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count, GsCtl* __restrict__ ctl)
+    int gx, int gy, int prefiltered, int sh_vec4, int tight, int* __restrict__ radii, GsRec* __restrict__ recs,
+    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ bsums, uint32_t* __restrict__ refsums,
+    uint32_t* __restrict__ tile_count, GsCtl* __restrict__ ctl)
 {
 	constexpr int NC = (D + 1) * (D + 1);
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	const int act = RAW ? act_arg : 0;
 	bool vis = false;
 	int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+	uint32_t ref_tiles = 0;   // area of the reference's getRect square: what the reference calls tiles_touched
 	int mr = 0;
 	float3 p_orig = {0.f, 0.f, 0.f};
 	float pix_x = 0.f, pix_y = 0.f, conic_x = 0.f, conic_y = 0.f, conic_z = 0.f, depth = 0.f, op_raw = 0.f;
@@ -220,12 +222,14 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 			rmaxx = min(gx, max(0, (int)((pix_x + r_ + GSR_BLOCK_X - 1) / GSR_BLOCK_X)));
 			rmaxy = min(gy, max(0, (int)((pix_y + r_ + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y)));
 			if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
+			ref_tiles = (uint32_t)((rmaxx - rminx) * (rmaxy - rminy));
 			mr = r_;
 			depth = p_view.z;
 			vis = true;
 		} while (0);
 	}
 
+	uint32_t my_tiles = 0;
 	if (vis) {
 		float rgb[3];
 		uint32_t clamped = 0;
@@ -237,6 +241,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 			rgb[2] = colors_precomp[3 * (size_t)idx + 2];
 		}
 		const float op = gs_act_opacity(op_raw, act);
+		// bin into the tight sub-rect of the reference's square (radii and the reported num_rendered keep the
+		// reference's definition); a Gaussian that cannot reach alpha >= 1/255 anywhere is binned nowhere
+		if (tight && !gs_tight_rect(pix_x, pix_y, conic_x, conic_y, conic_z, op, gx, gy, rminx, rminy, rmaxx, rmaxy))
+			rminx = rminy = rmaxx = rmaxy = 0;
+		my_tiles = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
 		// pcut: power < pcut  ==>  op*exp(power) < 1/255 with a 1e-3 margin, so skipping the pair is
 		// bit-identical to evaluating it and failing `alpha < 1/255` (forward.cu:346).  Clamped to the
 		// domain of gs_exp.  op <= 0 -> +inf (always skipped); NaN -> -80 (never skipped by pcut).
@@ -246,22 +255,40 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 		rec.q1 = make_float4(-0.5f * conic_z, op, depth, pcut);
 		rec.q2 = make_float4(rgb[0], rgb[1], rgb[2], __int_as_float(mr));
 		rec.q3 = make_uint4((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16),
-		                    clamped, (uint32_t)((rmaxy - rminy) * (rmaxx - rminx)));
+		                    clamped, 0u);   // .w = goff, patched by goff_apply_kernel
 		recs[idx] = rec;
 	}
 	if (idx < P) {
 		radii[idx] = vis ? mr : 0;
-		tiles_touched[idx] = vis ? (uint32_t)((rmaxy - rminy) * (rmaxx - rminx)) : 0u;
+		tiles_touched[idx] = my_tiles;
+	}
+	// per-block partial sums of the binned and of the reference-defined tile counts (scanned by tile_scan's second
+	// workgroup): the Gaussian-major row offsets of the backward and the reference's num_rendered
+	{
+		__shared__ uint32_t s_sum[2][4];
+		uint32_t a = my_tiles, b = ref_tiles;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			a += (uint32_t)__shfl_xor((int)a, o, 64);
+			b += (uint32_t)__shfl_xor((int)b, o, 64);
+		}
+		if ((threadIdx.x & 63) == 0) { s_sum[0][threadIdx.x >> 6] = a; s_sum[1][threadIdx.x >> 6] = b; }
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			bsums[blockIdx.x] = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
+			refsums[blockIdx.x] = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
+		}
 	}
 	// fallback binning only (tile grids too large for the LDS histogram): count instances per tile with
 	// device-scope atomics.  The default path counts in bin_hist_kernel without global atomics.
 	if (tile_count != nullptr)
-		for_each_tile(vis, rminx, rminy, rmaxx, rmaxy, 0u, 0u,
+		for_each_tile(my_tiles > 0, rminx, rminy, rmaxx, rmaxy, 0u, 0u,
 		              [&](int x, int y, uint32_t, uint32_t) { atomicAdd(&tile_count[y * gx + x], 1u); });
 }
 
 void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs,
-                           uint32_t* tiles_touched, uint32_t* tile_count, GsCtl* ctl, hipStream_t s)
+                           uint32_t* tiles_touched, uint32_t* bsums, uint32_t* refsums, uint32_t* tile_count,
+                           GsCtl* ctl, hipStream_t s)
 {
 	const float focal_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:225-226
 	const float focal_x = a.W / (2.0f * a.tan_fovx);
@@ -272,7 +299,7 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 	hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, RAW>), grid, block, 0, s, a.P, a.M, a.means3D, a.scales,        \
 	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.shs_rest, a.act, a.cov3D_precomp,       \
 	                   a.colors_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, focal_x, focal_y, il.gx, il.gy,     \
-	                   a.prefiltered, sh_vec4, radii, recs, tiles_touched, tile_count, ctl)
+	                   a.prefiltered, sh_vec4, a.tight, radii, recs, tiles_touched, bsums, refsums, tile_count, ctl)
 #define GSR_LAUNCH_PRE_D(RAW)                          \
 	switch (D) {                                       \
 		case 0: GSR_LAUNCH_PRE(0, RAW); break;         \
@@ -287,17 +314,82 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exclusive scan over T tile counts by one 1024-thread workgroup; also resets the counters so
-// that bin_scatter can reuse them as per-tile cursors.
+// tile_scan: two 1024-thread workgroups.
+//   block 0: exclusive scan over the T tile counts -> per-tile [start, end) ranges and the number of binned
+//            instances (replaces identifyTileRanges + the InclusiveSum total); also resets the counters so that the
+//            atomic-fallback bin_scatter can reuse them as per-tile cursors;
+//   block 1: exclusive scan (in place) of the per-256-Gaussian block sums left by preprocess_fwd -> base row offset
+//            of every block (goff_apply finishes the scan), and the sum of the reference-defined tile counts = the
+//            reference's num_rendered (rasterizer_impl.cu:280-284).
+// Both mirror their control words into pinned host memory (host_ctl): the host reads them after an event wait
+// without a copy command sitting in the stream.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(v, o, 64);
+		if (lane >= o) v += t;
+	}
+	return v;
+}
+
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __restrict__ tile_count,
-                                                         uint2* __restrict__ ranges, GsCtl* __restrict__ ctl)
+                                                         uint2* __restrict__ ranges, int nblk,
+                                                         uint32_t* __restrict__ bsums,
+                                                         const uint32_t* __restrict__ refsums,
+                                                         GsCtl* __restrict__ ctl, GsCtl* __restrict__ host_ctl)
 {
 	__shared__ uint32_t s_wave[16];
 	__shared__ uint32_t s_max[16];
 	__shared__ uint64_t s_wave64[16];
 	const int tid = threadIdx.x;
+	const int lane = tid & 63, wv = tid >> 6;
+	if (blockIdx.x == 1) {
+		const int chunk = (nblk + 1023) / 1024;
+		const int b = min(nblk, tid * chunk), e = min(nblk, b + chunk);
+		uint32_t sum = 0;
+		uint64_t rsum = 0;
+#pragma unroll 4
+		for (int i = b; i < e; i++) {
+			sum += bsums[i];
+			rsum += refsums[i];
+		}
+		const uint32_t incl = wave_incl_scan(sum, lane);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) rsum += (uint64_t)__shfl_xor((long long)rsum, o, 64);
+		if (lane == 63) s_wave[wv] = incl;
+		if (lane == 0) s_wave64[wv] = rsum;
+		__syncthreads();
+		uint32_t base = 0, total = 0;
+		uint64_t rtotal = 0;
+		for (int w = 0; w < 16; w++) {
+			if (w < wv) base += s_wave[w];
+			total += s_wave[w];
+			rtotal += s_wave64[w];
+		}
+		uint32_t run = base + incl - sum;
+#pragma unroll 4
+		for (int i = b; i < e; i++) {
+			const uint32_t c = bsums[i];
+			bsums[i] = run;
+			run += c;
+		}
+		if (tid == 0) {
+			bsums[nblk] = total;
+			const uint32_t ovf = rtotal > 0x7fffffffull ? 1u : 0u;   // the reference returns an int
+			ctl->ref_rendered = (uint32_t)rtotal;
+			ctl->err_overflow = ovf;
+			if (host_ctl) {
+				host_ctl->ref_rendered = (uint32_t)rtotal;
+				host_ctl->err_overflow = ovf;
+				host_ctl->err_prefiltered = ctl->err_prefiltered;   // set by preprocess_fwd, an earlier kernel
+				__threadfence_system();
+			}
+		}
+		return;
+	}
 	const int chunk = (T + 1023) / 1024;
-	const int b = tid * chunk, e = min(T, b + chunk);
+	const int b = min(T, tid * chunk), e = min(T, b + chunk);
 	uint32_t sum = 0, mx = 0;
 #pragma unroll 8
 	for (int i = b; i < e; i++) {   // (unrolled: eight independent loads in flight; 32 serial round trips took 59 us at 4K)
@@ -306,13 +398,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
 		mx = max(mx, c);
 	}
 	// inclusive scan across the wave, then across the 16 waves
-	uint32_t incl = sum;
-	const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t v = __shfl_up(incl, o, 64);
-		if (lane >= o) incl += v;
-	}
+	const uint32_t incl = wave_incl_scan(sum, lane);
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
 	uint64_t wsum = sum;
@@ -322,13 +408,16 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
 	if (lane == 0) { s_max[wv] = mx; s_wave64[wv] = wsum; }
 	__syncthreads();
 	uint32_t base = 0, total = 0, gmax = 0;
-	uint64_t total64 = 0;                      // the u32 scan wraps past 2^32 instances; the host rejects > 2^31 - 1
+	uint64_t total64 = 0;
 	for (int w = 0; w < 16; w++) {
 		if (w < wv) base += s_wave[w];
 		total += s_wave[w];
 		total64 += s_wave64[w];
 		gmax = max(gmax, s_max[w]);
 	}
+	// the u32 scan wraps past 2^32 instances (the host rejects the frame: the reference count is at least as large);
+	// report a count no capacity can hold so that every kernel enqueued ahead of the host's check leaves at once
+	if (total64 > 0x7fffffffull) total = 0xffffffffu;
 	uint32_t run = base + incl - sum;
 #pragma unroll 8
 	for (int i = b; i < e; i++) {
@@ -338,29 +427,67 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
 		tile_count[i] = 0;
 	}
 	if (tid == 0) {
-		ctl->num_rendered = total;
+		ctl->num_binned = total;           // <= the reference count, whose overflow block 1 checks
 		ctl->max_tile_count = gmax;
-		ctl->err_overflow = total64 > 0x7fffffffull ? 1u : 0u;
+		if (host_ctl) {
+			host_ctl->num_binned = total;
+			host_ctl->max_tile_count = gmax;
+			__threadfence_system();
+		}
 	}
 }
 
-void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, GsCtl* ctl, hipStream_t s)
+void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, int nblk, uint32_t* bsums, const uint32_t* refsums,
+                      GsCtl* ctl, GsCtl* host_ctl, hipStream_t s)
 {
-	hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, T, tile_count, ranges, ctl);
+	hipLaunchKernelGGL(tile_scan_kernel, dim3(2), dim3(1024), 0, s, T, tile_count, ranges, nblk, bsums, refsums, ctl,
+	                   host_ctl);
+}
+
+// goff[g] = bsums[block of g] + exclusive scan of tiles_touched inside the 256-Gaussian block; also written into the
+// record (q3.w) so that composite_bwd finds a Gaussian's first row in the 64-B record it gathers anyway.
+__global__ __launch_bounds__(GSR_PRE_BLOCK) void goff_apply_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+                                                                   const uint32_t* __restrict__ bsums,
+                                                                   uint32_t* __restrict__ goff, GsRec* __restrict__ recs)
+{
+	__shared__ uint32_t s_w[4];
+	const int idx = blockIdx.x * GSR_PRE_BLOCK + threadIdx.x;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const uint32_t v = idx < P ? tiles_touched[idx] : 0u;
+	const uint32_t incl = wave_incl_scan(v, lane);
+	if (lane == 63) s_w[wv] = incl;
+	__syncthreads();
+	uint32_t run = bsums[blockIdx.x] + incl - v;
+	for (int w = 0; w < wv; w++) run += s_w[w];
+	if (idx < P) {
+		goff[idx] = run;
+		if (v > 0) reinterpret_cast<uint32_t*>(recs + idx)[15] = run;   // GsRec::q3.w
+		if (idx == P - 1) goff[P] = run + v;
+	}
+}
+
+void launch_goff_apply(int P, const uint32_t* tiles_touched, const uint32_t* bsums, uint32_t* goff, GsRec* recs,
+                       hipStream_t s)
+{
+	hipLaunchKernelGGL(goff_apply_kernel, dim3((P + GSR_PRE_BLOCK - 1) / GSR_PRE_BLOCK), dim3(GSR_PRE_BLOCK), 0, s, P,
+	                   tiles_touched, bsums, goff, recs);
 }
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const int* __restrict__ radii,
+                                                          const uint32_t* __restrict__ tiles_touched,
                                                           const GsRec* __restrict__ recs,
                                                           const uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ cursor,
-                                                          uint64_t* __restrict__ keys)
+                                                          uint64_t* __restrict__ keys, const GsCtl* __restrict__ ctl,
+                                                          uint32_t cap)
 {
+	if (ctl->num_binned > cap) return;   // launched ahead of the host's read-back: the buffer is too small, the host re-launches
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	bool vis = false;
 	int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
 	uint32_t dbits = 0;
-	if (idx < P && radii[idx] > 0) {
+	if (idx < P && radii[idx] > 0 && tiles_touched[idx] > 0) {
 		vis = true;
 		const uint4 q3 = recs[idx].q3;
 		rminx = q3.x & 0xffff; rminy = q3.x >> 16;
@@ -376,11 +503,12 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const i
 	});
 }
 
-void launch_bin_scatter(int P, int gx, const int* radii, const GsRec* recs, const uint2* ranges, uint32_t* cursor,
-                        uint64_t* keys, hipStream_t s)
+void launch_bin_scatter(int P, int gx, const int* radii, const uint32_t* tiles_touched, const GsRec* recs,
+                        const uint2* ranges, uint32_t* cursor, uint64_t* keys, const GsCtl* ctl, uint32_t cap,
+                        hipStream_t s)
 {
-	hipLaunchKernelGGL(bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, radii, recs, ranges,
-	                   cursor, keys);
+	hipLaunchKernelGGL(bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, radii, tiles_touched, recs,
+	                   ranges, cursor, keys, ctl, cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,10 +529,12 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int c
                                                         const uint32_t* __restrict__ tiles_touched,
                                                         const GsRec* __restrict__ recs,
                                                         uint32_t* __restrict__ Hm, const uint2* __restrict__ ranges,
-                                                        uint64_t* __restrict__ keys)
+                                                        uint64_t* __restrict__ keys, const GsCtl* __restrict__ ctl,
+                                                        uint32_t cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
+	if (SCATTER && ctl->num_binned > cap) return;   // see bin_scatter_kernel
 	const int tid = threadIdx.x;
 	const int g = blockIdx.x;   // (an XCD-banded chunk order was measured: no effect on the scatter)
 	uint32_t* row = Hm + (size_t)g * T;
@@ -481,19 +611,19 @@ void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const 
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<false>, lds);
 	hipLaunchKernelGGL(bin_chunk_kernel<false>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
-	                   (const uint2*)nullptr, (uint64_t*)nullptr);
+	                   (const uint2*)nullptr, (uint64_t*)nullptr, (const GsCtl*)nullptr, 0u);
 	hipLaunchKernelGGL(bin_colscan_kernel, dim3((T + 63) / 64), dim3(64 * GSR_COLSCAN_Q), 0, s, G, T, Hm, tile_count);
 }
 
 void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
-                         const uint2* ranges, uint64_t* keys, hipStream_t s)
+                         const uint2* ranges, uint64_t* keys, const GsCtl* ctl, uint32_t cap, hipStream_t s)
 {
 	const int G = bin_chunks(P);
 	const int chunk = ((P + G - 1) / G + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS * GSR_BIN_THREADS;
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<true>, lds);
 	hipLaunchKernelGGL(bin_chunk_kernel<true>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
-	                   ranges, keys);
+	                   ranges, keys, ctl, cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,8 +692,10 @@ __device__ __forceinline__ void gs_wave_sort_tile(const uint64_t* __restrict__ k
 }
 
 __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ point_list)
+                                                        uint32_t* __restrict__ point_list, const GsCtl* __restrict__ ctl,
+                                                        uint32_t cap)
 {
+	if (ctl->num_binned > cap) return;   // see bin_scatter_kernel
 	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per tile, no cross-wave traffic
 	if (tile >= T) return;
 	const int lane = threadIdx.x & 63;
@@ -641,11 +773,13 @@ __device__ __forceinline__ void tile_radix_pass(const uint64_t* __restrict__ src
 
 __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __restrict__ ranges,
                                                               uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
-                                                              uint32_t* __restrict__ point_list, uint32_t lo)
+                                                              uint32_t* __restrict__ point_list, uint32_t lo,
+                                                              const GsCtl* __restrict__ ctl, uint32_t cap)
 {
 	__shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave running offsets
 	__shared__ uint32_t s_tot[4];
 	__shared__ uint32_t s_maxrun;
+	if (ctl->num_binned > cap || ctl->max_tile_count <= lo) return;   // see bin_scatter_kernel; no long list at all
 	const uint2 range = ranges[blockIdx.x];
 	const uint32_t n = range.y - range.x;
 	if (n <= lo) return;
@@ -829,15 +963,15 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 	for (uint32_t i = tid; i < n; i += 256) point_list[range.x + i] = (uint32_t)src[i];
 }
 
-void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
-                      uint32_t* point_list, hipStream_t s)
+void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
+                      uint32_t* point_list, const GsCtl* ctl, uint32_t cap, hipStream_t s)
 {
-	if (max_tile_count == 0) return;
-	// <= GSR_SORT_LDS_MAX keys: register bitonic network, one wave per tile; longer: radix path
-	hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list);
-	if (max_tile_count > GSR_SORT_LDS_MAX)
+	// <= GSR_SORT_LDS_MAX keys: register bitonic network, one wave per tile; longer: radix path (needs keys2)
+	if (with_short)
+		hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list, ctl, cap);
+	if (with_long)
 		hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list,
-		                   GSR_SORT_LDS_MAX);
+		                   GSR_SORT_LDS_MAX, ctl, cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -852,15 +986,22 @@ void launch_tile_sort(int T, uint32_t max_tile_count, const uint2* ranges, uint6
 // XCD-aware tile order: workgroup b runs on XCD b%8 (observed placement, speed only); each XCD is
 // given a contiguous band of tiles so that neighbouring tiles, which share Gaussians, gather the
 // same records from the same 4 MiB L2.
+// NOCULL (debugging / parity A/B, gsr_set_option("cull", 0)): every staged instance is evaluated by every wave and
+// the pcut pre-test is replaced by the domain bound of gs_exp -- the culling must not change a single bit.
+template <bool NOCULL>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     int T, int chunk, int gx, int W, int H, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib)
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const GsCtl* __restrict__ ctl, uint32_t cap,
+    uint32_t max_sorted)
 {
 	__shared__ float4 sA[256];
 	__shared__ float4 sB[256];
 	__shared__ float4 sC[256];
+	// launched ahead of the host's read-back (see bin_scatter_kernel): leave when the binning buffer was too small or
+	// a list is longer than what the sort kernels launched with this call handle (its point_list is not written)
+	if (ctl->num_binned > cap || ctl->max_tile_count > max_sorted) return;
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
@@ -908,7 +1049,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 			if (__ballot(!done) == 0ull) break;   // every pixel of this wave has saturated
 			const int jl = sub + lane;
 			bool hit = false;
-			if (jl < cnt) hit = gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
+			if (jl < cnt) hit = NOCULL ? true : gs_box_may_touch(sA[jl], sB[jl], bx0, by0, bx1, by1);
 			unsigned long long m = __ballot(hit);
 			// walk the surviving instances in list order; the body is straight-line predicated code (no
 			// per-test branches, no short-circuit evaluation: within a hit block about half of the lanes are
@@ -923,7 +1064,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 				const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
 				const float alpha = fminf(0.99f, B.y * gs_exp(power));
 				// forward.cu:339 (+ pcut), :346
-				const bool valid = (!done) & (power <= 0.0f) & (power >= B.w) & (!(alpha < 1.0f / 255.0f));
+				const bool valid = (!done) & (power <= 0.0f) & (power >= (NOCULL ? -80.0f : B.w)) & (!(alpha < 1.0f / 255.0f));
 				const float test_T = T_ * (1 - alpha);
 				const bool stop = valid & (test_T < 0.0001f);                        // forward.cu:357-361
 				done = done | stop;
@@ -978,11 +1119,16 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, hipStream_t s)
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, const GsCtl* ctl, uint32_t cap,
+                          uint32_t max_sorted, bool nocull, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
-	hipLaunchKernelGGL(composite_fwd_kernel, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges,
-	                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib);
+	if (nocull)
+		hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges,
+		                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib, ctl, cap, max_sorted);
+	else
+		hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges,
+		                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib, ctl, cap, max_sorted);
 }
 
 }  // namespace gsr

@@ -144,7 +144,14 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
 			}
 			if (cached_slot < 0) { atomicOr(&status[0], 1u); return; }   // table full
 			const int local = ((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7);
-			atomicAdd(&vox[(size_t)cached_slot * BLOCK_VOX + local], (unsigned long long)(q * (1ll << 24) + 1));
+			const unsigned long long add = (unsigned long long)(q * (1ll << 24) + 1);
+			const unsigned long long prev = atomicAdd(&vox[(size_t)cached_slot * BLOCK_VOX + local], add);
+			if ((prev & 0xffffffull) == 0xffffffull) {
+				// the 24-bit observation count is full: undo the add (the carry would corrupt the sum field) and
+				// report it -- status bit 1; the voxel keeps its 2^24 - 1 observations
+				atomicAdd(&vox[(size_t)cached_slot * BLOCK_VOX + local], (unsigned long long)(-(long long)add));
+				atomicOr(&status[0], 2u);
+			}
 		}
 		// DDA::step
 		const int axis = min_index(nx, ny, nz);

@@ -53,32 +53,63 @@ void require_device(const torch::Tensor& t, const char* name)
 
 void* current_stream(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
-// One-shot output arena for the NEXT backward (gaustudio_amd/parallel.py): five caller-owned tensors
-// [dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations], typically slices of one flat all-reduce buffer,
-// so that the gradients are born where the collective reads them (no pack copy).  Consumed by the first backward
-// whose shapes match; any later backward of the same step allocates as usual and autograd accumulates.
-std::vector<torch::Tensor> g_arena;
-std::mutex g_arena_mutex;   // armed on the caller's thread, consumed on an autograd worker thread
+// One-shot output arena for the NEXT backward of ONE specific graph (gaustudio_amd/parallel.py): five caller-owned
+// tensors [dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations], typically slices of one flat all-reduce
+// buffer, so that the gradients are born where the collective reads them (no pack copy).  The arena is keyed to the
+// data pointers of the operator inputs it was armed for (means3D, sh, scales, rotations -- the ones the backward
+// sees; 0 = wildcard): an unrelated backward that happens to have the same P (a second model, an eval pass,
+// torch.autograd.grad) does not match and allocates as usual.  All five slots are validated up front; on any
+// mismatch the arena is left armed and untouched.  Optionally the SH stage of that backward runs in `sh_chunks`
+// Gaussian ranges and `chunk_hook(c, g0, g1)` is called after chunk c has been enqueued, which lets the caller start
+// the all-reduce of that slice of dL_dsh while the next chunk computes.
+struct GradArena {
+	std::vector<torch::Tensor> outs;
+	std::vector<int64_t> keys;   // data_ptr of [means3D, sh, scales, rotations]
+	int sh_chunks = 1;
+	py::object hook;             // None or callable
+};
+GradArena& g_arena = *new GradArena();   // never destroyed: holds a Python object, must not outlive the interpreter's teardown
+std::mutex g_arena_mutex;                // armed on the caller's thread, consumed on an autograd worker thread
 
-torch::Tensor arena_or_empty(std::vector<torch::Tensor>& arena, size_t slot, at::IntArrayRef shape, const torch::TensorOptions& fo)
+bool arena_matches(const GradArena& a, int64_t P, int64_t M, const torch::TensorOptions& fo, const int64_t keys[4])
 {
-	if (arena.size() == 5) {
-		const torch::Tensor& t = arena[slot];
-		if (t.defined() && t.sizes() == shape && t.device() == fo.device() && t.scalar_type() == torch::kFloat32 &&
-		    t.is_contiguous())
-			return t;
-		arena.clear();   // mismatch: do not half-use it
+	if (a.outs.size() != 5) return false;
+	const std::vector<int64_t> shapes[5] = {{P, 3}, {P, M, 3}, {P, 1}, {P, 3}, {P, 4}};
+	for (int i = 0; i < 5; i++) {
+		const torch::Tensor& t = a.outs[i];
+		if (!t.defined() || t.sizes() != at::IntArrayRef(shapes[i]) || t.device() != fo.device() ||
+		    t.scalar_type() != torch::kFloat32 || !t.is_contiguous())
+			return false;
 	}
-	return torch::empty(shape, fo);
+	for (size_t i = 0; i < a.keys.size() && i < 4; i++)
+		if (a.keys[i] != 0 && a.keys[i] != keys[i]) return false;
+	return true;
+}
+
+void check_rows(const torch::Tensor& t, int64_t P, int64_t per_row, const char* name)
+{
+	if (t.numel() == 0) return;   // absent
+	TORCH_CHECK(t.numel() == P * per_row, name, " must hold ", per_row, " values for each of the ", P, " Gaussians (got ",
+	            t.numel(), " elements)");
+}
+
+void check_small(const torch::Tensor& t, int64_t n, const char* name)
+{
+	TORCH_CHECK(t.numel() >= n, name, " must hold at least ", n, " values (got ", t.numel(), ")");
+	TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " must be float32");
 }
 
 }  // namespace
 
-void set_grad_arena(std::vector<torch::Tensor> outs)
+void set_grad_arena(std::vector<torch::Tensor> outs, std::vector<int64_t> keys, int sh_chunks, py::object hook)
 {
 	TORCH_CHECK(outs.empty() || outs.size() == 5, "set_grad_arena expects [means3D, sh, opacity, scales, rotations] gradients or []");
+	TORCH_CHECK(keys.empty() || keys.size() == 4, "set_grad_arena keys: data_ptr of [means3D, sh, scales, rotations] or []");
 	std::lock_guard<std::mutex> lock(g_arena_mutex);
-	g_arena = std::move(outs);
+	g_arena.outs = std::move(outs);
+	g_arena.keys = std::move(keys);
+	g_arena.sh_chunks = sh_chunks > 1 ? sh_chunks : 1;
+	g_arena.hook = std::move(hook);
 }
 
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -103,6 +134,22 @@ RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D
 	const auto campos = campos_.contiguous(), bg = background.contiguous();
 	if (colors.numel() != 0 && (colors.ndimension() != 2 || colors.size(1) != 3))
 		AT_ERROR("colors_precomp must have dimensions (num_points, 3)");   // NUM_CHANNELS == 3, config.h:15
+	// the reference checks means3D only and lets the kernels read out of bounds; malformed input is an error here
+	check_rows(colors, P, 3, "colors_precomp");
+	// (PCDRenderer passes torch.ones_like(xyz), i.e. [P,3], as opacities -- renderers/pcd_renderer.py:26 -- and the
+	// reference reads its first P floats: at least P values, not exactly P)
+	TORCH_CHECK(opacity.numel() >= P, "opacities must hold at least one value per Gaussian (got ", opacity.numel(), " for ", P, ")");
+	check_rows(scales, P, 3, "scales");
+	check_rows(rotations, P, 4, "rotations");
+	check_rows(cov3D_precomp, P, 6, "cov3D_precomp");
+	if (sh.numel() != 0) {
+		TORCH_CHECK(sh.ndimension() == 3 && sh.size(0) == P && sh.size(2) == 3, "sh must have dimensions (num_points, M, 3)");
+	}
+	check_small(viewmatrix, 16, "viewmatrix");
+	check_small(projmatrix, 16, "projmatrix");
+	check_small(campos, 3, "campos");
+	check_small(bg, 3, "bg");
+	TORCH_CHECK(H > 0 && W > 0, "image size must be positive");
 	for (const auto& p : {std::make_pair(&colors, "colors_precomp"), std::make_pair(&opacity, "opacities"),
 	                      std::make_pair(&scales, "scales"), std::make_pair(&rotations, "rotations"),
 	                      std::make_pair(&cov3D_precomp, "cov3D_precomp"), std::make_pair(&sh, "sh")})
@@ -155,31 +202,73 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 	const int M = (sh.numel() != 0 && sh.size(0) != 0) ? (int)sh.size(1) : 0;
 
 	const auto fo = means3D.options().dtype(torch::kFloat32);
-	// torch::empty: the library writes every row (zeros for culled Gaussians); the reference needed torch::zeros
-	std::vector<torch::Tensor> arena;
-	{
-		std::lock_guard<std::mutex> lock(g_arena_mutex);
-		arena.swap(g_arena);   // one-shot
+	for (const auto& p : {std::make_pair(&g_color, (int64_t)3), std::make_pair(&g_depth, (int64_t)1),
+	                      std::make_pair(&g_median, (int64_t)3), std::make_pair(&g_op, (int64_t)1)})
+		TORCH_CHECK(p.first->numel() == p.second * H * W && p.first->is_cuda(), "upstream gradients must be device tensors of the "
+		            "rendered image size (", H, "x", W, ")");
+	check_rows(colors, P, 3, "colors_precomp");
+	check_rows(scales, P, 3, "scales");
+	check_rows(rotations, P, 4, "rotations");
+	check_rows(cov3D_precomp, P, 6, "cov3D_precomp");
+	check_rows(radii, P, 1, "radii");
+	if (sh.numel() != 0)
+		TORCH_CHECK(sh.ndimension() == 3 && sh.size(0) == P && sh.size(2) == 3, "sh must have dimensions (num_points, M, 3)");
+	check_small(bg, 3, "bg");
+	TORCH_CHECK(R >= 0, "num_rendered must be non-negative");
+	if (P != 0) {
+		TORCH_CHECK(geomBuffer.is_cuda() && imageBuffer.is_cuda() && binningBuffer.is_cuda(), "the three opaque buffers must be the "
+		            "device tensors rasterize_gaussians returned");
+		TORCH_CHECK((size_t)geomBuffer.numel() >= gsr_geometry_bytes(P) && (size_t)imageBuffer.numel() >= gsr_image_bytes(W, H),
+		            "geomBuffer / imgBuffer are smaller than what a forward with P = ", P, ", ", W, "x", H, " produces");
 	}
-	torch::Tensor dL_dmeans3D = arena_or_empty(arena, 0, {P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
+	// torch::empty: the library writes every row (zeros for culled Gaussians); the reference needed torch::zeros
+	GradArena arena;
+	{
+		const int64_t keys[4] = {(int64_t)(uintptr_t)means3D_.data_ptr(), (int64_t)(uintptr_t)sh_.data_ptr(),
+		                         (int64_t)(uintptr_t)scales_.data_ptr(), (int64_t)(uintptr_t)rotations_.data_ptr()};
+		std::lock_guard<std::mutex> lock(g_arena_mutex);
+		if (arena_matches(g_arena, P, M, fo, keys)) {   // one-shot, and only for the graph it was armed for
+			arena = std::move(g_arena);
+			g_arena = GradArena();
+		}
+	}
+	const bool in_arena = arena.outs.size() == 5;
+	torch::Tensor dL_dmeans3D = in_arena ? arena.outs[0] : torch::empty({P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
 	torch::Tensor dL_dcolors = torch::empty({P, 3}, fo), dL_dcov3D = torch::empty({P, 6}, fo);
-	torch::Tensor dL_dsh = arena_or_empty(arena, 1, {P, M, 3}, fo), dL_dopacity = arena_or_empty(arena, 2, {P, 1}, fo);
-	torch::Tensor dL_dscales = arena_or_empty(arena, 3, {P, 3}, fo), dL_drotations = arena_or_empty(arena, 4, {P, 4}, fo);
+	torch::Tensor dL_dsh = in_arena ? arena.outs[1] : torch::empty({P, M, 3}, fo);
+	torch::Tensor dL_dopacity = in_arena ? arena.outs[2] : torch::empty({P, 1}, fo);
+	torch::Tensor dL_dscales = in_arena ? arena.outs[3] : torch::empty({P, 3}, fo);
+	torch::Tensor dL_drotations = in_arena ? arena.outs[4] : torch::empty({P, 4}, fo);
 	if (P != 0) {
 		const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
 		torch::Tensor scratch = torch::empty({(long long)gsr_backward_scratch_bytes(P, R)}, bo);
-		const int rc = gsr_backward(
-		    P, degree, M, R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(sh, "sh"), fptr(colors, "colors_precomp"),
-		    fptr(scales, "scales"), scale_modifier, fptr(rotations, "rotations"), fptr(cov3D_precomp, "cov3D_precomp"),
-		    fptr(viewmatrix, "viewmatrix"), fptr(projmatrix, "projmatrix"), fptr(campos, "campos"), tan_fovx, tan_fovy,
-		    radii.data_ptr<int>(), reinterpret_cast<const char*>(geomBuffer.data_ptr()),
-		    reinterpret_cast<const char*>(binningBuffer.data_ptr()), reinterpret_cast<const char*>(imageBuffer.data_ptr()),
-		    fptr(g_color, "dL_dout_color"), fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"),
-		    fptr(g_op, "dL_dout_final_opacity"), dL_dmeans2D.data_ptr<float>(), dL_dopacity.data_ptr<float>(),
-		    dL_dcolors.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(),
-		    M ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(),
-		    reinterpret_cast<char*>(scratch.data_ptr()), debug ? 1 : 0, current_stream(means3D));
-		if (rc < 0) fail(rc);
+		auto run = [&](int parts, int g0, int g1) {
+			const int rc = gsr_backward_parts(
+			    parts, g0, g1, P, degree, M, R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(sh, "sh"),
+			    fptr(colors, "colors_precomp"), fptr(scales, "scales"), scale_modifier, fptr(rotations, "rotations"),
+			    fptr(cov3D_precomp, "cov3D_precomp"), tan_fovx, tan_fovy, radii.data_ptr<int>(),
+			    reinterpret_cast<const char*>(geomBuffer.data_ptr()), reinterpret_cast<const char*>(binningBuffer.data_ptr()),
+			    reinterpret_cast<const char*>(imageBuffer.data_ptr()), fptr(g_color, "dL_dout_color"),
+			    fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"), fptr(g_op, "dL_dout_final_opacity"),
+			    dL_dmeans2D.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
+			    dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr,
+			    dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(), reinterpret_cast<char*>(scratch.data_ptr()),
+			    debug ? 1 : 0, current_stream(means3D));
+			if (rc < 0) fail(rc);
+		};
+		const bool chunked = in_arena && arena.sh_chunks > 1 && !arena.hook.is_none() && M > 0 && sh.numel() != 0;
+		if (!chunked) {
+			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P);
+		} else {
+			// SH stage in Gaussian ranges (multiples of 256): the hook sees each range as soon as it is enqueued
+			run(GSR_BWD_PART_MAIN, 0, 0);
+			const int per = (int)(((int64_t)(P + arena.sh_chunks - 1) / arena.sh_chunks + 255) / 256 * 256);
+			for (int c = 0, g0 = 0; g0 < P; c++, g0 += per) {
+				const int g1 = std::min(P, g0 + per);
+				run(GSR_BWD_PART_SH, g0, g1);
+				arena.hook(c, g0, g1);
+			}
+		}
 	}
 	return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
 }
@@ -294,7 +383,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 	m.def("rasterize_gaussians", &RasterizeGaussians);
 	m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
 	m.def("mark_visible", &markVisible);
-	m.def("set_grad_arena", &set_grad_arena);
+	m.def("set_grad_arena", &set_grad_arena, py::arg("outs"), py::arg("keys") = std::vector<int64_t>(), py::arg("sh_chunks") = 1,
+	      py::arg("hook") = py::none());
 	m.def("rasterize_gaussians_raw", &RasterizeGaussiansRaw);
 	m.def("rasterize_gaussians_raw_backward", &RasterizeGaussiansRawBackward);
 }

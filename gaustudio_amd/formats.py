@@ -19,7 +19,7 @@ Reference behaviour followed here
 The reference reads and writes PLY through the third-party `plyfile` package (not vendored, not installed
 here).  The reader/writer below restate the PLY 1.0 container format itself (header grammar + packed
 little/big-endian or ascii scalar records); parity for the container is pinned by byte-level known-answer
-tests (tests/test_io.py), parity for the camera math by a fixture generated from the reference's own
+tests (tests/test_formats.py), parity for the camera math by a fixture generated from the reference's own
 functions (tests/golden/py_cameras.npz).
 """
 import json

@@ -1,13 +1,21 @@
-"""Multi-GPU data parallelism for the rasterizer: one camera per GPU, replicated Gaussians, ONE
+"""Multi-GPU data parallelism for the rasterizer: one camera per GPU, replicated Gaussians, ONE logical
 all-reduce of the per-Gaussian gradients after backward (BASELINE.json north_star).
 
 The reference has no distributed code at all ("Collective / NCCL call sites: none");
 this is new design for an 8 x MI355X node: one process per GPU, torch.distributed backend "nccl"
 (= RCCL over xGMI on ROCm).  Views are independent given replicated parameters, so forward and
 backward need no exchange; the only collective is a SUM over ranks of a single flat fp32 buffer
-[means3D 3 | sh 3M | opacity 1 | scales 3 | rotations 4] = 59 floats (236 B) per Gaussian at M = 16,
-which equals accumulating the N views on one GPU.  One flat buffer -> one large collective: xGMI is
-point-to-point (7 links x ~153 GB/s per GPU), so a few large transfers beat many small ones.
+[sh 3M | means3D 3 | opacity 1 | scales 3 | rotations 4] = 59 floats (236 B) per Gaussian at M = 16,
+which equals accumulating the N views on one GPU.
+
+Volume and overlap (DESIGN.md s7 has the alpha-beta model).  xGMI is point-to-point (7 links x ~153 GB/s per GPU):
+a ring all-reduce moves 2 (N-1)/N x 236 B per Gaussian over every link, so the collective costs about as much as
+the whole forward + backward and must not simply be appended to it.  81 % of the payload (dL_dsh) is produced by the
+LAST kernel of the backward (the SH stage), which is independent per Gaussian: `arm(overlap_chunks=K)` makes that
+backward run the SH stage in K Gaussian ranges and reduce each range's slice of the flat buffer as soon as its kernel
+is enqueued (async, on the communicator's stream), so all but the last chunk's transfer and the 19 % tail (means /
+opacity / scale / rotation gradients) hide behind compute.  It stays one logical reduction of one flat buffer: the
+chunks partition it, every element is reduced exactly once, and the result is bit-identical to the single call.
 
 The same code runs on CPU tensors with the "gloo" backend (tests/test_distributed.py, world_size 2).
 """
@@ -18,51 +26,87 @@ import torch.distributed as dist
 
 
 ARENA_ROLES = ("means3D", "shs", "opacities", "scales", "rotations")
+_KEY_ROLES = ("means3D", "shs", "scales", "rotations")      # the operator inputs the backward sees (arena key)
+
+
+def _multi(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
 class FlatGradBucket:
     """A persistent flat fp32 buffer holding the gradients of `params` back to back.
 
     `roles` (optional) names which parameter plays which operator input (keys of ARENA_ROLES).  With roles,
-    `arm()` makes the NEXT rasterizer backward write its gradients straight into this buffer, so that autograd
-    adopts slices of it as `p.grad` and the all-reduce needs no pack copy (236 MB read + written per step at 1 M
-    Gaussians otherwise).  Anything that does not end up aliased (another op in the graph, autograd deciding to
-    copy) is still handled by pack()."""
+    `arm()` makes the NEXT rasterizer backward OF THESE PARAMETERS write its gradients straight into this buffer,
+    so that autograd adopts slices of it as `p.grad` and the all-reduce needs no pack copy (236 MB read + written
+    per step at 1 M Gaussians otherwise).  The `shs` parameter is laid out FIRST, so that the chunks reduced while
+    the backward is still running are a contiguous prefix and what remains for the final call is one contiguous tail.
+    Anything that does not end up aliased (another op in the graph, autograd deciding to copy) is still handled by
+    pack()."""
 
     def __init__(self, params: Sequence[torch.Tensor], roles: Optional[dict] = None):
         self.params: List[torch.Tensor] = list(params)
         self.roles = None
+        if not self.params:
+            raise ValueError("FlatGradBucket needs at least one parameter")
+        idx = {id(p): i for i, p in enumerate(self.params)}
         if roles is not None:
             if set(roles) != set(ARENA_ROLES):
                 raise ValueError(f"roles must name exactly {ARENA_ROLES}")
-            idx = {id(p): i for i, p in enumerate(self.params)}
             if any(id(roles[r]) not in idx for r in ARENA_ROLES):
                 raise ValueError("every role parameter must be one of the bucket's parameters")
             self.roles = [idx[id(roles[r])] for r in ARENA_ROLES]
-        if not self.params:
-            raise ValueError("FlatGradBucket needs at least one parameter")
+            self._key_params = [roles[r] for r in _KEY_ROLES]
         dev = self.params[0].device
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("all parameters must be float32 on one device")
         self.sizes = [p.numel() for p in self.params]
-        self.offsets = [0]
-        for n in self.sizes:
-            self.offsets.append(self.offsets[-1] + n)
-        self.flat = torch.zeros(self.offsets[-1], dtype=torch.float32, device=dev)
+        # storage order: the SH parameter first (see class docstring), the others as given
+        order = list(range(len(self.params)))
+        self._sh = self.roles[1] if self.roles is not None else None
+        if self._sh is not None:
+            order.remove(self._sh)
+            order.insert(0, self._sh)
+        self.offsets = [0] * len(self.params)
+        o = 0
+        for i in order:
+            self.offsets[i] = o
+            o += self.sizes[i]
+        self.flat = torch.zeros(o, dtype=torch.float32, device=dev)
+        self._works = []          # async chunk reductions issued from inside the backward
+        self._reduced_upto = 0    # elements [0, _reduced_upto) of flat are already (being) reduced
+        self._group = None
+        self.stats = {"chunks": 0, "chunk_bytes": 0, "tail_bytes": 0}
 
     def views(self):
         return [self.flat[o:o + n].view_as(p) for o, n, p in zip(self.offsets, self.sizes, self.params)]
 
-    def arm(self):
-        """Directs the next rasterizer backward into this buffer.  Only when every p.grad is None (an existing
-        p.grad could BE a slice of this buffer from the previous step: writing the new gradient over it and then
-        accumulating would be wrong), on a ROCm device, and with roles given; otherwise a no-op (pack() copies)."""
+    # ---- arming: gradients born in the flat buffer -----------------------------------------------------------
+    def arm(self, overlap_chunks: int = 0, group: Optional[dist.ProcessGroup] = None):
+        """Directs the next rasterizer backward of these parameters into this buffer.  Only when every p.grad is
+        None (an existing p.grad could BE a slice of this buffer from the previous step: writing the new gradient
+        over it and then accumulating would be wrong), on a ROCm device, and with roles given; otherwise a no-op
+        (pack() copies).
+
+        overlap_chunks > 1 (and a process group with more than one rank): that backward runs its SH stage in this
+        many Gaussian ranges and the slice of each finished range is all-reduced asynchronously while the next range
+        computes.  Only valid when the armed backward is the LAST one contributing to these gradients before the
+        reduction (one view per rank): a later local accumulation would be added after the sum over ranks."""
+        self._works = []
+        self._reduced_upto = 0
         if self.roles is None or not self.flat.is_cuda or any(p.grad is not None for p in self.params):
             return False
         from . import _C
         views = self.views()
-        _C.set_grad_arena([views[i] for i in self.roles])
+        keys = [int(p.data_ptr()) for p in self._key_params]
+        hook = None
+        chunks = 1
+        if overlap_chunks > 1 and _multi(group):
+            self._group = group
+            hook = self._on_sh_chunk
+            chunks = int(overlap_chunks)
+        _C.set_grad_arena([views[i] for i in self.roles], keys, chunks, hook)
         return True
 
     def disarm(self):
@@ -70,6 +114,22 @@ class FlatGradBucket:
             from . import _C
             _C.set_grad_arena([])
 
+    def _on_sh_chunk(self, c: int, g0: int, g1: int):
+        """Called by the backward (csrc/torch_binding.cpp) right after the SH kernel for the Gaussians [g0, g1) has
+        been enqueued: their rows of dL_dsh -- flat[g0 * 3M, g1 * 3M), the buffer starts with the SH gradients -- are
+        final.  The collective is stream-ordered behind that kernel and runs on the communicator's own stream."""
+        P = self.params[self._sh].shape[0]
+        per = self.sizes[self._sh] // max(P, 1)
+        lo, hi = g0 * per, g1 * per
+        if lo != self._reduced_upto:       # ranges must arrive in order and without gaps; otherwise leave it to the tail
+            return
+        w = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+        self._works.append(w)
+        self._reduced_upto = hi
+        self.stats["chunks"] += 1
+        self.stats["chunk_bytes"] += (hi - lo) * 4
+
+    # ---- pack / unpack ----------------------------------------------------------------------------------------
     def pack(self):
         """Brings every p.grad into the flat buffer: zeros where a parameter received none, nothing to do where
         p.grad already IS the slice (arm()), a copy otherwise."""
@@ -93,13 +153,43 @@ class FlatGradBucket:
 
 def allreduce_gaussian_grads(bucket: FlatGradBucket, group: Optional[dist.ProcessGroup] = None,
                              async_op: bool = False):
-    """SUM-all-reduces the packed gradients across ranks in one collective and re-attaches them.
-    With world_size 1 (or no process group) there is nothing to exchange: gradients stay where autograd
-    put them and nothing is copied."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    """SUM-all-reduces the packed gradients across ranks and re-attaches them: ONE collective over the whole flat
+    buffer, or -- when the backward already reduced a prefix chunk by chunk (FlatGradBucket.arm(overlap_chunks=K))
+    -- one collective over the remaining tail, after which the chunk handles are waited for.  Every element of the
+    buffer is reduced exactly once either way.  With world_size 1 (or no process group) there is nothing to
+    exchange: gradients stay where autograd put them and nothing is copied."""
+    if not _multi(group):
+        bucket._works = []
+        bucket._reduced_upto = 0
         return None
-    bucket.pack()
-    work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    done = bucket._reduced_upto
+    works = bucket._works
+    if done > 0:
+        # the prefix was reduced in place while the backward ran; it is only valid if those gradients really live in
+        # the buffer (they do when the arena was consumed, which is the only way the hook gets called)
+        sh = bucket.params[bucket._sh]
+        v = bucket.views()[bucket._sh]
+        if sh.grad is None or sh.grad.data_ptr() != v.data_ptr():
+            raise RuntimeError("chunked all-reduce ran but the SH gradient does not live in the flat buffer")
+    # pack everything that is not yet reduced (copies only what is not already aliased)
+    for i, (v, p) in enumerate(zip(bucket.views(), bucket.params)):
+        if done > 0 and i == bucket._sh:
+            continue
+        if p.grad is None:
+            v.zero_()
+        elif not (p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape and p.grad.is_contiguous()):
+            v.copy_(p.grad)
+    tail = bucket.flat[done:]
+    bucket.stats["tail_bytes"] += tail.numel() * 4
+    work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group, async_op=async_op or bool(works))
+    if works:
+        for w in works:
+            w.wait()
+        if work is not None and not async_op:
+            work.wait()
+            work = None
+    bucket._works = []
+    bucket._reduced_upto = 0
     if work is None or not async_op:
         bucket.unpack()
     return work
@@ -116,15 +206,19 @@ def shard_views(views: Sequence, rank: Optional[int] = None, world_size: Optiona
 
 
 def render_views_and_reduce(render_fn, views: Iterable, bucket: FlatGradBucket,
-                            group: Optional[dist.ProcessGroup] = None):
+                            group: Optional[dist.ProcessGroup] = None, overlap_chunks: int = 0):
     """One data-parallel iteration: `render_fn(view)` must run forward+backward for one camera and
     accumulate into p.grad; afterwards gradients are summed over ranks.  Returns what render_fn
-    returned for each local view."""
+    returned for each local view.  overlap_chunks > 1 overlaps the reduction with the tail of the backward
+    (FlatGradBucket.arm) when this rank renders exactly one view."""
+    views = list(views)
     for p in bucket.params:
         p.grad = None
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _multi(group)
     if multi:
-        bucket.arm()            # the first view's gradients are born in the flat buffer
+        # the first view's gradients are born in the flat buffer; with a single local view its backward is also the
+        # last one, so its SH chunks may be reduced while it is still running
+        bucket.arm(overlap_chunks if len(views) == 1 else 0, group)
     try:
         outs = [render_fn(v) for v in views]
     finally:

@@ -65,9 +65,13 @@ class TSDFVolume:
             raise RuntimeError(f"gsr_tsdf_integrate failed (rc={rc})")
 
     def _check_overflow(self):
-        if int(self.status.item()) & 1:
+        st = int(self.status.item())
+        if st & 1:
             raise RuntimeError(f"TSDFVolume: the block hash ({self.capacity} slots) overflowed; "
                                "create the volume with a larger capacity_blocks")
+        if st & 2:
+            raise RuntimeError("TSDFVolume: a voxel received more than 2^24 - 1 observations (the count field of the packed "
+                               "voxel word is full); later observations of it were dropped")
 
     # ------------------------------------------------------------------ inspection
     def occupied_blocks(self):

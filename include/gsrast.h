@@ -56,12 +56,14 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
                      unsigned char* present, void* stream);
 
 /* Replaces Rasterizer::forward (rasterizer.h:31-59; rasterizer_impl.cu:198-343).
- * Returns num_rendered (>= 0, number of Gaussian x tile instances) or a negative GSR_ERR_*.
+ * Returns num_rendered (>= 0) or a negative GSR_ERR_*.  num_rendered keeps the reference's definition -- the sum
+ * over visible Gaussians of the tiles of their getRect square (rasterizer_impl.cu:280-284) -- although fewer
+ * instances are actually binned (only tiles that can hold a pixel with alpha >= 1/255; gsr_inspect_counts).
  * D = active SH degree, M = SH coefficients per Gaussian as stored (row stride of `shs`).
  * Exactly one of {shs, colors_precomp} and one of {scales+rotations, cov3D_precomp} must be non-NULL.
  * out_color[3,H,W], out_depth[1,H,W], out_median_depth[3,H,W], out_opacity[1,H,W], radii[P] are
- * fully overwritten (no pre-zeroing needed).  Blocks the host once to read num_rendered back
- * (as rasterizer_impl.cu:283-284 does). */
+ * fully overwritten (no pre-zeroing needed).  The host waits once for num_rendered (the reference blocks the
+ * device as well, rasterizer_impl.cu:283-284); here the remaining kernels are already enqueued by then. */
 int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx,
                 gsr_alloc_fn binning_alloc, void* binning_ctx,
                 gsr_alloc_fn image_alloc, void* image_ctx,
@@ -94,6 +96,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx,
  * atomics, backward.cu:559-607, plus one validity byte each; the per-Gaussian row offsets live in the
  * geometry buffer). */
 size_t gsr_backward_scratch_bytes(int P, int R);
+
+/* Lower bounds on the sizes of the geometry / image buffers a gsr_forward with these dimensions requests
+ * (adapters use them to reject buffers that cannot belong to the backward they are handed to). */
+size_t gsr_geometry_bytes(int P);
+size_t gsr_image_bytes(int width, int height);
 
 /* Replaces Rasterizer::backward (rasterizer.h:61-91; rasterizer_impl.cu:347-452).
  * R = num_rendered returned by the matching gsr_forward; geom/binning/image buffers are the ones its
@@ -135,6 +142,37 @@ int gsr_backward(int P, int D, int M, int R,
                  char* scratch,
                  int debug,
                  void* stream);
+
+/* gsr_backward in stages (new; lets the caller overlap a collective with the tail of the backward,
+ * gaustudio_amd/parallel.py): `parts` selects GSR_BWD_PART_MAIN (compositing backward + the per-Gaussian geometry
+ * stage: every output except dL_dsh, and dL_dmean3D still lacks its SH term) and / or GSR_BWD_PART_SH (the SH
+ * stage for the Gaussians [sh_g0, sh_g1), sh_g0 a multiple of 256: writes those rows of dL_dsh and adds their SH
+ * term to dL_dmean3D; needs MAIN to have run on the same buffers).  gsr_backward == both parts over [0, P). */
+#define GSR_BWD_PART_MAIN 1
+#define GSR_BWD_PART_SH 2
+int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int R, const float* background, int width,
+                       int height, const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp, float tan_fovx,
+                       float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
+                       const char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth,
+                       const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D,
+                       float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                       float* dL_dscale, float* dL_drot, char* scratch, int debug, void* stream);
+
+/* Process-wide tunables (also read from the environment at load: GSR_TIGHT_BINNING, GSR_CULL, GSR_BWD_VARIANT,
+ * GSR_SPECULATIVE).  None of them changes a result bit; they exist for A/B measurements and parity tests:
+ *   "tight_binning" 1|0  bin each Gaussian into the tight sub-rect of the reference's getRect square (default 1);
+ *   "cull"          1|0  wave-level culling + pcut pre-test in composite_fwd (default 1);
+ *   "speculative"   1|0  enqueue binning + compositing before the host has read the instance count (default 1);
+ *   "bwd_variant"   -1 = auto (gsr_selftest), bit 0 = keep the select on T in composite_bwd;
+ *   "bin_capacity"  n    binning capacity (instances) assumed by the next gsr_forward on the current device
+ *                        (0 = forget; tests use a small n to force the re-allocate-and-relaunch path). */
+int gsr_set_option(const char* name, int value);
+int gsr_get_option(const char* name);
+
+/* Device self-test of the arithmetic identities composite_bwd relies on: bit 0: v_rcp_f32(1.0) == 1.0,
+ * bit 1: t * v_rcp_f32(1.0) == t.  Synchronises the stream.  Negative = GSR_ERR_*. */
+int gsr_selftest(void* stream);
 
 /* ---- fused parameter activations (new, not in the reference's interface) ----
  * gsr_forward_raw / gsr_backward_raw take GauStudio's RAW point-cloud attributes -- f_dc[P,1,3] and f_rest[P,M-1,3]
@@ -179,7 +217,12 @@ int gsr_inspect_geometry(const char* geom_buffer, int P, const int* radii, float
 int gsr_inspect_backward_sums(const char* geom_buffer, const char* scratch, int P, int R, const int* radii,
                                float* sums, void* stream);
 
-/* point_list[R] (Gaussian ids, tile-major, depth-sorted), ranges[T,2] ([start,end) per tile). */
+/* out = { instances binned (tight rects; the length of point_list), longest tile list, the reference-defined
+ * num_rendered (what gsr_forward returned), overflow flag }.  `out` is HOST memory; synchronises the stream. */
+int gsr_inspect_counts(const char* image_buffer, int width, int height, uint32_t out[4], void* stream);
+
+/* point_list[R] (Gaussian ids, tile-major, depth-sorted; R = instances binned, see gsr_inspect_counts),
+ * ranges[T,2] ([start,end) per tile). */
 int gsr_inspect_binning(const char* binning_buffer, const char* image_buffer, int R, int width, int height,
                         uint32_t* point_list, uint32_t* ranges, void* stream);
 
@@ -210,7 +253,8 @@ int gsr_depth_to_normals(const float* depth, int width, int height, const float*
  *   voxels[capacity * 512] u64, zero-initialised: (sum_q << 24) | count with sum_q the sum of tsdf / sdf_trunc in
  *       2^-15 fixed point (a block's voxels live at its hash slot; the fields hold up to 2^24 - 1 observations
  *       of a voxel);
- *   status[1] u32, zero-initialised: bit 0 set when the hash table overflowed.
+ *   status[1] u32, zero-initialised: bit 0 set when the hash table overflowed (the ray that hit it is dropped from there
+ *       on), bit 1 when a voxel was offered more than 2^24 - 1 observations (the surplus is dropped).
  * Algorithm and parity status: gaustudio_amd/csrc/gsr_tsdf.hip, DESIGN.md s8. ---- */
 
 /* VDBVolume::Integrate(points, origin) with the default weighting (weight 1): points[num_points,3] device,
@@ -238,8 +282,8 @@ int gsr_tsdf_mc_emit(const uint64_t* block_keys, uint64_t capacity, const uint64
                      const uint32_t* edge_flags, const uint32_t* block_vertex_offset, const uint32_t* block_triangle_offset,
                      uint32_t* vertex_base, float* vertices, int* triangles, void* stream);
 
-/* Per-stage GPU time, averaged over every gsr_forward / gsr_backward call made on this thread since
- * gsr_set_profiling(1): milliseconds for {preprocess, scan(+readback), scatter, sort, composite} (forward)
+/* Per-stage GPU time, averaged over every gsr_forward / gsr_backward call made in this process (any thread) since
+ * gsr_set_profiling(1): milliseconds for {preprocess, scan (tile histogram + scans + row offsets), scatter, sort, composite} (forward)
  * or {composite_bwd, preprocess_bwd} (backward), measured with HIP events recorded on the launch stream.
  * Recording costs one event per stage and no synchronisation; the getters synchronise on the last
  * recorded event and return the number of calls averaged (0 = nothing recorded). */

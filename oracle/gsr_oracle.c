@@ -378,6 +378,121 @@ int64_t orc_count_rendered(int P, const uint32_t* tiles_touched)
 	return R;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * NOT in the reference: the product bins each Gaussian into a TIGHT sub-rect of the reference's getRect square
+ * (gaustudio_amd/csrc/gsr_common.h gs_tight_rect: tiles that cannot hold a pixel with alpha >= 1/255 are left
+ * out).  The oracle restates that function operation for operation (IEEE +,*,/,sqrt,fma only; explicit ternaries)
+ * so that tests can (1) prove on the CPU that the images of the tight and of the reference binning are
+ * bit-identical and the tight list is a sub-sequence of the reference list holding every contributor, and
+ * (2) compare the product's lists / ranges / n_contrib bit for bit against the oracle run on the same rects.
+ * rects[4P] = (rminx, rminy, rmaxx, rmaxy), all 0 for Gaussians binned nowhere.
+ * ---------------------------------------------------------------------------------------------- */
+static inline float orc_log(float x)
+{
+	uint32_t xb;
+	memcpy(&xb, &x, 4);
+	const int e = (int)((xb >> 23) & 0xff) - 127;
+	uint32_t mb = (xb & 0x007fffffu) | 0x3f800000u;
+	float m;
+	memcpy(&m, &mb, 4);
+	const float s = (m - 1.0f) / (m + 1.0f);
+	const float s2 = s * s;
+	float p = 0.11111111f;
+	p = FMA(p, s2, 0.14285715f);
+	p = FMA(p, s2, 0.2f);
+	p = FMA(p, s2, 0.33333334f);
+	p = FMA(p, s2, 1.0f);
+	return FMA((float)e, 0.69314718f, (2.0f * s) * p);
+}
+
+static int tight_rect(float px, float py, float ca, float cb, float cc, float op, int gx, int gy, int* rminx,
+                      int* rminy, int* rmaxx, int* rmaxy)
+{
+	if (op <= 0.0f) return 0;
+	const float t = orc_log(255.0f * op) + 0.01f;
+	if (t <= 0.0f) return 0;
+	const float det = FMA(-cb, cb, ca * cc);
+	if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return 1;
+	const float rel = (ca * cc) / det;
+	if (!(rel < 1.0e5f)) return 1;
+	const float teff = FMA(t * 4.0e-5f, rel, t) + 0.05f;
+	if (!(teff > 0.0f)) return 1;
+	const float ex = sqrtf((2.0f * teff) * (cc / det)) + 0.01f;
+	const float ey = sqrtf((2.0f * teff) * (ca / det)) + 0.01f;
+	float fx0 = ceilf((px - ex - 15.0f) * 0.0625f), fx1 = floorf((px + ex) * 0.0625f) + 1.0f;
+	float fy0 = ceilf((py - ey - 15.0f) * 0.0625f), fy1 = floorf((py + ey) * 0.0625f) + 1.0f;
+	const float fgx = (float)gx, fgy = (float)gy;
+	fx0 = fx0 > 0.0f ? fx0 : 0.0f; fx0 = fx0 < fgx ? fx0 : fgx;
+	fx1 = fx1 > 0.0f ? fx1 : 0.0f; fx1 = fx1 < fgx ? fx1 : fgx;
+	fy0 = fy0 > 0.0f ? fy0 : 0.0f; fy0 = fy0 < fgy ? fy0 : fgy;
+	fy1 = fy1 > 0.0f ? fy1 : 0.0f; fy1 = fy1 < fgy ? fy1 : fgy;
+	*rminx = imax(*rminx, (int)fx0); *rmaxx = imin(*rmaxx, (int)fx1);
+	*rminy = imax(*rminy, (int)fy0); *rmaxy = imin(*rmaxy, (int)fy1);
+	return *rmaxx > *rminx && *rmaxy > *rminy;
+}
+
+/* tight != 0: gs_tight_rect; tight == 0: the reference's getRect squares.  Returns the number of instances. */
+int64_t orc_rects(int P, int W, int H, const float* means2D, const float* conic_opacity, const int* radii, int tight,
+                  int32_t* rects, uint32_t* tiles)
+{
+	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+	int64_t R = 0;
+	for (int idx = 0; idx < P; idx++) {
+		int r[4] = {0, 0, 0, 0};
+		if (radii[idx] > 0) {
+			getRect(means2D[2 * idx], means2D[2 * idx + 1], radii[idx], gx, gy, &r[0], &r[1], &r[2], &r[3]);
+			const float* co = conic_opacity + 4 * (size_t)idx;
+			if (tight && !tight_rect(means2D[2 * idx], means2D[2 * idx + 1], co[0], co[1], co[2], co[3], gx, gy, &r[0],
+			                         &r[1], &r[2], &r[3]))
+				r[0] = r[1] = r[2] = r[3] = 0;
+		}
+		for (int k = 0; k < 4; k++) rects[4 * (size_t)idx + k] = r[k];
+		const uint32_t n = (uint32_t)((r[2] - r[0]) * (r[3] - r[1]));
+		if (tiles) tiles[idx] = n;
+		R += n;
+	}
+	return R;
+}
+
+/* orc_bin_sort over explicit rects (see orc_rects) */
+void orc_bin_sort_rects(int P, int W, int H, const float* depths, const int32_t* rects, int64_t R,
+                        uint32_t* point_list, uint32_t* ranges)
+{
+	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+	kv_t* kv = (kv_t*)malloc(sizeof(kv_t) * (size_t)(R > 0 ? R : 1));
+	int64_t off = 0;
+	for (int idx = 0; idx < P; idx++) {
+		const int32_t* r = rects + 4 * (size_t)idx;
+		uint32_t dbits;
+		memcpy(&dbits, &depths[idx], 4);
+		for (int y = r[1]; y < r[3]; y++)
+			for (int x = r[0]; x < r[2]; x++) {
+				uint64_t key = (uint64_t)(y * gx + x);
+				key <<= 32;
+				key |= dbits;
+				kv[off].key = key;
+				kv[off].id = (uint32_t)idx;
+				off++;
+			}
+	}
+	qsort(kv, (size_t)R, sizeof(kv_t), kv_cmp);
+	memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)gx * gy);
+	for (int64_t i = 0; i < R; i++) {
+		point_list[i] = kv[i].id;
+		uint32_t currtile = (uint32_t)(kv[i].key >> 32);
+		if (i == 0) ranges[2 * currtile] = 0;
+		else {
+			uint32_t prevtile = (uint32_t)(kv[i - 1].key >> 32);
+			if (currtile != prevtile) {
+				ranges[2 * prevtile + 1] = (uint32_t)i;
+				ranges[2 * currtile] = (uint32_t)i;
+			}
+		}
+		if (i == R - 1) ranges[2 * currtile + 1] = (uint32_t)R;
+	}
+	free(kv);
+}
+
 /* point_list[R], ranges[2T] (start,end) ; tiles with no instance keep (0,0) (rasterizer_impl.cu:313) */
 void orc_bin_sort(int P, int W, int H, const float* means2D, const float* depths, const int* radii,
                   int64_t R, uint32_t* point_list, uint32_t* ranges)

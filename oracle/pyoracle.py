@@ -35,6 +35,7 @@ def lib():
         _LIB.orc_exp.restype = ctypes.c_float
         _LIB.orc_exp.argtypes = [ctypes.c_float]
         _LIB.orc_count_rendered.restype = ctypes.c_int64
+        _LIB.orc_rects.restype = ctypes.c_int64
         _LIB.orc_num_threads.restype = ctypes.c_int
     return _LIB
 
@@ -78,9 +79,13 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh_degree=0,
             shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-            scale_modifier=1.0, prefiltered=False, bg=None, tile_step=1):
+            scale_modifier=1.0, prefiltered=False, bg=None, tile_step=1, tight=False):
     """Returns a dict with the five outputs + radii + every intermediate buffer (the state the
-    reference keeps in geomBuffer / binningBuffer / imgBuffer)."""
+    reference keeps in geomBuffer / binningBuffer / imgBuffer).
+
+    tight=False follows the reference exactly (getRect squares).  tight=True bins into the product's tight rects
+    (gs_tight_rect, restated in gsr_oracle.c:orc_rects): `num_rendered` stays the reference's count, `num_binned`,
+    `tiles_touched`, `point_list`, `ranges`, `n_contrib` describe the shorter lists; images must not change."""
     L = lib()
     means3D = _f32(means3D)
     P = means3D.shape[0]
@@ -108,11 +113,20 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
         raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
     R = int(L.orc_count_rendered(P, _p(st["tiles_touched"])))
     st["num_rendered"] = R
-    st["point_list"] = np.zeros(max(R, 1), np.uint32)[:R]
     st["ranges"] = np.zeros((gx * gy, 2), np.uint32)
-    pl = np.zeros(max(R, 1), np.uint32)
-    L.orc_bin_sort(P, int(W), int(H), _p(st["means2D"]), _p(st["depths"]), _p(st["radii"]),
-                   ctypes.c_int64(R), _p(pl), _p(st["ranges"]))
+    if tight:
+        st["rects"] = np.zeros((P, 4), np.int32)
+        st["tiles_touched"] = np.zeros(P, np.uint32)
+        R = int(L.orc_rects(P, int(W), int(H), _p(st["means2D"]), _p(st["conic_opacity"]), _p(st["radii"]), 1,
+                            _p(st["rects"]), _p(st["tiles_touched"])))
+        pl = np.zeros(max(R, 1), np.uint32)
+        L.orc_bin_sort_rects(P, int(W), int(H), _p(st["depths"]), _p(st["rects"]), ctypes.c_int64(R), _p(pl),
+                             _p(st["ranges"]))
+    else:
+        pl = np.zeros(max(R, 1), np.uint32)
+        L.orc_bin_sort(P, int(W), int(H), _p(st["means2D"]), _p(st["depths"]), _p(st["radii"]),
+                       ctypes.c_int64(R), _p(pl), _p(st["ranges"]))
+    st["num_binned"] = R
     st["point_list"] = pl[:R]
     st["_pl_full"] = pl
     feat = colors_precomp if colors_precomp is not None else st["rgb"]

@@ -103,7 +103,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     L = _C.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/gsrast.h but not exported by libgsrast.so"
-    assert L.gsr_abi_version() == 4
+    assert L.gsr_abi_version() == 5
     L.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
     assert L.gsr_backward_scratch_bytes(ctypes.c_int(1000), ctypes.c_int(5000)) >= 5000 * 49
 

@@ -80,6 +80,49 @@ def test_allreduced_grads_equal_single_device_accumulation(tmp_path, oracle):
         assert float(want.abs().max()) > 0
 
 
+def _worker_chunked(rank, world, port, out_dir):
+    """The overlapped reduction without a GPU: the hook the backward calls per SH chunk is driven by hand."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, M = 1000, 16
+        g = torch.Generator().manual_seed(100 + rank)
+        shapes = dict(means3D=(P, 3), shs=(P, M, 3), opacities=(P, 1), scales=(P, 3), rotations=(P, 4))
+        params = {k: torch.zeros(shp, requires_grad=True) for k, shp in shapes.items()}
+        grads = {k: torch.randn(shp, generator=g) for k, shp in shapes.items()}
+        bucket = parallel.FlatGradBucket(list(params.values()), roles=params)
+        assert bucket.offsets[1] == 0                      # the SH gradients lead the buffer
+        # what the armed backward does: MAIN part writes the small gradients, then SH ranges land chunk by chunk
+        views = dict(zip(params, bucket.views()))
+        for k in ("means3D", "opacities", "scales", "rotations"):
+            views[k].copy_(grads[k])
+        for c, (g0, g1) in enumerate(((0, 256), (256, 512), (512, 768), (768, 1000))):
+            views["shs"][g0:g1].copy_(grads["shs"][g0:g1])
+            bucket._on_sh_chunk(c, g0, g1)
+        for k, p in params.items():
+            p.grad = views[k]                              # autograd adopts the arena slices
+        assert bucket.stats["chunks"] == 4 and bucket._reduced_upto == P * M * 3
+        parallel.allreduce_gaussian_grads(bucket)
+        assert bucket.stats["chunk_bytes"] + bucket.stats["tail_bytes"] == bucket.nbytes   # every element reduced exactly once
+        torch.save({k: p.grad.clone() for k, p in params.items()}, os.path.join(out_dir, f"chunk_rank{rank}.pt"))
+        torch.save(grads, os.path.join(out_dir, f"chunk_in{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_overlapped_reduction_equals_one_allreduce(tmp_path):
+    """FlatGradBucket.arm(overlap_chunks=K): SH chunks reduced from inside the backward + one tail call == the sum over
+    ranks of every gradient, bit for bit, and every element of the flat buffer is reduced exactly once."""
+    world = 2
+    mp.spawn(_worker_chunked, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ins = [torch.load(os.path.join(tmp_path, f"chunk_in{r}.pt")) for r in range(world)]
+    outs = [torch.load(os.path.join(tmp_path, f"chunk_rank{r}.pt")) for r in range(world)]
+    for k in ins[0]:
+        want = ins[0][k] + ins[1][k]
+        assert torch.equal(outs[0][k], want) and torch.equal(outs[1][k], want), k
+
+
 def test_bucket_roundtrip_and_view_sharding_without_process_group():
     ps = [torch.randn(5, 3, requires_grad=True), torch.randn(5, 16, 3, requires_grad=True), torch.randn(5, 1, requires_grad=True)]
     b = parallel.FlatGradBucket(ps)
@@ -119,7 +162,11 @@ def _gpu_worker(rank, world, port, out_dir):
             g = [t.to(dev) for t in scenes.make_output_grads(cam, seed=5)]
             torch.autograd.backward([out[0], out[2], out[3], out[4]], g)
 
-        parallel.render_views_and_reduce(render, parallel.shard_views(cams), bucket)
+        # overlap_chunks=3: the SH stage of the backward runs in Gaussian ranges and each range's slice of the flat
+        # buffer is all-reduced from inside the backward (csrc/torch_binding.cpp -> FlatGradBucket._on_sh_chunk)
+        parallel.render_views_and_reduce(render, parallel.shard_views(cams), bucket, overlap_chunks=3)
+        assert bucket.stats["chunks"] == 3, bucket.stats
+        assert bucket.stats["chunk_bytes"] + bucket.stats["tail_bytes"] == bucket.nbytes
         for p, v in zip(bucket.params, bucket.views()):
             assert p.grad.data_ptr() == v.data_ptr()
         torch.save([p.grad.cpu() for p in bucket.params], os.path.join(out_dir, f"gpu_rank{rank}.pt"))
@@ -129,8 +176,9 @@ def _gpu_worker(rank, world, port, out_dir):
 
 @pytest.mark.gpu
 def test_two_ranks_real_kernels_gradients_born_in_the_bucket(tmp_path):
-    """The N > 1 step with the HIP kernels: each rank renders its camera, the backward writes into the armed flat bucket,
-    ONE all-reduce; result == both views accumulated in one process (fp32 sum of two terms: exact up to commutation)."""
+    """The N > 1 step with the HIP kernels: each rank renders its camera, the backward writes into the armed flat bucket
+    and reduces its SH gradients chunk by chunk while it runs, one tail call finishes the reduction; result == both
+    views accumulated in one process (fp32 sum of two terms: exact up to commutation)."""
     from gaustudio_amd import GaussianRasterizationSettings, GaussianRasterizer
     world = 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

@@ -162,3 +162,42 @@ def test_backward_long_lists_row_flag_regime(oracle, P, sigma):
     assert os_["num_rendered"] > 1024 * r.shape[0] and int((r[:, 1] - r[:, 0]).max()) > 1024
     assert int(os_["n_contrib"].max()) < int((r[:, 1] - r[:, 0]).max())          # some entries are never reached
     _check(oracle, sc, cam, 2, kw, seed=3)
+
+
+@pytest.mark.parametrize("name,P,W,H,D", [("C2", 300_000, 800, 800, 3), ("C3", 1_000_000, 1920, 1080, 3)])
+def test_backward_baseline_configs(oracle, name, P, W, H, D):
+    """BASELINE configs C2 and full-size C3: composite-stage sums inside the rigorous fp32 summation bound, the
+    per-Gaussian stage bit-exact given the same sums, end-to-end gradients within 2e-4 of each tensor's scale."""
+    cam = scenes.make_camera(W, H)
+    sc = scenes.make_scene(P, cam, seed=0)
+    _check(oracle, sc, cam, D, scene_kwargs(sc, True, False))
+
+
+def test_backward_variants_of_the_kernel_agree_bit_for_bit():
+    """composite_bwd carries dead pixels through arithmetically (G masked to 0, 1/(1-0) == 1); the variant that keeps
+    an explicit select on T must give the same bits, and so must a run on the reference's square binning (the extra
+    instances contribute exact zeros)."""
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(640, 360)
+    sc = scenes.make_scene(120000, cam, seed=12)
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam)
+    hs = hip_forward(sc, cam, 3, kw)
+    a = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+    old = _C.get_option("bwd_variant")
+    try:
+        _C.set_option("bwd_variant", 1)
+        b = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+    finally:
+        _C.set_option("bwd_variant", old)
+    for k in GRAD_KEYS + ("acc",):
+        assert torch.equal(a[k], b[k]), k
+    try:
+        _C.set_option("tight_binning", 0)
+        hs0 = hip_forward(sc, cam, 3, kw)
+        c = hip_backward_raw(hs0, sc, cam, 3, kw, grads)
+    finally:
+        _C.set_option("tight_binning", 1)
+    assert hs0["num_binned"] > hs["num_binned"]
+    for k in GRAD_KEYS + ("acc",):
+        assert torch.equal(a[k], c[k]), k

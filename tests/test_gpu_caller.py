@@ -1,0 +1,160 @@
+"""-m gpu: the operator driven exactly the way GauStudio's renderers drive it.
+
+The reference checkout is not present on the GPU box, so the call sequence of
+gaustudio/renderers/base.py:10-63 (BaseRenderer.render) is replayed here step by step -- keyword-constructed
+GaussianRasterizationSettings, a CPU `bg` tensor (vanilla_renderer.py:23, pcd_renderer.py:20), the
+`zeros_like(xyz, requires_grad=True) + 0` screen-space carrier with retain_grad(), `sh_degree = active degree if shs
+is given else 1`, keyword call of the rasterizer with None for the absent inputs, `median[2:3].int()`, `radii > 0`
+-- with the property sets VanillaRenderer.get_gaussians_properties (vanilla_renderer.py:28-51: activated attributes of
+the point cloud, models/vanilla_sg.py:33-37) and PCDRenderer.get_gaussians_properties (pcd_renderer.py:24-36:
+opacity = ones_like(xyz) i.e. [P,3], scales = ones * kernel_size, identity rotations, colors_precomp = rgb / 255)
+produce.  Results are checked against the CPU oracle.  (On a machine that has /root/reference, the import-level test
+in test_api_surface.py additionally loads the unmodified renderer classes against this module.)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gaustudio_amd import scenes
+from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+from util import to_np
+
+pytestmark = pytest.mark.gpu
+
+
+class _Camera:
+    """The attributes of gaustudio.datasets.Camera that BaseRenderer.render reads (datasets/__init__.py:138-183)."""
+
+    def __init__(self, cam: scenes.Cam, dev):
+        self.image_height, self.image_width = cam.height, cam.width
+        self.FoVx, self.FoVy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
+        self.world_view_transform = cam.viewmatrix.to(dev)
+        self.full_proj_transform = cam.projmatrix.to(dev)
+        self.camera_center = cam.campos.to(dev)
+
+
+def _render_like_base_renderer(props, camera, active_sh_degree, bg_color, scaling_modifier=1.0, debug=False):
+    """base.py:10-63, call for call."""
+    xyz, shs, colors_precomp, opacity, scales, rotations, cov3D_precomp = props
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device="cuda") + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(camera.image_height), image_width=int(camera.image_width),
+        tanfovx=math.tan(camera.FoVx * 0.5), tanfovy=math.tan(camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=camera.world_view_transform,
+        projmatrix=camera.full_proj_transform, sh_degree=active_sh_degree if shs is not None else 1,
+        campos=camera.camera_center, prefiltered=False, debug=debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    image, radii, depth, median_map, final_opacity = rasterizer(
+        means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": image, "rendered_depth": depth, "rendered_median_depth": median_map[0:1],
+            "rendered_median_weight": median_map[1:2], "rendered_median_id": median_map[2:3].int(),
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "rendered_final_opacity": final_opacity, "radii": radii}
+
+
+def test_vanilla_renderer_call_pattern_forward_and_backward(oracle):
+    """VanillaRenderer: raw point-cloud attributes -> torch activations -> the op, inside a larger autograd graph;
+    active SH degree 2 of 16 stored coefficients; CPU background; gradients back to the RAW attributes."""
+    dev = torch.device("cuda")
+    cam = scenes.make_camera(320, 200)
+    sc = scenes.make_scene(6000, cam, seed=31, sigma_px_median=2.5)
+    # raw attributes such that the activations reproduce the scene (vanilla_sg.py:33-37: exp / sigmoid / normalize)
+    raw = dict(xyz=sc.means3D.clone(), scale=torch.log(sc.scales), rot=sc.rotations * 1.7,
+               opacity=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)), f_dc=sc.shs[:, :1].clone(), f_rest=sc.shs[:, 1:].clone())
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in raw.items()}
+
+    def properties():   # vanilla_renderer.py:28-51 with convert_SHs_python = compute_cov3D_python = False
+        return (leaves["xyz"], torch.cat((leaves["f_dc"], leaves["f_rest"]), dim=1), None, torch.sigmoid(leaves["opacity"]),
+                torch.exp(leaves["scale"]), torch.nn.functional.normalize(leaves["rot"]), None)
+
+    bg = torch.tensor([0, 0, 0], dtype=torch.float32)                  # CPU tensor, as the renderer builds it
+    pkg = _render_like_base_renderer(properties(), _Camera(cam, dev), active_sh_degree=2, bg_color=bg)
+    assert pkg["rendered_median_id"].dtype == torch.int32 and pkg["visibility_filter"].dtype == torch.bool
+    grads = [g.to(dev) for g in scenes.make_output_grads(cam, seed=3)]
+    median_full = torch.cat([pkg["rendered_median_depth"], pkg["rendered_median_weight"],
+                             torch.zeros_like(pkg["rendered_median_depth"])], 0)
+    loss = (pkg["render"] * grads[0]).sum() + (pkg["rendered_depth"] * grads[1]).sum() + \
+           (median_full * grads[2]).sum() + (pkg["rendered_final_opacity"] * grads[3]).sum()
+    loss.backward()
+
+    # oracle on the activated values (computed by torch in float32, exactly what the op received)
+    with torch.no_grad():
+        act = dict(means3D=leaves["xyz"], shs=torch.cat((leaves["f_dc"], leaves["f_rest"]), 1),
+                   opacities=torch.sigmoid(leaves["opacity"]), scales=torch.exp(leaves["scale"]),
+                   rotations=torch.nn.functional.normalize(leaves["rot"]))
+        act = {k: v.cpu().numpy() for k, v in act.items()}
+    st = oracle.forward(act["means3D"], act["opacities"], cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
+                        cam.campos.numpy(), cam.width, cam.height, cam.tanfovx, cam.tanfovy, sh_degree=2,
+                        shs=act["shs"], scales=act["scales"], rotations=act["rotations"], tight=True)
+    assert np.array_equal(to_np(pkg["render"]), st["color"]) and np.array_equal(to_np(pkg["rendered_depth"]), st["depth"])
+    assert np.array_equal(to_np(pkg["rendered_median_depth"]), st["median"][0:1])
+    assert np.array_equal(to_np(pkg["rendered_median_id"]), st["median"][2:3].astype(np.int32))
+    assert np.array_equal(to_np(pkg["radii"]), st["radii"]) and np.array_equal(to_np(pkg["visibility_filter"]), st["radii"] > 0)
+    gm = grads[2].cpu().numpy().copy()
+    gm[2] = 0                                                       # the loss does not touch the id channel
+    bw = oracle.backward(st, grads[0].cpu().numpy(), grads[1].cpu().numpy(), gm, grads[3].cpu().numpy())
+    vp = pkg["viewspace_points"].grad                               # retained on the non-leaf carrier (densification statistics)
+    assert vp is not None and np.abs(to_np(vp) - bw["dL_dmeans2D"]).max() <= 2e-4 * np.abs(bw["dL_dmeans2D"]).max()
+    assert np.abs(to_np(leaves["xyz"].grad) - bw["dL_dmeans3D"]).max() <= 2e-4 * np.abs(bw["dL_dmeans3D"]).max()
+    # chain rules of the activations, applied by torch to the op's gradients
+    sh_g = np.concatenate([to_np(leaves["f_dc"].grad), to_np(leaves["f_rest"].grad)], 1)
+    assert np.abs(sh_g - bw["dL_dsh"]).max() <= 2e-4 * np.abs(bw["dL_dsh"]).max()
+    assert not sh_g[:, 9:].any()                                    # coefficients above the active degree get zero gradient
+    want_scale = bw["dL_dscales"] * act["scales"]
+    assert np.abs(to_np(leaves["scale"].grad) - want_scale).max() <= 2e-4 * np.abs(want_scale).max()
+    op = act["opacities"]
+    want_op = bw["dL_dopacity"] * op * (1 - op)
+    assert np.abs(to_np(leaves["opacity"].grad) - want_op).max() <= 2e-4 * np.abs(want_op).max()
+    assert leaves["rot"].grad is not None and torch.isfinite(leaves["rot"].grad).all()
+
+
+def test_pcd_renderer_call_pattern(oracle):
+    """PCDRenderer: colours precomputed, shs=None with sh_degree 1, opacity = ones_like(xyz) ([P,3]: the op reads its
+    first P values), scales = ones * kernel_size, identity rotations; white background on the CPU."""
+    dev = torch.device("cuda")
+    cam = scenes.make_camera(256, 192)
+    sc = scenes.make_scene(20000, cam, seed=33)
+    xyz = sc.means3D.to(dev)
+    rgb = (torch.rand(xyz.shape[0], 3, generator=torch.Generator().manual_seed(1)) * 255).floor().to(dev)
+    for kernel_size in (0.0, 0.01):
+        opacity = torch.ones_like(xyz, device=xyz.device)
+        scales = torch.ones_like(xyz, device=xyz.device) * kernel_size
+        rotations = torch.zeros((xyz.shape[0], 4), device=xyz.device)
+        rotations[:, 0] = 1
+        rotations = torch.nn.functional.normalize(rotations)
+        props = (xyz, None, rgb / 255, opacity, scales, rotations, None)
+        bg = torch.tensor([1, 1, 1], dtype=torch.float32)
+        with torch.no_grad():
+            pkg = _render_like_base_renderer(props, _Camera(cam, dev), active_sh_degree=3, bg_color=bg)
+        st = oracle.forward(sc.means3D.numpy(), np.ones((xyz.shape[0], 1), np.float32), cam.viewmatrix.numpy(),
+                            cam.projmatrix.numpy(), cam.campos.numpy(), cam.width, cam.height, cam.tanfovx, cam.tanfovy,
+                            sh_degree=1, colors_precomp=to_np(rgb / 255), scales=to_np(scales), rotations=to_np(rotations),
+                            bg=bg.numpy(), tight=True)
+        assert np.array_equal(to_np(pkg["render"]), st["color"])
+        assert np.array_equal(to_np(pkg["rendered_depth"]), st["depth"])
+        assert np.array_equal(to_np(pkg["rendered_final_opacity"]), st["opacity"])
+        assert np.array_equal(to_np(pkg["rendered_median_id"]), st["median"][2:3].astype(np.int32))
+        assert np.array_equal(to_np(pkg["radii"]), st["radii"]) and int(pkg["visibility_filter"].sum()) > 1000
+
+
+def test_renderer_debug_flag_and_mark_visible():
+    """debug=True (the renderers' `debug` option) runs the same call with per-stage synchronisation and dumps; the
+    rasterizer's markVisible is what gaustudio's densification code calls on the same settings object."""
+    dev = torch.device("cuda")
+    cam = scenes.make_camera(128, 96)
+    sc = scenes.make_scene(3000, cam, seed=35)
+    props = (sc.means3D.to(dev), sc.shs.to(dev), None, sc.opacities.to(dev), sc.scales.to(dev), sc.rotations.to(dev), None)
+    bg = torch.tensor([0, 0, 0], dtype=torch.float32)
+    with torch.no_grad():
+        a = _render_like_base_renderer(props, _Camera(cam, dev), 3, bg, debug=False)
+        b = _render_like_base_renderer(props, _Camera(cam, dev), 3, bg, debug=True)
+    for k in ("render", "rendered_depth", "rendered_median_depth", "rendered_final_opacity", "radii"):
+        assert torch.equal(a[k], b[k]), k

@@ -60,8 +60,8 @@ def test_large_footprints_cooperative_binning(oracle):
 
 @pytest.mark.parametrize("P,lo,hi", [(2500, 256, 4096), (12000, 4096, 16384), (100000, 16384, 1 << 30)])
 def test_long_tile_lists_lds_and_global_sort(oracle, P, lo, hi):
-    """Per-tile lists in each regime of tile_sort: <= 4096 keys (bitonic network in LDS) and the per-tile
-    radix sort beyond (12 k and 93 k keys per tile)."""
+    """Per-tile lists in each regime of the sort: 2 k keys (past the 1024-key register network: bucketed path with
+    register-resident keys), 10 k and 87 k keys per tile (bucketed / radix path streaming from memory)."""
     cam = scenes.make_camera(48, 32)
     sc = scenes.make_scene(P, cam, seed=13, sigma_px_median=6.0)
     kw = scene_kwargs(sc, True, False)
@@ -105,7 +105,8 @@ def test_all_culled_and_empty(oracle):
     assert hs["num_rendered"] == 0 and int(hs["radii"].abs().sum()) == 0
     for k in ("color", "depth", "median", "opacity"):
         assert np.array_equal(to_np(hs[k]), os_[k]), k
-    # P == 0 (rasterize_points.cu:84): zero images, rendered = 0, empty buffers
+    # P == 0 (rasterize_points.cu:67-84): nothing is launched, the torch::full(0.0) images come back as they are
+    # (all three median channels 0: the 15.0 sentinel only appears when the render kernel runs), rendered = 0
     e = torch.Tensor([])
     dev = "cuda"
     out = _C.rasterize_gaussians(torch.zeros(3), torch.zeros(0, 3, device=dev), e, torch.zeros(0, 1, device=dev),
@@ -113,7 +114,8 @@ def test_all_culled_and_empty(oracle):
                                  cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.tanfovx, cam.tanfovy, cam.height,
                                  cam.width, torch.zeros(0, 16, 3, device=dev), 3, cam.campos.to(dev), False, False)
     assert out[0] == 0 and out[1].shape == (3, 60, 100) and float(out[1].abs().sum()) == 0.0
-    assert float(out[3][0].min()) == 15.0 and out[5].numel() == 0
+    assert float(out[3].abs().sum()) == 0.0 and float(out[2].abs().sum()) == 0.0 and float(out[4].abs().sum()) == 0.0
+    assert out[5].numel() == 0
 
 
 def test_mark_visible(oracle):
@@ -176,9 +178,96 @@ def test_single_tile_list_lengths_around_the_sort_size_classes(oracle, P):
     means = sc.means3D.clone()
     means[:, 0] *= 0.5
     means[:, 1] *= 0.5                                       # well inside the frame
-    sc = sc._replace(means3D=means.contiguous())
+    # opaque enough that every Gaussian reaches alpha >= 1/255 at its nearest pixel: none is pruned by the tight binning
+    sc = sc._replace(means3D=means.contiguous(), opacities=torch.full_like(sc.opacities, 0.9))
     kw = scene_kwargs(sc, True, False)
     os_ = oracle_forward(oracle, sc, cam, 1, kw)
-    assert os_["num_rendered"] == P and os_["ranges"].shape[0] == 1
+    assert os_["num_rendered"] == P and os_["num_binned"] == P and os_["ranges"].shape[0] == 1
     hs = hip_forward(sc, cam, 1, kw)
     compare_forward_exact(hs, os_)
+
+
+@pytest.mark.parametrize("name,P,W,H,D", [("C2", 300_000, 800, 800, 3), ("C3", 1_000_000, 1920, 1080, 3),
+                                            ("C3-D0", 1_000_000, 1920, 1080, 0)])
+def test_baseline_configs_bit_exact_vs_oracle(oracle, name, P, W, H, D):
+    """BASELINE configs C2 and the full-size headline C3 (SH degree 3 and 0): every output and every intermediate of
+    the HIP path equals the CPU oracle's to the bit -- not just within the 1e-5 of the north star."""
+    hs, os_ = _run(oracle, P, W, H, D)
+    assert hs["num_binned"] < hs["num_rendered"]          # the tight binning dropped instances, the images did not notice
+
+
+def _with_options(**opts):
+    from contextlib import contextmanager
+    from gaustudio_amd import _C
+
+    @contextmanager
+    def cm():
+        old = {k: _C.get_option(k) for k in opts}
+        try:
+            for k, v in opts.items():
+                _C.set_option(k, v)
+            yield
+        finally:
+            for k, v in old.items():
+                _C.set_option(k, v)
+    return cm()
+
+
+@pytest.mark.parametrize("P,W,H,D", [(20000, 400, 400, 3), (1_000_000, 1920, 1080, 3)], ids=["small", "C3"])
+def test_culling_and_tight_binning_change_no_bit(P, W, H, D):
+    """A/B against the library's own un-optimised configuration: with the wave-level box cull and the pcut pre-test
+    disabled (every wave evaluates every staged instance) and with the reference's square getRect binning, the images,
+    radii and num_rendered are bit-identical -- the optimisations only remove work."""
+    cam = scenes.make_camera(W, H)
+    sc = scenes.make_scene(P, cam, seed=0)
+    kw = scene_kwargs(sc, True, False)
+    a = hip_forward(sc, cam, D, kw)
+    with _with_options(cull=0):
+        b = hip_forward(sc, cam, D, kw)
+    with _with_options(tight_binning=0):
+        c = hip_forward(sc, cam, D, kw)
+    with _with_options(tight_binning=0, cull=0):
+        d = hip_forward(sc, cam, D, kw)
+    assert c["num_binned"] == c["num_rendered"] == a["num_rendered"] and a["num_binned"] < a["num_rendered"]
+    for other in (b, c, d):
+        assert other["num_rendered"] == a["num_rendered"]
+        for k in ("color", "depth", "median", "opacity", "radii", "final_T"):
+            assert torch.equal(a[k], other[k]), k
+    for k in ("point_list", "ranges", "n_contrib"):
+        assert torch.equal(a[k], b[k]), k          # same binning, only the cull differs
+
+
+def test_speculative_launch_overflow_is_retried():
+    """The kernels behind the instance count are enqueued against the remembered binning capacity before the host
+    has read the count; when the capacity is too small (forced here) they leave without touching memory and the host
+    re-allocates and re-launches.  Results must be those of the ordinary path; so must a capacity that is too small
+    only for the long-list sort (a tile list > 1024 keys after a frame without one)."""
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(320, 240)
+    sc = scenes.make_scene(40000, cam, seed=3, sigma_px_median=2.5)
+    kw = scene_kwargs(sc, True, False)
+    with _with_options(speculative=0):
+        want = hip_forward(sc, cam, 3, kw)
+    _C.set_option("bin_capacity", 1000)                      # far below num_binned
+    got = hip_forward(sc, cam, 3, kw)
+    assert _C.get_option("bin_capacity") >= want["num_binned"]
+    again = hip_forward(sc, cam, 3, kw)                      # now speculates successfully
+    for g in (got, again):
+        for k in ("color", "depth", "median", "opacity", "radii", "point_list", "ranges", "n_contrib", "final_T"):
+            assert torch.equal(want[k], g[k]), k
+    # a frame with a > 1024-key tile list right after frames without one: the speculative launch lacks the radix path
+    cam2 = scenes.make_camera(48, 32)
+    sc2 = scenes.make_scene(12000, cam2, seed=13, sigma_px_median=6.0)
+    kw2 = scene_kwargs(sc2, True, False)
+    with _with_options(speculative=0):
+        want2 = hip_forward(sc2, cam2, 0, kw2)
+    hip_forward(sc, cam, 3, kw)                              # resets the "long lists" memory
+    got2 = hip_forward(sc2, cam2, 0, kw2)
+    for k in ("color", "depth", "median", "opacity", "point_list", "n_contrib"):
+        assert torch.equal(want2[k], got2[k]), k
+
+
+def test_device_selftest():
+    """v_rcp_f32(1.0) == 1.0 on this device: composite_bwd carries dead pixels through without a select on T."""
+    from gaustudio_amd import _C
+    assert _C.selftest() == 3

@@ -6,7 +6,8 @@ Tolerance (BASELINE.json north_star): 1e-5 abs on rendered RGB / depth / opacity
 implementation use different exp() (ocml expf vs the explicit polynomial) and different FMA contraction, so
 a pixel whose alpha / T / power sits within ~1e-7 of a threshold (alpha < 1/255, T < 1e-4, power > 0) can
 take the other branch: such "flipped" pixels change by up to alpha*T*c ~ 4e-3.  They are counted and
-bounded: at most 2e-5 of the values of an output may exceed 1e-5, and none may exceed one alpha-quantum.
+bounded: at most twice the count measured and committed in profiles/r02_parity.json may exceed 1e-5 (depth included, in
+scene units, no rescaling), and none may exceed one alpha-quantum.
 """
 import glob
 import os
@@ -27,46 +28,88 @@ REF_FILES = sorted(glob.glob(os.path.join(GOLD, "ref_*.npz")))
 GRAD_KEYS = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
 
 
-def _image_close(name, a, b, quantum, flip_frac=2e-5):
+PARITY_JSON = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_parity.json")
+
+
+def _recorded_flips(config):
+    """Flip counts measured on an MI355X and committed (profiles/r02_parity.json, written by this test with
+    GSR_DUMP_PARITY=1): the number of values of each output that differ from the reference kernels by more than 1e-5."""
+    import json
+    path = os.path.normpath(PARITY_JSON)
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("configs", {}).get(config)
+
+
+def _image_close(name, a, b, quantum, recorded):
+    """1e-5 absolute on every value except threshold flips, which are COUNTED: at most twice the committed count
+    (profiles/r02_parity.json; a blanket 2e-5 of the values when no record exists) and never more than one alpha
+    quantum."""
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))
     n_bad = int((d > 1e-5).sum())
-    assert n_bad <= max(2, flip_frac * d.size), f"{name}: {n_bad} of {d.size} values differ by more than 1e-5 (max {d.max():.3e})"
+    budget = max(4, 2 * recorded[name]["over_1e-5"]) if recorded and name in recorded else max(2, 2e-5 * d.size)
+    assert n_bad <= budget, f"{name}: {n_bad} of {d.size} values differ by more than 1e-5 (budget {budget}, max {d.max():.3e})"
     assert d.max() <= quantum, f"{name}: max deviation {d.max():.3e} exceeds one alpha quantum {quantum:.3e}"
-    return n_bad, float(d.max())
+    return {"over_1e-5": n_bad, "values": int(d.size), "max_abs": float(d.max())}
 
 
-def _compare(hs, ref, depth_scale):
+def _compare(hs, ref, config):
+    recorded = _recorded_flips(config)
     assert hs["num_rendered"] == ref["num_rendered"]
     radii = to_np(hs["radii"])
     assert (radii != ref["radii"].numpy()).sum() <= 1e-5 * radii.size
-    stats = {}
-    stats["color"] = _image_close("color", to_np(hs["color"]), ref["color"].numpy(), 6e-3)
-    stats["opacity"] = _image_close("opacity", to_np(hs["opacity"]), ref["opacity"].numpy(), 6e-3)
-    stats["depth"] = _image_close("depth", to_np(hs["depth"]) / depth_scale, ref["depth"].numpy() / depth_scale, 6e-3)
+    stats = {"radii_differ": int((radii != ref["radii"].numpy()).sum())}
+    stats["color"] = _image_close("color", to_np(hs["color"]), ref["color"].numpy(), 6e-3, recorded)
+    stats["opacity"] = _image_close("opacity", to_np(hs["opacity"]), ref["opacity"].numpy(), 6e-3, recorded)
+    # depth in scene units (2 .. 20 here), 1e-5 ABSOLUTE like colour; a flipped contributor moves it by alpha*T*depth
+    stats["depth"] = _image_close("depth", to_np(hs["depth"]), ref["depth"].numpy(), 6e-3 * 20.0, recorded)
     mid_a, mid_b = to_np(hs["median"])[2], ref["median"].numpy()[2]
-    assert (mid_a != mid_b).sum() <= max(2, 2e-5 * mid_a.size), "median id"
+    stats["median_id_differ"] = int((mid_a != mid_b).sum())
+    assert stats["median_id_differ"] <= max(2, 2e-5 * mid_a.size), "median id"
     return stats
 
 
-@pytest.mark.skipif(not ref_util.available(), reason="oracle/_ref/libgsref.so not built")
+def _dump_parity(config, stats):
+    """GSR_DUMP_PARITY=1: merge the measured counts into gpurun_out/r02_parity.json (copied to profiles/ by hand)."""
+    if os.environ.get("GSR_DUMP_PARITY") != "1":
+        return
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out", "r02_parity.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    data = json.load(open(out)) if os.path.exists(out) else {"what": "HIP path vs the reference's own kernels (oracle/_ref/libgsref.so) "
+                                                              "on an MI355X: values differing by more than 1e-5 abs", "configs": {}}
+    data["configs"][config] = stats
+    json.dump(data, open(out, "w"), indent=1, sort_keys=True)
+
+
 @pytest.mark.parametrize("P,W,H,D", [(10000, 400, 400, 0), (300000, 800, 800, 3), (1000000, 1920, 1080, 3)],
                          ids=["C1", "C2", "C3"])
-def test_hip_vs_reference_kernels_at_baseline_configs(P, W, H, D):
-    """BASELINE configs C1, C2 and the full-size headline C3, forward and backward."""
+def test_hip_vs_reference_kernels_at_baseline_configs(request, P, W, H, D):
+    """BASELINE configs C1, C2 and the full-size headline C3, forward and backward, against the reference's own kernels.
+    oracle/_ref/libgsref.so is built in the dev container (oracle/build_ref.sh) and travels with the snapshot: its
+    absence on a GPU box is a FAILURE, not a skip -- this comparison is what pins the parity claim."""
+    if not ref_util.available():
+        pytest.fail("oracle/_ref/libgsref.so is missing: run oracle/build_ref.sh in the dev container (needs "
+                    "/root/reference) before shipping the tree to the GPU box")
+    config = request.node.callspec.id
     cam = scenes.make_camera(W, H)
     sc = scenes.make_scene(P, cam, seed=0)
     kw = scene_kwargs(sc, True, False)
     grads = scenes.make_output_grads(cam)
     ref = ref_util.run(sc, cam, D, kw, grads)
     hs = hip_forward(sc, cam, D, kw)
-    _compare(hs, ref, depth_scale=20.0)
+    stats = _compare(hs, ref, config)
     hb = hip_backward_raw(hs, sc, cam, D, kw, grads)
+    stats["grads"] = {}
     for k in GRAD_KEYS:
         a = to_np(hb[k]); b = ref[k].numpy().reshape(a.shape)
         scale = np.abs(b).max()
+        stats["grads"][k] = {"max_rel": float(np.abs(a - b).max() / max(scale, 1e-30)), "mean_rel": float(np.abs(a - b).mean() / max(scale, 1e-30))}
         # both sides sum thousands of fp32 terms per Gaussian in different orders, plus rare branch flips
         assert np.abs(a - b).max() <= 5e-4 * scale, (k, float(np.abs(a - b).max()), float(scale))
         assert np.abs(a - b).mean() <= 1e-6 * scale, k
+    _dump_parity(config, stats)
 
 
 @pytest.mark.parametrize("path", REF_FILES, ids=[os.path.basename(p)[:-4] for p in REF_FILES])
@@ -108,11 +151,12 @@ def test_full_size_c3_properties():
     assert float(hs["color"][:, empty].abs().sum()) == 0.0 and float(hs["opacity"][0][empty].abs().sum()) == 0.0
     assert bool((hs["median"][0][empty] == 15.0).all())
     r = hs["ranges"].long()
-    assert int(r[0, 0]) == 0 and int(r[-1, 1]) == hs["num_rendered"] and bool((r[1:, 0] == r[:-1, 1]).all())
+    assert int(r[0, 0]) == 0 and int(r[-1, 1]) == hs["num_binned"] and bool((r[1:, 0] == r[:-1, 1]).all())
+    assert hs["num_binned"] < hs["num_rendered"]                                       # tight binning vs the reference's count
     pl = hs["point_list"].long()
     depth_bits = hs["depths"].view(torch.int32).long()[pl]
     key = depth_bits * (1 << 32) + pl
     tile_of = torch.repeat_interleave(torch.arange(r.shape[0], device=pl.device), (r[:, 1] - r[:, 0]))
     same_tile = tile_of[1:] == tile_of[:-1]
     assert bool((key[1:][same_tile] > key[:-1][same_tile]).all()), "per-tile lists must be strictly (depth, id) sorted"
-    assert int(hs["tiles_touched"].long().sum()) == hs["num_rendered"]
+    assert int(hs["tiles_touched"].long().sum()) == hs["num_binned"]

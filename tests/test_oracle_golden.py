@@ -115,3 +115,69 @@ def test_oracle_gradients_match_float64_autograd(oracle, D):
     for k, v in ref.items():
         o = torch.tensor(bw[k]).double().reshape(v.shape)
         assert float((o - v).abs().max()) <= 2e-5 * float(v.abs().max()), k
+
+
+@pytest.mark.parametrize("case", ["c1", "ragged", "huge", "dense", "aniso_lowop", "op1", "op_threshold", "ring"])
+def test_tight_binning_is_invisible_in_the_oracle(oracle, case):
+    """The product bins Gaussians into a tight sub-rect of the reference's getRect square (gs_tight_rect, restated in
+    gsr_oracle.c:orc_rects).  On the CPU, for the reference's binning (tight=False) and the tight one: every image,
+    final_T and radii are bit-identical, num_rendered keeps the reference's definition, and per tile the tight list is
+    the reference list minus instances that contribute to no pixel (an order-preserving sub-sequence holding every
+    contributor)."""
+    import torch
+    from gaustudio_amd import scenes
+    from util import oracle_forward, scene_kwargs
+    D, mod = 3, 1.0
+    if case == "c1":
+        cam = scenes.make_camera(400, 400); sc = scenes.make_scene(10000, cam, seed=0)
+    elif case == "ragged":
+        cam = scenes.make_camera(401, 399); sc = scenes.make_scene(3000, cam, seed=5, sigma_px_median=2.5)
+    elif case == "huge":
+        cam = scenes.make_camera(512, 384); sc = scenes.make_scene(600, cam, seed=11, sigma_px_median=60.0); D = 1
+    elif case == "dense":
+        cam = scenes.make_camera(64, 64); sc = scenes.make_scene(5000, cam, seed=4, sigma_px_median=8.0); mod = 1.7
+    elif case in ("aniso_lowop", "op1", "op_threshold"):
+        cam = scenes.make_camera(256, 256); sc = scenes.make_scene(8000, cam, seed=9, sigma_px_median=3.0)
+        g = torch.Generator().manual_seed(5)
+        op = {"aniso_lowop": torch.rand(8000, 1, generator=g).pow(4).clamp(1e-4, 1.0),
+              "op1": torch.ones(8000, 1),
+              "op_threshold": torch.full((8000, 1), 1 / 255.0) + (torch.rand(8000, 1, generator=g) - 0.5) * 4e-6}[case]
+        sc = sc._replace(scales=(sc.scales * torch.tensor([10.0, 0.05, 1.0])).contiguous(), opacities=op.contiguous())
+        D = 2
+    else:
+        sc = scenes.make_ball_scene(20000, radius=3.0, seed=5, sigma=0.03); cam = scenes.ring_cameras(3, 320, 208, radius=8.0)[1]
+    kw = scene_kwargs(sc, True, False)
+    a = oracle_forward(oracle, sc, cam, D, kw, scale_modifier=mod, tight=False)
+    b = oracle_forward(oracle, sc, cam, D, kw, scale_modifier=mod, tight=True)
+    for k in ("color", "depth", "median", "opacity", "final_T", "radii", "means2D", "conic_opacity", "rgb"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["num_rendered"] == b["num_rendered"] == a["num_binned"] and b["num_binned"] <= a["num_binned"]
+    assert int(b["tiles_touched"].sum()) == b["num_binned"]
+    if case != "op1":
+        assert b["num_binned"] < a["num_binned"]
+    # per tile: sub-sequence + every contributor kept.  A contributor of pixel p is a list entry that passes the
+    # alpha test at p before p's last_contributor; the union over the tile's pixels must survive.
+    W, H = cam.width, cam.height
+    gx = (W + 15) // 16
+    T = a["ranges"].shape[0]
+    rng = np.random.default_rng(0)
+    for t in rng.choice(T, size=min(T, 40), replace=False):
+        la = a["point_list"][a["ranges"][t, 0]:a["ranges"][t, 1]]
+        lb = b["point_list"][b["ranges"][t, 0]:b["ranges"][t, 1]]
+        keep = np.isin(la, lb)
+        assert np.array_equal(la[keep], lb), "tight list is not an order-preserving sub-sequence"
+        if len(la) == 0:
+            continue
+        tx, ty = t % gx, t // gx
+        xs = np.arange(tx * 16, min(tx * 16 + 16, W), dtype=np.float32)
+        ys = np.arange(ty * 16, min(ty * 16 + 16, H), dtype=np.float32)
+        px, py = np.meshgrid(xs, ys)
+        dropped = la[~keep]
+        if len(dropped) == 0:
+            continue
+        co = a["conic_opacity"][dropped].astype(np.float64)
+        dx = a["means2D"][dropped, 0][:, None, None].astype(np.float64) - px[None]
+        dy = a["means2D"][dropped, 1][:, None, None].astype(np.float64) - py[None]
+        power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+        alpha = co[:, 3, None, None] * np.exp(np.minimum(power, 0.0))
+        assert not ((power <= 0) & (alpha >= 1 / 255.0)).any(), "a dropped instance could have contributed"

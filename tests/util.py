@@ -27,12 +27,15 @@ def scene_kwargs(sc, use_sh=True, use_cov=False):
     return kw
 
 
-def oracle_forward(po, sc, cam, D, kw, scale_modifier=1.0, bg=None, prefiltered=False):
+def oracle_forward(po, sc, cam, D, kw, scale_modifier=1.0, bg=None, prefiltered=False, tight=True):
+    """tight=True: the oracle bins into the product's tight rects (oracle/gsr_oracle.c:orc_rects), so that lists,
+    ranges and n_contrib are comparable bit for bit; tests/test_oracle_golden.py proves on the CPU that this changes
+    no image bit with respect to tight=False, the reference's own binning."""
     npk = {k: v.numpy() for k, v in kw.items()}
     return po.forward(sc.means3D.numpy(), sc.opacities.numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(),
                       cam.campos.numpy(), cam.width, cam.height, cam.tanfovx, cam.tanfovy, sh_degree=D,
                       scale_modifier=scale_modifier, bg=None if bg is None else bg.numpy(),
-                      prefiltered=prefiltered, **npk)
+                      prefiltered=prefiltered, tight=tight, **npk)
 
 
 def hip_forward(sc, cam, D, kw, scale_modifier=1.0, bg=None, prefiltered=False, debug=False, device="cuda"):
@@ -51,7 +54,10 @@ def hip_forward(sc, cam, D, kw, scale_modifier=1.0, bg=None, prefiltered=False, 
               geom=geom, binning=binning, img=img)
     st.update(_C.inspect_geometry(geom, radii) if radii.numel() else {})
     if radii.numel():
-        st["point_list"], st["ranges"] = _C.inspect_binning(binning, img, R, cam.width, cam.height)
+        cnt = _C.inspect_counts(img, cam.width, cam.height)
+        assert cnt["num_rendered"] == R
+        st["num_binned"] = cnt["num_binned"]
+        st["point_list"], st["ranges"] = _C.inspect_binning(binning, img, cnt["num_binned"], cam.width, cam.height)
         st["final_T"], st["n_contrib"] = _C.inspect_image(img, cam.width, cam.height)
     return st
 
@@ -75,7 +81,8 @@ def compare_forward_exact(hs, os_, vis_only=True):
     """HIP state vs oracle state: every output and every intermediate must match to the bit."""
     radii = to_np(hs["radii"])
     assert_bits_equal(radii, os_["radii"], "radii")
-    assert hs["num_rendered"] == os_["num_rendered"], (hs["num_rendered"], os_["num_rendered"])
+    assert hs["num_rendered"] == os_["num_rendered"], (hs["num_rendered"], os_["num_rendered"])   # reference-defined
+    assert hs["num_binned"] == os_["num_binned"], (hs["num_binned"], os_["num_binned"])
     vis = radii > 0
     for k in ("means2D", "depths", "conic_opacity", "rgb", "clamped", "tiles_touched"):
         a = to_np(hs[k]); b = os_[k]
