@@ -5,7 +5,7 @@
 //                    four DPP steps and added to the instance's LDS row; each (tile, Gaussian) instance leaves one
 //                    plain-stored 48-B row in Gaussian-major order -- no global atomics
 //                    (replaces backward.cu:415-610 renderCUDA: 11-12 atomicAdd per (pixel, Gaussian))
-//   gaussian_scan    exclusive scan of tiles_touched -> row offsets (run by the FORWARD in its read-back bubble)
+//   (row offsets goff: per-block sums in preprocess_fwd + tile_scan block 1 + goff_apply, gsr_kernels_fwd.hip)
 //   preprocess_bwd   one lane per Gaussian: fixed-order sum of its rows (fetched wave-cooperatively through LDS),
 //                    dL/dconic -> dL/dcov3D, dL/dmean (projection + depth), cov3D -> scale / raw-quaternion
 //                    backward, activation chain rules of the raw interface

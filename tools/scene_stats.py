@@ -12,7 +12,7 @@ P, W, H, D = 1_000_000, 1920, 1080, 3
 cam = scenes.make_camera(W, H); sc = scenes.make_scene(P, cam, seed=0)
 hs = hip_forward(sc, cam, D, scene_kwargs(sc, True, False))
 r = hs["ranges"].long(); L = (r[:, 1] - r[:, 0])
-print("R", hs["num_rendered"], "tiles", L.numel(), "len mean", float(L.float().mean()), "max", int(L.max()),
+print("R", hs["num_rendered"], "binned", hs["num_binned"], "tiles", L.numel(), "len mean", float(L.float().mean()), "max", int(L.max()),
       "p50/p90/p99", [int(torch.quantile(L.float(), q)) for q in (0.5, 0.9, 0.99)])
 nc = hs["n_contrib"].long(); fT = hs["final_T"]
 print("n_contrib mean", float(nc.float().mean()), "max", int(nc.max()), "saturated pixels", float((fT < 1e-3).float().mean()))
@@ -20,7 +20,7 @@ gx = (W + 15) // 16
 # per tile: traversal needed = max n_contrib over tile (block terminates when all done or list ends)
 ncpad = torch.zeros(((H + 15) // 16) * 16, gx * 16, dtype=torch.long, device=nc.device); ncpad[:H, :W] = nc
 tmax = ncpad.view(-1, 16, gx, 16).permute(0, 2, 1, 3).reshape(-1, 256).max(1).values
-print("sum over tiles of max n_contrib / R:", float(tmax.sum()) / hs["num_rendered"])
+print("sum over tiles of max n_contrib / R:", float(tmax.sum()) / hs["num_binned"])
 g = torch.Generator().manual_seed(0)
 tiles = torch.randperm(L.numel(), generator=g)[:200]
 xy = hs["means2D"]; co = hs["conic_opacity"]; pl = hs["point_list"].long()
