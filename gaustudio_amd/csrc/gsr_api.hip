@@ -359,6 +359,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	uint32_t* tile_count = reinterpret_cast<uint32_t*>(img + il.tile_count);
 	float* final_T = reinterpret_cast<float*>(img + il.final_T);
 	uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + il.n_contrib);
+	uint32_t* med_pos = reinterpret_cast<uint32_t*>(img + il.med_pos);
 
 	Timer tm(prof_next(g_fwd_log), s);
 	// camera block + control words + tile counters
@@ -430,7 +431,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 		}
 		tm.mark();
 		launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
-		                     out_opacity, final_T, n_contrib, ctl, cap, with_long ? 0xffffffffu : GSR_SORT_LDS_MAX, nocull, s);
+		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap, with_long ? 0xffffffffu : GSR_SORT_LDS_MAX, nocull, s);
 		STAGE_CHECK("composite_fwd", debug, s);
 		tm.mark();
 		return 0;
@@ -550,6 +551,7 @@ static int backward_impl(int parts, int sh_g0, int sh_g1, int P, int D, int M, i
 	const uint2* ranges = reinterpret_cast<const uint2*>(image_buffer + il.ranges);
 	const float* final_T = reinterpret_cast<const float*>(image_buffer + il.final_T);
 	const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + il.n_contrib);
+	const uint32_t* med_pos = reinterpret_cast<const uint32_t*>(image_buffer + il.med_pos);
 	const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + bl.point_list);
 	const BwdLayout wl((size_t)P, (size_t)(R > 0 ? R : 0));
 	const uint32_t* goff = reinterpret_cast<const uint32_t*>(geom_buffer + gl.goff);   // scanned by the forward
@@ -593,7 +595,7 @@ static int backward_impl(int parts, int sh_g0, int sh_g1, int P, int D, int M, i
 
 	tm.mark();
 	if (R > 0) {
-		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, final_T, n_contrib, dL_dpix,
+		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, final_T, n_contrib, med_pos, dL_dpix,
 		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags, bwd_variant(s), s);
 		STAGE_CHECK("composite_bwd", debug, s);
 	}

@@ -32,10 +32,13 @@ struct GeomLayout {
 };
 
 // image buffer: [GsCtl][ranges uint2 x T][tile_count/cursor u32 x T][final_T f32 x T*256][n_contrib u32 x T*256]
+//               [med_pos u32 x T*256]
 // (replaces ImageState, rasterizer_impl.h:50-57; per-pixel state is tile-major so that a tile's 256
-// threads read/write 1 KiB contiguous; ranges are sized per tile, not per pixel)
+// threads read/write 1 KiB contiguous; ranges are sized per tile, not per pixel).  med_pos = 1-based position in
+// the tile's list of the Gaussian at which the pixel's transmittance crossed 0.5 (0 = none): the forward's own
+// median decision (forward.cu:368-373), which the backward uses for the median-depth gradient.
 struct ImgLayout {
-	size_t ctl, ranges, tile_count, final_T, n_contrib, total;
+	size_t ctl, ranges, tile_count, final_T, n_contrib, med_pos, total;
 	int gx, gy, T;
 	ImgLayout(int W, int H)
 	{
@@ -47,7 +50,8 @@ struct ImgLayout {
 		tile_count = ranges + align_up(sizeof(uint2) * (size_t)T);
 		final_T = tile_count + align_up(sizeof(uint32_t) * (size_t)T);
 		n_contrib = final_T + align_up(sizeof(float) * (size_t)T * GSR_TILE_PIX);
-		total = n_contrib + align_up(sizeof(uint32_t) * (size_t)T * GSR_TILE_PIX);
+		med_pos = n_contrib + align_up(sizeof(uint32_t) * (size_t)T * GSR_TILE_PIX);
+		total = med_pos + align_up(sizeof(uint32_t) * (size_t)T * GSR_TILE_PIX);
 	}
 };
 
@@ -113,8 +117,8 @@ void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* range
                       uint32_t* point_list, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, const GsCtl* ctl, uint32_t cap,
-                          uint32_t max_sorted, bool nocull, hipStream_t s);
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, const GsCtl* ctl,
+                          uint32_t cap, uint32_t max_sorted, bool nocull, hipStream_t s);
 
 // --- launchers (gsr_kernels_bwd.hip) ---
 struct BwdArgs {
@@ -155,7 +159,7 @@ struct BwdLayout {
 // variant: 0 = default; other values select A/B variants of the kernel (gsr_set_option("bwd_variant", v))
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const float* final_T,
-                          const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                          const uint32_t* n_contrib, const uint32_t* med_pos, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
                           int variant, hipStream_t s);
 // parts: GSR_PART_GEOM = the per-Gaussian geometry kernel (all P Gaussians); GSR_PART_SH = the SH kernel over

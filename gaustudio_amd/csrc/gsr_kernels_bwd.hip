@@ -107,213 +107,183 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 	                   sums10);
 }
 
-#define GSR_SG_STRIDE 11
+// ------------------------------------------------------------------------------------------------
+// composite_bwd: ONE workgroup of 4 wave64 per 16x16 tile; wave w owns the 8x8 pixel block w of the tile, one pixel
+// per lane -- the forward's layout (gs_pixel_of_thread), walked back to front.
+//
+// The expensive part of this kernel used to be the cross-lane reduction: every (wave, instance) pair has to turn 64
+// per-pixel contributions into ten per-Gaussian sums, and a lane-swap / DPP tree for ten quantities costs ~130 VALU
+// cycles per pair however it is arranged (rounds 1-2: 45 % of the kernel).  It is now done by TRANSPOSITION
+// through LDS instead:
+//   phase 1 (lane = pixel): per pair only the two per-pixel scalars everything else is linear in are computed,
+//           q = G * dL_dalpha   and   w = alpha * T_before,
+//           and stored as one 8-byte LDS write per lane into the pair's row of the wave's slab;
+//   phase 2 (lane = (pair u, pixel row g), every GSR_BWD_UNITS pairs): each lane walks the 8 pixels of ITS row of
+//           ITS pair and accumulates the ten sums with plain FMAs against per-pixel constants (upstream gradients
+//           from a small LDS table, dx / dy recomputed) -- 64 pixels x 10 FMAs = 10 wave-instructions per pair
+//           instead of a reduction tree; three swap / DPP steps fold the 8 rows (lanes of the same pair only).
+// No LDS float atomics, and the per-pixel products (q*dx, w*dL_dpixel, ...) leave phase 1 as well.  The four waves
+// write their sums into four private planes that the flush adds in a fixed order: gradients stay bit-reproducible
+// from run to run.
+// The median-depth gradient (backward.cu:566-569) goes to the Gaussian the FORWARD recorded as the pixel's median
+// (med_pos, same decision as forward.cu:368-373 on the forward's own transmittances): one integer compare per pixel
+// in phase 2.  The reference re-derives the crossing from a transmittance reconstructed by division, which is
+// ill-conditioned at the threshold; the two can only disagree inside the window tests/ grant as `flip9`.
+// Staging is software-pipelined: the records of the NEXT batch (and the ids of the one after) are requested before
+// the walk of the current one, four threads per 64-B record, so the dependent point_list -> record gathers are not
+// waited for between batches.
+// ------------------------------------------------------------------------------------------------
+#define GSR_BWD_THREADS 256
+#define GSR_BWD_BATCH 64      // instances staged per round: one lane-test per (wave, instance) in a single ballot
+#ifndef GSR_BWD_UNITS
+#define GSR_BWD_UNITS 8       // pairs per transposed reduction; lane = (pair u = lane % UNITS, pixel group g = lane / UNITS)
+#endif
+#define GSR_SLAB_STRIDE 65    // float2 per pair row: 64 pixels + 1 pad (conflict-free b64 reads across pairs)
+#define GSR_PLANE_STRIDE 10   // floats per instance in a wave's plane of sums
+#define GSR_TAB_ROW 17        // float4 per pixel row of the constants table: 8 pixels x 2 + 1 pad (rows on distinct banks)
 
-// composite_bwd: ONE workgroup of 2 wave64 per 16x16 tile; wave w owns the 8-wide, 16-tall half tile
-// (columns 8w..8w+7) and every lane owns TWO pixels of it, (x, y) and (x, y+8) -- one in each of the wave's two 8x8
-// pixel blocks.  The cross-lane reduction of the ten gradient components costs ~130 VALU cycles per (wave, instance)
-// regardless of how many pixels feed it; with two pixels per lane it is paid once per 128 pixel evaluations and the
-// per-pixel math issues as packed FP32.  Culling is per 8x8 BLOCK (box test + the block's own last-contributor
-// bound): an instance that can only touch one of the wave's two blocks -- half of the surviving pairs at C3 -- is
-// evaluated for that block's 64 pixels alone, with plain FP32 instructions (half the arithmetic of the packed body,
-// the same IEEE operations per pixel, so the result does not depend on which body ran).
-// Pixel state comes from the forward's tile-major arrays: index = (forward wave)*64 + (forward lane).
-#define GSR_BWD_THREADS 128
-#define GSR_BWD_BATCH 128
-
-// ---- arithmetic on one pixel (float) or both pixels of a lane (v2f) with the same source text ----
-struct GsM2 { bool a, b; };
-template <int K> struct GsPix;   // K = 0 / 1: only pixel 0 / 1 of the lane, K = 2: both
-template <> struct GsPix<2> {
-	typedef v2f V;
-	typedef GsM2 M;
-	static __device__ __forceinline__ V get(v2f x) { return x; }
-	static __device__ __forceinline__ void put(v2f& d, V x) { d = x; }
-	static __device__ __forceinline__ V splat(float a) { return v2f{a, a}; }
-	static __device__ __forceinline__ M live(int pos, v2i lc, V power, float pcut, V a0)
-	{
-		// per-pixel predicates stay scalar bools (SGPR lane masks): a select is then ONE v_cndmask
-		// (no short-circuit evaluation: `&` keeps the body free of exec-mask branches)
-		const bool a = (pos < lc.x) & (power.x <= 0.0f) & (power.x >= pcut) & (!(a0.x < 1.0f / 255.0f));
-		const bool b = (pos < lc.y) & (power.y <= 0.0f) & (power.y >= pcut) & (!(a0.y < 1.0f / 255.0f));
-		return GsM2{a, b};
-	}
-	static __device__ __forceinline__ M med(M l, V tT, V T)
-	{
-		const bool a = l.a & (tT.x > 0.5f) & (T.x < 0.5f), b = l.b & (tT.y > 0.5f) & (T.y < 0.5f);
-		return GsM2{a, b};
-	}
-	static __device__ __forceinline__ bool any(M m) { return __ballot(m.a | m.b) != 0ull; }
-	static __device__ __forceinline__ V sel(M m, V a, V b) { return v2f{m.a ? a.x : b.x, m.b ? a.y : b.y}; }
-	static __device__ __forceinline__ float hsum(V a) { return a.x + a.y; }
-	static __device__ __forceinline__ V exp(V p, v2f magic, v2f c5) { return gs_exp2(p, magic, c5); }
-	static __device__ __forceinline__ V min99(V a) { return v2f{fminf(0.99f, a.x), fminf(0.99f, a.y)}; }
-	static __device__ __forceinline__ V rcp(V a) { return v2f{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
-	static __device__ __forceinline__ V fma(V a, V b, V c) { return vfma(a, b, c); }
-};
-template <int K> struct GsPix {
-	typedef float V;
-	typedef bool M;
-	static __device__ __forceinline__ V get(v2f x) { return K == 0 ? x.x : x.y; }
-	static __device__ __forceinline__ void put(v2f& d, V x) { if (K == 0) d.x = x; else d.y = x; }
-	static __device__ __forceinline__ V splat(float a) { return a; }
-	static __device__ __forceinline__ M live(int pos, v2i lc, V power, float pcut, V a0)
-	{
-		return (pos < (K == 0 ? lc.x : lc.y)) & (power <= 0.0f) & (power >= pcut) & (!(a0 < 1.0f / 255.0f));
-	}
-	static __device__ __forceinline__ M med(M l, V tT, V T) { return l & (tT > 0.5f) & (T < 0.5f); }
-	static __device__ __forceinline__ bool any(M m) { return __ballot(m) != 0ull; }
-	static __device__ __forceinline__ V sel(M m, V a, V b) { return m ? a : b; }
-	static __device__ __forceinline__ float hsum(V a) { return a; }
-	static __device__ __forceinline__ V exp(V p, v2f, v2f) { return gs_exp(p); }   // the same IEEE operations as one element of gs_exp2
-	static __device__ __forceinline__ V min99(V a) { return fminf(0.99f, a); }
-	static __device__ __forceinline__ V rcp(V a) { return __builtin_amdgcn_rcpf(a); }
-	static __device__ __forceinline__ V fma(V a, V b, V c) { return FMA(a, b, c); }
-};
-
-// per-lane pixel state of composite_bwd (two pixels)
-struct GsBwdPix {
-	v2f T_, S, dLp0, dLp1, dLp2, dLd, dLm, dLo, bg_dot, T_final, pixfy;
-	v2i lc;          // last_contributor (n_contrib of the forward)
-	float pixfx;
-};
-
-// One (wave, instance) pair for the pixels selected by K.  Returns false when no selected pixel is live; otherwise
-// q[0..9] = this lane's contribution to {M10, M01, M20, M11, M02, g5, g6, g7, g8, g9} (see the flush for their meaning).
-// The body is straight-line: a dead pixel is carried through with G masked to 0, which makes every quantity derived
-// from it exactly neutral -- alpha = 0, 1/(1-alpha) = 1 (v_rcp_f32(1.0) == 1.0, checked by gsr_selftest; TSEL keeps
-// a select on T for hardware where it is not), w = 0, q = 0, and S <- fma(0, ., S) = S -- so the only selects left are
-// the two on G (and the median's).  The reference's five back-to-front recurrences accum_rec[ch] (3 colours, depth,
-// opacity; backward.cu:541-573) enter dL_dalpha only through their dot product with the pixel's upstream gradients,
-// and the recurrence is linear: one scalar S = <accum_rec, dL_dpixel> is carried, updated EAGERLY with this
-// Gaussian's alpha (the reference folds `last_alpha`, `last_color` in at the next contributor: the same fma on the
-// same operands one step later, bit-identical).
-template <int K, bool TSEL>
-__device__ __forceinline__ bool gs_bwd_pair(const float4 A, const float4 B, const float4 Cc, const int pos, GsBwdPix& ps,
-                                            const bool any_bg, const v2f k_magic, const v2f k_c5, float* q)
+// Phase 2: the wave's slab holds (q, w) of `n` pairs; writes their ten sums into the wave's plane.
+//   sums: 0 M10 = sum q dx, 1 M01 = sum q dy, 2 M20, 3 M11, 4 M02, 5 sum (w dL_dopacity + q), 6..8 sum w dL_dpixel[c],
+//         9 sum w dL_ddepth + (median gradient of the pixels whose median this Gaussian is)
+// tab: per pixel (sx, row) two float4 at [row * GSR_TAB_ROW + 2 sx]: {dL_dpixel rgb, dL_ddepth}, {dL_dopacity,
+// dL_dmedian, med_pos bits, -}.
+__device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restrict__ slab, const int* __restrict__ unit_j,
+                                              const float4* __restrict__ sA, const float4* __restrict__ tab, const float fbx,
+                                              const float fby, const int top, float* __restrict__ plane, const int lane)
 {
-	typedef GsPix<K> P;
-	typedef typename P::V V;
-	const float dx = A.x - ps.pixfx;
-	const V dy = P::splat(A.y) - P::get(ps.pixfy);
-	const float ax = (A.z * dx) * dx, bxd = A.w * dx;
-	const V power = P::fma(P::splat(bxd), dy, P::fma(P::splat(B.x) * dy, dy, P::splat(ax)));
-	const V G = P::exp(power, k_magic, k_c5);
-	const V a0 = P::splat(B.y) * G;
-	const typename P::M live = P::live(pos, ps.lc, power, B.w, a0);
-	if (!P::any(live)) return false;
-	const V zero = P::splat(0.0f);
-	const V Gm = P::sel(live, G, zero);
-	const V alpha = P::min99(P::splat(B.y) * Gm);
-	// 1/(1-alpha) once, by v_rcp_f32 (1 ulp) instead of two IEEE divisions (backward.cu:536,587): the backward is
-	// tolerance-checked (its sums are order-dependent in the reference as well)
-	const V om = P::splat(1.0f) - alpha;
-	const V rinv = P::rcp(om);
-	const V Told = P::get(ps.T_);
-	const V test_T = Told * rinv;
-	const V w = alpha * test_T;   // dchannel_dcolor = dpixel_depth_ddepth = dpixel_opacity_dopacity
-	// <colour of this Gaussian, dL_dpixel> over the 5 blended channels (rgb, depth, opacity == 1)
-	const V cd = P::fma(P::splat(Cc.x), P::get(ps.dLp0), P::fma(P::splat(Cc.y), P::get(ps.dLp1),
-	             P::fma(P::splat(Cc.z), P::get(ps.dLp2), P::fma(P::splat(B.z), P::get(ps.dLd), P::get(ps.dLo)))));
-	const V Sold = P::get(ps.S);
-	const V diff = cd - Sold;
-	V dL_dalpha = diff * test_T;
-	if (any_bg) {                                                         // backward.cu:584-587
-		asm volatile("");   // not speculated: keeps this a scalar branch instead of compute-always + select
-		dL_dalpha = P::fma(-(P::get(ps.T_final) * rinv), P::get(ps.bg_dot), dL_dalpha);
+	constexpr int NG = 64 / GSR_BWD_UNITS;      // pixel groups: 8 (one pixel row each) or 16 (half a row each)
+	constexpr int PPL = GSR_BWD_UNITS;          // pixels per lane
+	const int u = lane & (GSR_BWD_UNITS - 1), g = lane / GSR_BWD_UNITS;
+	const bool act = u < n;
+	const int j = act ? unit_j[u] : 0;
+	const float2 ctr = *reinterpret_cast<const float2*>(&sA[j]);   // Gaussian centre
+	const uint32_t pos1 = (uint32_t)(top - j);   // list position + 1 of the pair's instance
+	const int prow = NG == 8 ? g : (g >> 1), pcol0 = NG == 8 ? 0 : ((g & 1) << 2);   // first pixel of the lane's group
+	const float dy = ctr.y - (fby + (float)prow);
+	const float fx0 = fbx + (float)pcol0;
+	const float2* row = slab + u * GSR_SLAB_STRIDE + prow * 8 + pcol0;
+	const float4* trow = tab + prow * GSR_TAB_ROW + 2 * pcol0;
+	float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
+#pragma unroll
+	for (int sx = 0; sx < PPL; sx++) {
+		const float2 v = row[sx];                           // (q, w) of the pixel
+		const float4 c0 = trow[2 * sx], c1 = trow[2 * sx + 1];
+		const float dx = ctr.x - (fx0 + (float)sx);
+		const float t = v.x * dx, tu = v.x * dy;
+		a0 += t;
+		a1 += tu;
+		a2 = FMA(t, dx, a2);
+		a3 = FMA(t, dy, a3);
+		a4 = FMA(tu, dy, a4);
+		a5 = FMA(v.y, c1.x, a5 + v.x);                       // backward.cu:575 + :607
+		a6 = FMA(v.y, c0.x, a6);
+		a7 = FMA(v.y, c0.y, a7);
+		a8 = FMA(v.y, c0.z, a8);
+		a9 = FMA(v.y, c0.w, a9) + ((__float_as_uint(c1.z) == pos1) ? c1.y : 0.f);
 	}
-	const V qa = Gm * dL_dalpha;                                          // dL_dG * G / opacity
-	// median-depth gradient (backward.cu:566-569)
-	const typename P::M med = P::med(live, test_T, Told);
-	const V g6v = w * P::get(ps.dLp0), g7v = w * P::get(ps.dLp1), g8v = w * P::get(ps.dLp2);
-	const V g9v = P::fma(w, P::get(ps.dLd), P::sel(med, P::get(ps.dLm), zero));
-	const V g5v = P::fma(w, P::get(ps.dLo), qa);                          // backward.cu:575 + :607
-	// moments of qa over the pixels; the conic / opacity factors are applied once per instance in the flush
-	const V qx = qa * P::splat(dx), qy = qa * dy;
-	const V m20 = qx * P::splat(dx), m11 = qx * dy, m02 = qy * dy;
-	P::put(ps.S, P::fma(alpha, diff, Sold));
-	P::put(ps.T_, TSEL ? P::sel(live, test_T, Told) : test_T);
-	q[0] = P::hsum(qx); q[1] = P::hsum(qy); q[2] = P::hsum(m20); q[3] = P::hsum(m11); q[4] = P::hsum(m02);
-	q[5] = P::hsum(g5v); q[6] = P::hsum(g6v); q[7] = P::hsum(g7v); q[8] = P::hsum(g8v); q[9] = P::hsum(g9v);
-	return true;
+	// fold the pixel groups of every pair: lanes u + UNITS * g (partners always belong to the same pair, so stale
+	// slab rows of inactive pairs never leak into active ones)
+	const float r0 = half_swap_sum(a0, a1);
+	const float r1 = half_swap_sum(a2, a3);
+	const float r2 = half_swap_sum(a4, a5);
+	const float r3 = half_swap_sum(a6, a7);
+	const float r4 = half_swap_sum(a8, a9);
+	float s0 = row_swap_sum(r0, r1), s1 = row_swap_sum(r2, r3), s2 = row_swap_sum(r4, 0.f);
+	GSR_DPP_ADD(s0, 0x128); GSR_DPP_ADD(s1, 0x128); GSR_DPP_ADD(s2, 0x128);   // row_ror:8: lanes l and l ^ 8
+	// UNITS == 4: lanes u + 4 k of a row still differ; after the previous step the values are symmetric under l ^ 8,
+	// so (l + 4) % 16 is as good as l ^ 4
+	if (NG == 16) { GSR_DPP_ADD(s0, 0x124); GSR_DPP_ADD(s1, 0x124); GSR_DPP_ADD(s2, 0x124); }   // row_ror:4
+	// 16-lane row r of s0 / s1 / s2 now holds component {0,2,1,3}[r] / 4+{0,2,1,3}[r] / {8,-,9,-}[r] of pair u
+	if (act && (lane & (16 - GSR_BWD_UNITS) & 15) == 0) {
+		const int rw = lane >> 4;
+		float* dst = plane + j * GSR_PLANE_STRIDE + (((rw & 1) << 1) | (rw >> 1));
+		dst[0] = s0;
+		dst[4] = s1;
+		if ((rw & 1) == 0) dst[8] = s2;
+	}
 }
 
-// FLAGS: long-list regime (per-row validity bytes); compile-time so that the short-list kernel carries none of it
+// FLAGS: long-list regime (per-row validity bytes); compile-time so that the short-list kernel carries none of it.
+// TSEL: keep a select on T for devices where v_rcp_f32(1.0) != 1.0 (gsr_selftest).
 template <bool FLAGS, bool TSEL>
 __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
     int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs,
-    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ med_pos,
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
     const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags)
 {
-	__shared__ float4 sA[GSR_BWD_BATCH];
-	__shared__ float4 sB[GSR_BWD_BATCH];
-	__shared__ float4 sC[GSR_BWD_BATCH];
-	// per-instance partial sums of the staged batch, 10 floats per row, row stride 11 words (odd: the
-	// flush's one-row-per-thread reads are bank-conflict free)
-	__shared__ float sG[GSR_BWD_BATCH * GSR_SG_STRIDE];
-	__shared__ int s_max[2];
+	__shared__ float4 sA[GSR_BWD_BATCH];   // q0: px, py, -a/2, -b
+	__shared__ float4 sB[GSR_BWD_BATCH];   // q1: -c/2, opacity, depth, pcut
+	__shared__ float4 sC[GSR_BWD_BATCH];   // q2: r, g, b, -
+	__shared__ uint32_t s_row[GSR_BWD_BATCH];   // Gaussian-major row of each staged instance
+	__shared__ __attribute__((aligned(16))) float s_plane[4][GSR_BWD_BATCH * GSR_PLANE_STRIDE];   // per-wave sums of the batch
+	__shared__ float2 s_slab[4][GSR_BWD_UNITS * GSR_SLAB_STRIDE];
+	__shared__ float4 s_tab[4][8 * GSR_TAB_ROW];            // per-pixel constants of phase 2
+	__shared__ int s_unit[4][GSR_BWD_UNITS];
+	__shared__ int s_max[4];
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
 	const int tx = tile % gx, ty = tile / gx;
-	const int px = tx * GSR_BLOCK_X + (wv << 3) + (lane & 7);
-	const int pyk[2] = {ty * GSR_BLOCK_Y + (lane >> 3), ty * GSR_BLOCK_Y + (lane >> 3) + 8};
-	// the wave's two 8x8 pixel blocks (pixel centres), clipped to the image
-	const float bx0 = (float)(tx * GSR_BLOCK_X + (wv << 3)), bx1 = fminf(bx0 + 7.f, (float)(W - 1));
-	const float by0a = (float)(ty * GSR_BLOCK_Y), by1a = fminf(by0a + 7.f, (float)(H - 1));
-	const float by0b = by0a + 8.f, by1b = fminf(by0a + 15.f, (float)(H - 1));
+	int lx, ly;
+	gs_pixel_of_thread(tid, lx, ly);
+	const int px = tx * GSR_BLOCK_X + lx, py = ty * GSR_BLOCK_Y + ly;
+	const bool inside = px < W && py < H;
+	const float pixfx = (float)px, pixfy = (float)py;
+	// this wave's pixel block (pixel centres), clipped to the image
+	const float fbx = (float)(tx * GSR_BLOCK_X + ((wv & 1) << 3)), fby = (float)(ty * GSR_BLOCK_Y + ((wv >> 1) << 3));
+	const float bx1 = fminf(fbx + 7.f, (float)(W - 1)), by1 = fminf(fby + 7.f, (float)(H - 1));
 	const uint2 range = ranges[tile];
 
-	GsBwdPix ps;
-	ps.pixfx = (float)px;
-	ps.pixfy = v2f{(float)pyk[0], (float)pyk[1]};
-#pragma unroll
-	for (int k = 0; k < 2; k++) {
-		const bool inside = px < W && pyk[k] < H;
-		const size_t sidx = (size_t)tile * GSR_TILE_PIX + (size_t)((2 * k + wv) * 64 + lane);   // forward's thread id
-		ps.T_final[k] = inside ? final_T[sidx] : 0.f;
-		ps.lc[k] = inside ? (int)n_contrib[sidx] : 0;
-		ps.dLp0[k] = ps.dLp1[k] = ps.dLp2[k] = ps.dLd[k] = ps.dLm[k] = ps.dLo[k] = 0.f;
+	const size_t sidx = (size_t)tile * GSR_TILE_PIX + tid;   // the forward's tile-major pixel state
+	const float T_final = inside ? final_T[sidx] : 0.f;
+	const int lc = inside ? (int)n_contrib[sidx] : 0;          // last_contributor
+	float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLo = 0.f;
+	{
+		float dLm = 0.f;
+		uint32_t mpos = 0u;
 		if (inside) {
 			const size_t HW = (size_t)H * W;
-			const size_t pix_id = (size_t)W * pyk[k] + px;
-			ps.dLp0[k] = dL_dpix[pix_id];
-			ps.dLp1[k] = dL_dpix[HW + pix_id];
-			ps.dLp2[k] = dL_dpix[2 * HW + pix_id];
-			ps.dLd[k] = dL_dpix_depth[pix_id];
-			ps.dLm[k] = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
-			ps.dLo[k] = dL_dpix_opacity[pix_id];
+			const size_t pix_id = (size_t)W * py + px;
+			dLp0 = dL_dpix[pix_id];
+			dLp1 = dL_dpix[HW + pix_id];
+			dLp2 = dL_dpix[2 * HW + pix_id];
+			dLd = dL_dpix_depth[pix_id];
+			dLm = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
+			dLo = dL_dpix_opacity[pix_id];
+			mpos = med_pos[sidx];
 		}
-		// bg . dL_dpixel (backward.cu:584-586), loop invariant
-		ps.bg_dot[k] = FMA(bg[2], ps.dLp2[k], FMA(bg[1], ps.dLp1[k], FMA(bg[0], ps.dLp0[k], 0.f)));
+		// lane = pixel (lx & 7, ly & 7) of the wave's block
+		float4* t = s_tab[wv] + (lane >> 3) * GSR_TAB_ROW + 2 * (lane & 7);
+		t[0] = make_float4(dLp0, dLp1, dLp2, dLd);
+		t[1] = make_float4(dLo, dLm, __uint_as_float(mpos), 0.f);
 	}
-	ps.T_ = ps.T_final;
-	ps.S = v2f{0.f, 0.f};
-	// wave-uniform: with a black background (the common case) the term is skipped by a scalar branch; a per-lane
-	// condition had the compiler evaluate it always and select (4 VALU per pair).  fma(x, 0, y) == y keeps lanes
-	// without a contribution exact when another lane of the wave has one.
-	const bool any_bg = __ballot(ps.bg_dot.x != 0.f || ps.bg_dot.y != 0.f) != 0ull;
+	// bg . dL_dpixel (backward.cu:584-586), loop invariant
+	const float bg_dot = FMA(bg[2], dLp2, FMA(bg[1], dLp1, FMA(bg[0], dLp0, 0.f)));
+	// wave-uniform: with a black background (the common case) the term is skipped by a scalar branch
+	const bool any_bg = __ballot(bg_dot != 0.f) != 0ull;
+	float T_ = T_final;
+	// The reference carries five back-to-front recurrences accum_rec[ch] (3 colours, depth, opacity;
+	// backward.cu:541-573) but dL_dalpha only needs their dot product with this pixel's upstream gradients, and the
+	// recurrence is linear: one scalar S = <accum_rec, dL_dpixel> is carried, updated EAGERLY with this Gaussian's
+	// alpha (the reference folds last_alpha / last_color in at the next contributor: the same fma one step later).
+	float S = 0.f;
 
-	// per 8x8 block: max of last_contributor -- list entries at or beyond it are dead for every pixel of the block
-	int wmax0 = ps.lc.x, wmax1 = ps.lc.y;
+	// block / tile maxima of last_contributor: list entries at or beyond them are dead for every pixel
+	int wmax = lc;
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		wmax0 = max(wmax0, __shfl_xor(wmax0, o, 64));
-		wmax1 = max(wmax1, __shfl_xor(wmax1, o, 64));
-	}
-	wmax0 = __builtin_amdgcn_readfirstlane(wmax0);
-	wmax1 = __builtin_amdgcn_readfirstlane(wmax1);
-	if (lane == 0) s_max[wv] = max(wmax0, wmax1);
+	for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+	wmax = __builtin_amdgcn_readfirstlane(wmax);
+	if (lane == 0) s_max[wv] = wmax;
 	__syncthreads();
-	const int bmax = max(s_max[0], s_max[1]);
+	const int bmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 
 	// List entries at or beyond bmax contribute to no pixel of this tile.  Two regimes, chosen by the launcher from
 	// the average list length:
-	//   short lists (most of a list is walked): their rows are zeroed here, under the shadow of the VALU-bound main
-	//     loop, and preprocess_bwd adds every row unconditionally;
+	//   short lists (most of a list is walked): their rows are zeroed here, under the shadow of the main loop, and
+	//     preprocess_bwd adds every row unconditionally;
 	//   long lists (real scenes: a few thousand entries of which ~15 % are reached): row_flags != nullptr -- written
 	//     rows set a validity byte, unreached entries are left alone and preprocess_bwd skips them WITHOUT reading
 	//     them (clearing + re-reading 48 B per unreached entry was the larger cost: C4 share 1.42 -> 0.59 ms here).
@@ -326,106 +296,124 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
-	// walk positions pos = bmax-1 ... 0, staged GSR_BWD_BATCH at a time (one instance per thread: a small
-	// batch keeps the workgroup at 12 KiB of LDS so that 13 of them -- 26 waves -- fit a CU)
-	GS_EXP2_CONSTANTS(k_magic, k_c5);
+	float2* slab = s_slab[wv];
+	float* plane = s_plane[wv];
+	// ---- software-pipelined staging: thread t fetches 16-B part (t & 3) of the record of staged instance t >> 2 ----
+	const int srec = tid >> 2, spart = tid & 3;
+	auto load_id = [&](int t) -> uint32_t {   // id of list position t-1-srec (0 when outside the walk)
+		return (t > 0 && srec < min(GSR_BWD_BATCH, t)) ? point_list[range.x + (uint32_t)(t - 1 - srec)] : 0u;
+	};
+	auto load_part = [&](int t, uint32_t id) -> float4 {
+		return (t > 0 && srec < min(GSR_BWD_BATCH, t)) ? reinterpret_cast<const float4*>(recs + id)[spart]
+		                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+	};
+	uint32_t id_next = load_id(bmax - GSR_BWD_BATCH);
+	float4 part_cur = load_part(bmax, load_id(bmax));
+	// walk positions pos = bmax-1 ... 0, staged GSR_BWD_BATCH at a time
 	for (int top = bmax; top > 0; top -= GSR_BWD_BATCH) {
 		const int cnt = min(GSR_BWD_BATCH, top);
-		uint32_t my_row = 0u;
-		__syncthreads();
-		{
-			const int st = tid;
-			if (st < cnt) {
-				const uint32_t id = point_list[range.x + (top - 1 - st)];
-				const GsRec* r = recs + id;
-				sA[st] = r->q0;
-				sB[st] = r->q1;
-				float4 c = r->q2;
-				c.w = __int_as_float((int)id);
-				sC[st] = c;
-				// Gaussian-major row of this (tile, Gaussian) instance: goff[g] (carried in the record) + raster index
-				// of the tile inside the Gaussian's tile rect -- the 64-B record is the only thing gathered
-				const uint4 q3 = r->q3;
-				const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
-				my_row = q3.w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
+		__syncthreads();   // the previous flush has read sA / sB / the planes
+		if (srec < cnt) {
+			if (spart == 0) sA[srec] = part_cur;
+			else if (spart == 1) sB[srec] = part_cur;
+			else if (spart == 2) sC[srec] = part_cur;
+			else {
+				// Gaussian-major row of this (tile, Gaussian) instance: goff[g] (carried in the record, q3.w) + raster
+				// index of the tile inside the Gaussian's tile rect -- the 64-B record is the only thing gathered
+				const uint32_t q3x = __float_as_uint(part_cur.x), q3y = __float_as_uint(part_cur.y), q3w = __float_as_uint(part_cur.w);
+				const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
+				s_row[srec] = q3w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
 			}
+		}
+		// request the next batch's records and the ids of the one after: in flight during this batch's walk
+		const float4 part_next = load_part(top - GSR_BWD_BATCH, id_next);
+		id_next = load_id(top - 2 * GSR_BWD_BATCH);
+		// zero the four planes of sums (4 x 64 x 10 floats = 640 float4)
+		for (int i = tid; i < 4 * GSR_BWD_BATCH * GSR_PLANE_STRIDE / 4; i += GSR_BWD_THREADS)
+			reinterpret_cast<float4*>(&s_plane[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		__syncthreads();
+		// per-wave cull of the staged batch: lane l tests instance l against the wave's pixel block (see composite_fwd)
+		bool hit = false;
+		if (lane < cnt && top - 1 - lane < wmax) hit = gs_box_may_touch(sA[lane], sB[lane], fbx, fby, bx1, by1);
+		unsigned long long m = __ballot(hit);
+		int nu = 0;   // pairs in the slab (wave-uniform)
+		while (m) {
+			const int j = __ffsll((long long)m) - 1;
+			m &= m - 1;
+			const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
+			const float4 A = sA[j];
+			const float4 B = sB[j];
+			const float4 Cc = sC[j];
+			const float dx = A.x - pixfx, dy = A.y - pixfy;
+			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
+			const float G = gs_exp(power);
+			const float a0 = B.y * G;
+			// no short-circuit evaluation: `&` keeps the body free of exec-mask branches
+			const bool live = (pos < lc) & (power <= 0.0f) & (power >= B.w) & (!(a0 < 1.0f / 255.0f));
+			if (__ballot(live) == 0ull) continue;
+			// a dead pixel is carried through with G masked to 0, which makes everything derived from it exactly
+			// neutral: alpha = 0, 1/(1-alpha) = 1 (v_rcp_f32(1.0) == 1.0, gsr_selftest), w = 0, q = 0, S <- fma(0,.,S)
+			const float Gm = live ? G : 0.f;
+			const float alpha = fminf(0.99f, B.y * Gm);
+			// 1/(1-alpha) once, by v_rcp_f32 (1 ulp) instead of two IEEE divisions (backward.cu:536,587): the backward
+			// is tolerance-checked (its sums are order-dependent in the reference as well)
+			const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+			const float test_T = T_ * rinv;
+			const float w = alpha * test_T;   // dchannel_dcolor = dpixel_depth_ddepth = dpixel_opacity_dopacity
+			// <colour of this Gaussian, dL_dpixel> over the 5 blended channels (rgb, depth, opacity == 1)
+			const float cd = FMA(Cc.x, dLp0, FMA(Cc.y, dLp1, FMA(Cc.z, dLp2, FMA(B.z, dLd, dLo))));
+			const float diff = cd - S;
+			float dL_dalpha = diff * test_T;
+			if (any_bg) {                                                         // backward.cu:584-587
+				asm volatile("");   // not speculated: keeps this a scalar branch instead of compute-always + select
+				dL_dalpha = FMA(-(T_final * rinv), bg_dot, dL_dalpha);
+			}
+			const float q = Gm * dL_dalpha;                                       // dL_dG * G / opacity
+			S = FMA(alpha, diff, S);
+			T_ = TSEL ? (live ? test_T : T_) : test_T;
+			slab[nu * GSR_SLAB_STRIDE + lane] = make_float2(q, w);
+			if (lane == 0) s_unit[wv][nu] = j;
+			nu++;
+			if (nu == GSR_BWD_UNITS) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				gs_bwd_phase2(GSR_BWD_UNITS, slab, s_unit[wv], sA, s_tab[wv], fbx, fby, top, plane, lane);
+				__builtin_amdgcn_wave_barrier();
+				nu = 0;
+			}
+		}
+		if (nu > 0) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			gs_bwd_phase2(nu, slab, s_unit[wv], sA, s_tab[wv], fbx, fby, top, plane, lane);
+		}
+		// flush: one thread per staged instance adds the four planes in fixed order and stores the 48-B row (plain
+		// stores, no global atomics), zeros included: every row of the scratch is written exactly once per backward,
+		// so nobody has to clear it
+		__syncthreads();
+		if (tid < cnt) {
+			float v[10];
 #pragma unroll
-			for (int k = 0; k < 10; k++) sG[st * GSR_SG_STRIDE + k] = 0.f;
+			for (int k = 0; k < 10; k++)
+				v[k] = ((s_plane[0][tid * GSR_PLANE_STRIDE + k] + s_plane[1][tid * GSR_PLANE_STRIDE + k]) +
+				        s_plane[2][tid * GSR_PLANE_STRIDE + k]) + s_plane[3][tid * GSR_PLANE_STRIDE + k];
+			// moments -> gradients (once per (tile, Gaussian)): with q = G*dL_dalpha summed over pixels,
+			//   dL_dmean2D.x = -0.5W * op * (a*M10 + b*M01)      (backward.cu:593-599)
+			//   dL_dconic    = -0.5 * op * (M20, M11, M02)       (backward.cu:602-604)
+			// where conic (a, b, c) = (-2*q0.z, -q0.w, -2*q1.x), op = q1.y
+			const float4 A = sA[tid], B = sB[tid];
+			const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x, op = B.y;
+			const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[4];
+			const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
+			const uint32_t my_row = s_row[tid];
+			float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row * GSR_ROW_STRIDE);
+			dst[0] = make_float4(-(op * FMA(cb, M01, ca * M10)) * ddelx_dx, -(op * FMA(cb, M10, cc * M01)) * ddely_dy,
+			                     -0.5f * op * M20, -0.5f * op * M11);
+			dst[1] = make_float4(-0.5f * op * M02, v[5], v[6], v[7]);
+			dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
+			if (FLAGS) row_flags[my_row] = 1;
 		}
-		__syncthreads();
-		// per-wave, per-block cull of the staged batch, 64 instances per ballot (see composite_fwd)
-		for (int sub = 0; sub < cnt; sub += 64) {
-			const int jl = sub + lane;
-			bool hit0 = false, hit1 = false;
-			if (jl < cnt) {
-				const int p = top - 1 - jl;
-				const float4 a = sA[jl], b = sB[jl];
-				if (p < wmax0) hit0 = gs_box_may_touch(a, b, bx0, by0a, bx1, by1a);
-				if (p < wmax1) hit1 = gs_box_may_touch(a, b, bx0, by0b, bx1, by1b);
-			}
-			const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-			unsigned long long m = m0 | m1;
-			while (m) {
-				const int bit = __ffsll((long long)m) - 1;
-				m &= m - 1;
-				const int j = sub + bit;
-				const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
-				const float4 A = sA[j];
-				const float4 B = sB[j];
-				const float4 Cc = sC[j];
-				const bool in0 = (m0 >> bit) & 1ull, in1 = (m1 >> bit) & 1ull;   // wave-uniform
-				float q[10];
-				bool any_live;
-				if (in0 && in1) any_live = gs_bwd_pair<2, TSEL>(A, B, Cc, pos, ps, any_bg, k_magic, k_c5, q);
-				else if (in0) any_live = gs_bwd_pair<0, TSEL>(A, B, Cc, pos, ps, any_bg, k_magic, k_c5, q);
-				else any_live = gs_bwd_pair<1, TSEL>(A, B, Cc, pos, ps, any_bg, k_magic, k_c5, q);
-				if (!any_live) continue;
-				// ten per-lane quantities -> three registers whose 16-lane rows carry different quantities ->
-				// within-row sums.  Row r of s0 / s1 / s2 holds component {0,2,1,3}[r] / 4+{0,2,1,3}[r] / {8,-,9,-}[r].
-				const float r0 = half_swap_sum(q[0], q[1]);   // [M10 | M01]
-				const float r1 = half_swap_sum(q[2], q[3]);   // [M20 | M11]
-				const float r2 = half_swap_sum(q[4], q[5]);   // [M02 | g5 ]
-				const float r3 = half_swap_sum(q[6], q[7]);   // [g6  | g7 ]
-				const float r4 = half_swap_sum(q[8], q[9]);   // [g8  | g9 ]
-				float s0 = row_swap_sum(r0, r1), s1 = row_swap_sum(r2, r3), s2 = row_swap_sum(r4, 0.f);
-				row_sum16x3(s0, s1, s2);
-				asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2));   // keep the last DPP step a fused v_add_f32_dpp (it was split into mov_dpp + add and sunk into the branch)
-				if ((lane & 15) == 0) {
-					// LDS float atomics (ds_add_f32), one lane per row = four components per instruction: the two
-					// waves of the tile meet here; global memory sees one row per (tile, instance) in the flush
-					const int row = lane >> 4;
-					float* dst = sG + j * GSR_SG_STRIDE + (((row & 1) << 1) | (row >> 1));
-					atomicAdd(dst, s0);
-					atomicAdd(dst + 4, s1);
-					if ((row & 1) == 0) atomicAdd(dst + 8, s2);
-				}
-			}
-		}
-		// flush: one thread per staged instance stores its 48-B row (plain stores, no global atomics), zeros
-		// included: every row of the scratch is written exactly once per backward, so nobody has to clear it
-		__syncthreads();
-		{
-			const int st = tid;
-			if (st < cnt) {
-				float v[10];
-#pragma unroll
-				for (int k = 0; k < 10; k++) v[k] = sG[st * GSR_SG_STRIDE + k];
-				// moments -> gradients (once per (tile, Gaussian)): with q = G*dL_dalpha summed over pixels,
-				//   dL_dmean2D.x = -0.5W * op * (a*M10 + b*M01)      (backward.cu:593-599)
-				//   dL_dconic    = -0.5 * op * (M20, M11, M02)       (backward.cu:602-604)
-				// where conic (a, b, c) = (-2*q0.z, -q0.w, -2*q1.x), op = q1.y
-				const float4 A = sA[st], B = sB[st];
-				const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x, op = B.y;
-				const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[4];
-				const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
-				float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row * GSR_ROW_STRIDE);
-				dst[0] = make_float4(-(op * FMA(cb, M01, ca * M10)) * ddelx_dx, -(op * FMA(cb, M10, cc * M01)) * ddely_dy,
-				                     -0.5f * op * M20, -0.5f * op * M11);
-				dst[1] = make_float4(-0.5f * op * M02, v[5], v[6], v[7]);
-				dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
-				if (FLAGS) row_flags[my_row] = 1;
-			}
-		}
+		part_cur = part_next;
 	}
 }
 
@@ -448,7 +436,7 @@ void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s)
 
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const float* final_T,
-                          const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                          const uint32_t* n_contrib, const uint32_t* med_pos, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
                           int variant, hipStream_t s)
 {
@@ -456,7 +444,7 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
 	const bool tsel = (variant & 1) != 0;
 #define GSR_LAUNCH_CB(FL, TS)                                                                                      \
 	hipLaunchKernelGGL((composite_bwd_kernel<FL, TS>), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, \
-	                   bg, ranges, point_list, recs, final_T, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_median,      \
+	                   bg, ranges, point_list, recs, final_T, n_contrib, med_pos, dL_dpix, dL_dpix_depth, dL_dpix_median,      \
 	                   dL_dpix_opacity, rows, row_flags)
 	if (row_flags != nullptr) {
 		if (tsel) GSR_LAUNCH_CB(true, true); else GSR_LAUNCH_CB(true, false);

@@ -993,8 +993,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     int T, int chunk, int gx, int W, int H, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, const GsCtl* __restrict__ ctl, uint32_t cap,
-    uint32_t max_sorted)
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ med_pos_out,
+    const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted)
 {
 	__shared__ float4 sA[256];
 	__shared__ float4 sB[256];
@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 	}
 	final_T[(size_t)tile * GSR_TILE_PIX + tid] = T_;
 	n_contrib[(size_t)tile * GSR_TILE_PIX + tid] = last_contributor;
+	uint32_t med_final = 0;   // list position (+1) of the median Gaussian, 0 = the transmittance never crossed 0.5
 	if (inside) {
 		// median depth / weight / id (forward.cu:368-373): the candidate crossed 0.5 iff its test_T < 0.5; alpha is
 		// recomputed with the very operations of the walk, so the result is the bit pattern the walk would have kept
@@ -1102,6 +1103,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 				median_D = B.z;
 				median_weight = alpha * med_T;
 				median_id = (int)id;
+				med_final = med_pos;
 			}
 		}
 		const size_t HW = (size_t)H * W;
@@ -1115,20 +1117,21 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 		out_median[2 * HW + pix_id] = (float)median_id;
 		out_opacity[pix_id] = 1 - T_;
 	}
+	med_pos_out[(size_t)tile * GSR_TILE_PIX + tid] = med_final;
 }
 
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, const GsCtl* ctl, uint32_t cap,
-                          uint32_t max_sorted, bool nocull, hipStream_t s)
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, const GsCtl* ctl,
+                          uint32_t cap, uint32_t max_sorted, bool nocull, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
 	if (nocull)
 		hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges,
-		                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib, ctl, cap, max_sorted);
+		                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted);
 	else
 		hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges,
-		                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib, ctl, cap, max_sorted);
+		                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted);
 }
 
 }  // namespace gsr
