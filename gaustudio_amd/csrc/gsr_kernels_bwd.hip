@@ -147,7 +147,7 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 //         9 sum w dL_ddepth + (median gradient of the pixels whose median this Gaussian is)
 // tab: per pixel (sx, row) two float4 at [row * GSR_TAB_ROW + 2 sx]: {dL_dpixel rgb, dL_ddepth}, {dL_dopacity,
 // dL_dmedian, med_pos bits, -}.
-__device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restrict__ slab, const int* __restrict__ unit_j,
+__device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restrict__ slab, const int unit_j,
                                               const float4* __restrict__ sA, const float4* __restrict__ tab, const float fbx,
                                               const float fby, const int top, float* __restrict__ plane, const int lane)
 {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restr
 	constexpr int PPL = GSR_BWD_UNITS;          // pixels per lane
 	const int u = lane & (GSR_BWD_UNITS - 1), g = lane / GSR_BWD_UNITS;
 	const bool act = u < n;
-	const int j = act ? unit_j[u] : 0;
+	const int j = act ? unit_j : 0;             // batch index of the lane's pair (kept per lane by phase 1)
 	const float2 ctr = *reinterpret_cast<const float2*>(&sA[j]);   // Gaussian centre
 	const uint32_t pos1 = (uint32_t)(top - j);   // list position + 1 of the pair's instance
 	const int prow = NG == 8 ? g : (g >> 1), pcol0 = NG == 8 ? 0 : ((g & 1) << 2);   // first pixel of the lane's group
@@ -220,7 +220,6 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	__shared__ __attribute__((aligned(16))) float s_plane[4][GSR_BWD_BATCH * GSR_PLANE_STRIDE];   // per-wave sums of the batch
 	__shared__ float2 s_slab[4][GSR_BWD_UNITS * GSR_SLAB_STRIDE];
 	__shared__ float4 s_tab[4][8 * GSR_TAB_ROW];            // per-pixel constants of phase 2
-	__shared__ int s_unit[4][GSR_BWD_UNITS];
 	__shared__ int s_max[4];
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
@@ -336,21 +335,19 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		bool hit = false;
 		if (lane < cnt && top - 1 - lane < wmax) hit = gs_box_may_touch(sA[lane], sB[lane], fbx, fby, bx1, by1);
 		unsigned long long m = __ballot(hit);
-		int nu = 0;   // pairs in the slab (wave-uniform)
-		while (m) {
-			const int j = __ffsll((long long)m) - 1;
-			m &= m - 1;
+		int nu = 0;        // pairs in the slab (wave-uniform)
+		int unit_j = 0;    // lane u + UNITS*g: batch index of pair u of the slab
+		const int lane_u = lane & (GSR_BWD_UNITS - 1);
+		// one (wave, instance) pair; returns with the pair's (q, w) in the slab, or without a trace if no pixel is live
+		auto pair = [&](const float4 A, const float4 B, const float4 Cc, const int j) {
 			const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
-			const float4 A = sA[j];
-			const float4 B = sB[j];
-			const float4 Cc = sC[j];
 			const float dx = A.x - pixfx, dy = A.y - pixfy;
 			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
 			const float G = gs_exp(power);
 			const float a0 = B.y * G;
 			// no short-circuit evaluation: `&` keeps the body free of exec-mask branches
 			const bool live = (pos < lc) & (power <= 0.0f) & (power >= B.w) & (!(a0 < 1.0f / 255.0f));
-			if (__ballot(live) == 0ull) continue;
+			if (__ballot(live) == 0ull) return;
 			// a dead pixel is carried through with G masked to 0, which makes everything derived from it exactly
 			// neutral: alpha = 0, 1/(1-alpha) = 1 (v_rcp_f32(1.0) == 1.0, gsr_selftest), w = 0, q = 0, S <- fma(0,.,S)
 			const float Gm = live ? G : 0.f;
@@ -372,20 +369,45 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 			S = FMA(alpha, diff, S);
 			T_ = TSEL ? (live ? test_T : T_) : test_T;
 			slab[nu * GSR_SLAB_STRIDE + lane] = make_float2(q, w);
-			if (lane == 0) s_unit[wv][nu] = j;
+			unit_j = (lane_u == nu) ? j : unit_j;
 			nu++;
 			if (nu == GSR_BWD_UNITS) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
-				gs_bwd_phase2(GSR_BWD_UNITS, slab, s_unit[wv], sA, s_tab[wv], fbx, fby, top, plane, lane);
+				gs_bwd_phase2(GSR_BWD_UNITS, slab, unit_j, sA, s_tab[wv], fbx, fby, top, plane, lane);
 				__builtin_amdgcn_wave_barrier();
 				nu = 0;
+			}
+		};
+		// the record of the NEXT surviving instance is read (wave-uniform LDS reads) while the current pair computes:
+		// two copies of the body alternate between two register sets instead of moving 12 registers per pair
+		if (m) {
+			int j0 = __ffsll((long long)m) - 1, j1 = 0;
+			m &= m - 1;
+			float4 A0 = sA[j0], B0 = sB[j0], C0 = sC[j0], A1, B1, C1;
+			while (true) {
+				const bool more1 = m != 0ull;
+				if (more1) {
+					j1 = __ffsll((long long)m) - 1;
+					m &= m - 1;
+					A1 = sA[j1]; B1 = sB[j1]; C1 = sC[j1];
+				}
+				pair(A0, B0, C0, j0);
+				if (!more1) break;
+				const bool more0 = m != 0ull;
+				if (more0) {
+					j0 = __ffsll((long long)m) - 1;
+					m &= m - 1;
+					A0 = sA[j0]; B0 = sB[j0]; C0 = sC[j0];
+				}
+				pair(A1, B1, C1, j1);
+				if (!more0) break;
 			}
 		}
 		if (nu > 0) {
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-			gs_bwd_phase2(nu, slab, s_unit[wv], sA, s_tab[wv], fbx, fby, top, plane, lane);
+			gs_bwd_phase2(nu, slab, unit_j, sA, s_tab[wv], fbx, fby, top, plane, lane);
 		}
 		// flush: one thread per staged instance adds the four planes in fixed order and stores the 48-B row (plain
 		// stores, no global atomics), zeros included: every row of the scratch is written exactly once per backward,
