@@ -160,27 +160,29 @@ __device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restr
 	const uint32_t pos1 = (uint32_t)(top - j);   // list position + 1 of the pair's instance
 	const int prow = NG == 8 ? g : (g >> 1), pcol0 = NG == 8 ? 0 : ((g & 1) << 2);   // first pixel of the lane's group
 	const float dy = ctr.y - (fby + (float)prow);
-	const float fx0 = fbx + (float)pcol0;
+	const float X = ctr.x - (fbx + (float)pcol0);          // dx of the lane's first pixel; dx of pixel sx is X - sx
 	const float2* row = slab + u * GSR_SLAB_STRIDE + prow * 8 + pcol0;
 	const float4* trow = tab + prow * GSR_TAB_ROW + 2 * pcol0;
-	float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
+	// All pixels of a lane share dy, so dy factors out of M01, M11, M02 (exactly up to one rounding each, relative to
+	// the magnitude of the factored sum) and only sum q, sum q dx, sum q dx^2 are accumulated per pixel.
+	float S0 = 0.f, a0 = 0.f, a2 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
 #pragma unroll
 	for (int sx = 0; sx < PPL; sx++) {
 		const float2 v = row[sx];                           // (q, w) of the pixel
 		const float4 c0 = trow[2 * sx], c1 = trow[2 * sx + 1];
-		const float dx = ctr.x - (fx0 + (float)sx);
-		const float t = v.x * dx, tu = v.x * dy;
+		const float dx = X - (float)sx;
+		const float t = v.x * dx;
+		S0 += v.x;
 		a0 += t;
-		a1 += tu;
 		a2 = FMA(t, dx, a2);
-		a3 = FMA(t, dy, a3);
-		a4 = FMA(tu, dy, a4);
-		a5 = FMA(v.y, c1.x, a5 + v.x);                       // backward.cu:575 + :607
+		a5 = FMA(v.y, c1.x, a5);                             // backward.cu:575 (+ :607 below: + sum q)
 		a6 = FMA(v.y, c0.x, a6);
 		a7 = FMA(v.y, c0.y, a7);
 		a8 = FMA(v.y, c0.z, a8);
 		a9 = FMA(v.y, c0.w, a9) + ((__float_as_uint(c1.z) == pos1) ? c1.y : 0.f);
 	}
+	a5 += S0;
+	const float a1 = dy * S0, a3 = dy * a0, a4 = dy * a1;
 	// fold the pixel groups of every pair: lanes u + UNITS * g (partners always belong to the same pair, so stale
 	// slab rows of inactive pairs never leak into active ones)
 	const float r0 = half_swap_sum(a0, a1);
