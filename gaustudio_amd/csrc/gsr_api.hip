@@ -404,7 +404,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	// grows).
 	hipEvent_t ev = readback_event();
 	if (ev) HIP_TRY(hipEventRecord(ev, s));
-	launch_goff_apply(P, tiles_touched, bsums, reinterpret_cast<uint32_t*>(geom + gl.goff), recs, s);
+	launch_goff_apply(P, tiles_touched, bsums, reinterpret_cast<uint32_t*>(geom + gl.goff), s);
 	STAGE_CHECK("goff_apply", debug, s);
 	tm.mark();
 
@@ -595,7 +595,7 @@ static int backward_impl(int parts, int sh_g0, int sh_g1, int P, int D, int M, i
 
 	tm.mark();
 	if (R > 0) {
-		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, final_T, n_contrib, med_pos, dL_dpix,
+		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix,
 		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags, bwd_variant(s), s);
 		STAGE_CHECK("composite_bwd", debug, s);
 	}

@@ -99,8 +99,7 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
                            GsCtl* ctl, hipStream_t s);
 void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, int nblk, uint32_t* bsums, const uint32_t* refsums,
                       GsCtl* ctl, GsCtl* host_ctl, hipStream_t s);
-void launch_goff_apply(int P, const uint32_t* tiles_touched, const uint32_t* bsums, uint32_t* goff, GsRec* recs,
-                       hipStream_t s);
+void launch_goff_apply(int P, const uint32_t* tiles_touched, const uint32_t* bsums, uint32_t* goff, hipStream_t s);
 void launch_bin_scatter(int P, int gx, const int* radii, const uint32_t* tiles_touched, const GsRec* recs,
                         const uint2* ranges, uint32_t* cursor, uint64_t* keys, const GsCtl* ctl, uint32_t cap,
                         hipStream_t s);
@@ -158,7 +157,7 @@ struct BwdLayout {
 };
 // variant: 0 = default; other values select A/B variants of the kernel (gsr_set_option("bwd_variant", v))
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
-                          const uint32_t* point_list, const GsRec* recs, const float* final_T,
+                          const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const uint32_t* med_pos, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
                           int variant, hipStream_t s);

@@ -210,7 +210,7 @@ __device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restr
 template <bool FLAGS, bool TSEL>
 __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
     int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs,
+    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ med_pos,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
     const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags)
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		const uint32_t id = point_list[range.x + i];
 		const uint4 q3 = recs[id].q3;
 		const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
-		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(q3.w + (uint32_t)((ty - rminy) * rw + (tx - rminx))) * GSR_ROW_STRIDE);
+		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx))) * GSR_ROW_STRIDE);
 		dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -304,9 +304,14 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	auto load_id = [&](int t) -> uint32_t {   // id of list position t-1-srec (0 when outside the walk)
 		return (t > 0 && srec < min(GSR_BWD_BATCH, t)) ? point_list[range.x + (uint32_t)(t - 1 - srec)] : 0u;
 	};
+	// part 3 (q3: tile rect) also fetches the Gaussian's first row goff[id] into the unused .w
 	auto load_part = [&](int t, uint32_t id) -> float4 {
-		return (t > 0 && srec < min(GSR_BWD_BATCH, t)) ? reinterpret_cast<const float4*>(recs + id)[spart]
-		                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+		float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (t > 0 && srec < min(GSR_BWD_BATCH, t)) {
+			v = reinterpret_cast<const float4*>(recs + id)[spart];
+			if (spart == 3) v.w = __uint_as_float(goff[id]);
+		}
+		return v;
 	};
 	uint32_t id_next = load_id(bmax - GSR_BWD_BATCH);
 	float4 part_cur = load_part(bmax, load_id(bmax));
@@ -319,8 +324,8 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 			else if (spart == 1) sB[srec] = part_cur;
 			else if (spart == 2) sC[srec] = part_cur;
 			else {
-				// Gaussian-major row of this (tile, Gaussian) instance: goff[g] (carried in the record, q3.w) + raster
-				// index of the tile inside the Gaussian's tile rect -- the 64-B record is the only thing gathered
+				// Gaussian-major row of this (tile, Gaussian) instance: goff[g] (fetched with the record) + raster index
+				// of the tile inside the Gaussian's tile rect
 				const uint32_t q3x = __float_as_uint(part_cur.x), q3y = __float_as_uint(part_cur.y), q3w = __float_as_uint(part_cur.w);
 				const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
 				s_row[srec] = q3w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
@@ -459,7 +464,7 @@ void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s)
 }
 
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
-                          const uint32_t* point_list, const GsRec* recs, const float* final_T,
+                          const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const uint32_t* med_pos, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
                           int variant, hipStream_t s)
@@ -468,7 +473,7 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
 	const bool tsel = (variant & 1) != 0;
 #define GSR_LAUNCH_CB(FL, TS)                                                                                      \
 	hipLaunchKernelGGL((composite_bwd_kernel<FL, TS>), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, \
-	                   bg, ranges, point_list, recs, final_T, n_contrib, med_pos, dL_dpix, dL_dpix_depth, dL_dpix_median,      \
+	                   bg, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix, dL_dpix_depth, dL_dpix_median,      \
 	                   dL_dpix_opacity, rows, row_flags)
 	if (row_flags != nullptr) {
 		if (tsel) GSR_LAUNCH_CB(true, true); else GSR_LAUNCH_CB(true, false);

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 		rec.q1 = make_float4(-0.5f * conic_z, op, depth, pcut);
 		rec.q2 = make_float4(rgb[0], rgb[1], rgb[2], __int_as_float(mr));
 		rec.q3 = make_uint4((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16),
-		                    clamped, 0u);   // .w = goff, patched by goff_apply_kernel
+		                    clamped, my_tiles);
 		recs[idx] = rec;
 	}
 	if (idx < P) {
@@ -444,33 +444,41 @@ void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, int nblk, uint
 	                   host_ctl);
 }
 
-// goff[g] = bsums[block of g] + exclusive scan of tiles_touched inside the 256-Gaussian block; also written into the
-// record (q3.w) so that composite_bwd finds a Gaussian's first row in the 64-B record it gathers anyway.
-__global__ __launch_bounds__(GSR_PRE_BLOCK) void goff_apply_kernel(int P, const uint32_t* __restrict__ tiles_touched,
-                                                                   const uint32_t* __restrict__ bsums,
-                                                                   uint32_t* __restrict__ goff, GsRec* __restrict__ recs)
+// goff[g] = bsums[block of g] + exclusive scan of tiles_touched inside the 256-Gaussian block (4 Gaussians per thread:
+// a 256-thread workgroup finishes four blocks).
+__global__ __launch_bounds__(256) void goff_apply_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+                                                         const uint32_t* __restrict__ bsums, uint32_t* __restrict__ goff)
 {
-	__shared__ uint32_t s_w[4];
-	const int idx = blockIdx.x * GSR_PRE_BLOCK + threadIdx.x;
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const uint32_t v = idx < P ? tiles_touched[idx] : 0u;
-	const uint32_t incl = wave_incl_scan(v, lane);
-	if (lane == 63) s_w[wv] = incl;
-	__syncthreads();
-	uint32_t run = bsums[blockIdx.x] + incl - v;
-	for (int w = 0; w < wv; w++) run += s_w[w];
-	if (idx < P) {
-		goff[idx] = run;
-		if (v > 0) reinterpret_cast<uint32_t*>(recs + idx)[15] = run;   // GsRec::q3.w
-		if (idx == P - 1) goff[P] = run + v;
+	// wave w of the workgroup owns the 256-Gaussian block 4 * blockIdx.x + w: lane l holds Gaussians 4 l .. 4 l + 3
+	const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int base = blk * GSR_PRE_BLOCK + 4 * lane;
+	if (blk * GSR_PRE_BLOCK >= P) return;
+	uint32_t v[4];
+	if (base + 3 < P) {
+		const uint4 q = *reinterpret_cast<const uint4*>(tiles_touched + base);
+		v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; i++) v[i] = base + i < P ? tiles_touched[base + i] : 0u;
 	}
+	const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+	uint32_t run = bsums[blk] + wave_incl_scan(sum, lane) - sum;
+	uint32_t o[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) { o[i] = run; run += v[i]; }
+	if (base + 3 < P) {
+		*reinterpret_cast<uint4*>(goff + base) = make_uint4(o[0], o[1], o[2], o[3]);
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; i++) if (base + i < P) goff[base + i] = o[i];
+	}
+	if (base <= P - 1 && P - 1 < base + 4) goff[P] = o[P - 1 - base] + v[P - 1 - base];
 }
 
-void launch_goff_apply(int P, const uint32_t* tiles_touched, const uint32_t* bsums, uint32_t* goff, GsRec* recs,
-                       hipStream_t s)
+void launch_goff_apply(int P, const uint32_t* tiles_touched, const uint32_t* bsums, uint32_t* goff, hipStream_t s)
 {
-	hipLaunchKernelGGL(goff_apply_kernel, dim3((P + GSR_PRE_BLOCK - 1) / GSR_PRE_BLOCK), dim3(GSR_PRE_BLOCK), 0, s, P,
-	                   tiles_touched, bsums, goff, recs);
+	const int nblk = (P + GSR_PRE_BLOCK - 1) / GSR_PRE_BLOCK;
+	hipLaunchKernelGGL(goff_apply_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, P, tiles_touched, bsums, goff);
 }
 
 // ------------------------------------------------------------------------------------------------
