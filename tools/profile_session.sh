@@ -19,6 +19,11 @@ for p in $passes; do
     sq2)   timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM -d "$root/$out/sq2" -o k -- $bench > "$root/$out/sq2.log" 2>&1
            db=$(ls "$root/$out"/sq2/*/k_results.db "$root/$out"/sq2/k_results.db 2>/dev/null | head -1)
            python "$root/tools/pmc_dump.py" "$db" > "$root/$out/${wl}_pmc_sq2.txt" 2>&1 ;;
+    calib) ( cd "$root" && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$root/$out/cf" -o k -- "$root/tools/fetch_calib.bin" > "$root/$out/calib_fetch.log" 2>&1
+             db=$(ls "$root/$out"/cf/*/k_results.db "$root/$out"/cf/k_results.db 2>/dev/null | head -1); python "$root/tools/pmc_dump.py" "$db" > "$root/$out/calib_pmc_fetch.txt" 2>&1
+             timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$root/$out/cw" -o k -- "$root/tools/fetch_calib.bin" > "$root/$out/calib_write.log" 2>&1
+             db=$(ls "$root/$out"/cw/*/k_results.db "$root/$out"/cw/k_results.db 2>/dev/null | head -1); python "$root/tools/pmc_dump.py" "$db" > "$root/$out/calib_pmc_write.txt" 2>&1
+             rm -rf "$root/$out/cf" "$root/$out/cw" ) ;;
     fetch) timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$root/$out/fetch" -o k -- $bench > "$root/$out/fetch.log" 2>&1
            db=$(ls "$root/$out"/fetch/*/k_results.db "$root/$out"/fetch/k_results.db 2>/dev/null | head -1)
            python "$root/tools/pmc_dump.py" "$db" > "$root/$out/${wl}_pmc_fetch.txt" 2>&1 ;;
