@@ -351,36 +351,51 @@ __device__ __forceinline__ bool gs_box_may_touch(const float4 A, const float4 B,
 // 64*RF-float chunk, 1 KiB per load instruction, and each lane then picks its row out of the wave's LDS slab.
 // `chunk` must be 16-B aligned (base 16-B aligned; 64 rows are a multiple of 256 B).  Rows whose bit in `mask`
 // is clear are not fetched.  Caller brackets these with __builtin_amdgcn_wave_barrier() (LDS is in-order per wave).
+// Rows sit in the slab with a PADDED stride gs_row_stride<RF>(): a stride of 48 floats (degree 3) maps the
+// 64 lanes' b128 row accesses onto 8 banks out of 32 (round 2: 78 % of the SH kernel's LDS cycles were bank
+// conflicts); 52 floats spread every 8 lanes over all 32 banks.  Strides that are not multiples of 4 floats are odd
+// enough already and keep the plain layout (their float4 copies straddle rows).
+template <int RF>
+__device__ __host__ constexpr int gs_row_stride() { return (RF % 4 == 0 && RF > 0) ? RF + 4 : RF; }
+
 template <int RF>
 __device__ __forceinline__ void gs_wave_rows_to_lds(const float* __restrict__ chunk, int nrows, unsigned long long mask,
                                                     float* __restrict__ slab, int lane)
 {
+	constexpr int RFP = gs_row_stride<RF>();
 	const int nfl = nrows * RF, nv = nfl >> 2;
 #pragma unroll
 	for (int it = 0; it < (16 * RF + 63) / 64; it++) {
 		const int j = it * 64 + lane;
 		if (j < nv) {
 			const int r0 = (4 * j) / RF, r1 = (4 * j + 3) / RF;
-			if (((mask >> r0) | (mask >> r1)) & 1ull)
-				reinterpret_cast<float4*>(slab)[j] = reinterpret_cast<const float4*>(chunk)[j];
+			if (((mask >> r0) | (mask >> r1)) & 1ull) {
+				const int at = (RFP == RF) ? 4 * j : r0 * RFP + (4 * j - r0 * RF);   // RF % 4 == 0: a float4 stays inside its row
+				*reinterpret_cast<float4*>(slab + at) = reinterpret_cast<const float4*>(chunk)[j];
+			}
 		}
 	}
 	const int t = (nv << 2) + lane;   // < 4 trailing floats, only in the last (partial) wave of a launch
-	if (t < nfl && ((mask >> (t / RF)) & 1ull)) slab[t] = chunk[t];
+	if (t < nfl && ((mask >> (t / RF)) & 1ull)) slab[(t / RF) * RFP + t % RF] = chunk[t];
 }
 
 template <int RF>
 __device__ __forceinline__ void gs_wave_lds_to_rows(float* __restrict__ chunk, int nrows, const float* __restrict__ slab,
                                                     int lane)
 {
+	constexpr int RFP = gs_row_stride<RF>();
 	const int nfl = nrows * RF, nv = nfl >> 2;
 #pragma unroll
 	for (int it = 0; it < (16 * RF + 63) / 64; it++) {
 		const int j = it * 64 + lane;
-		if (j < nv) reinterpret_cast<float4*>(chunk)[j] = reinterpret_cast<const float4*>(slab)[j];
+		if (j < nv) {
+			const int r0 = (4 * j) / RF;
+			const int at = (RFP == RF) ? 4 * j : r0 * RFP + (4 * j - r0 * RF);
+			reinterpret_cast<float4*>(chunk)[j] = *reinterpret_cast<const float4*>(slab + at);
+		}
 	}
 	const int t = (nv << 2) + lane;
-	if (t < nfl) chunk[t] = slab[t];
+	if (t < nfl) chunk[t] = slab[(t / RF) * RFP + t % RF];
 }
 
 // lane-private row in the slab <-> registers (float4 accesses when rows are 16-B multiples)

@@ -790,6 +790,13 @@ __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __re
 // preprocess_bwd_sh with the SH rows and their gradients staged through LDS wave-cooperatively (gs_wave_rows_to_lds):
 // used when the stored rows hold exactly the active degree (M == (D+1)^2, the steady state) and the bases are
 // 16-B aligned; every global access is then a full 1 KiB-per-instruction stream.  Same arithmetic, same results.
+// floats per staged SH row (>= 1 so that the templates stay well-formed at degree 0 with split storage)
+constexpr int gs_sh_row_floats(int deg, bool split)
+{
+	const int rf = split ? ((deg + 1) * (deg + 1) - 1) * 3 : (deg + 1) * (deg + 1) * 3;
+	return rf > 0 ? rf : 1;
+}
+
 template <int D, bool SPLIT>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
     int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
@@ -809,8 +816,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 	if (nrows <= 0) return;   // wave-uniform
 	const bool vis = idx < P && radii[idx] > 0;
 	const unsigned long long vm = __ballot(vis);
-	float* slab = sh_slab + wv * 64 * RF;
-	float* row = slab + lane * RF;
+	constexpr int RFP = gs_row_stride<RFA>();   // padded row stride in the slab (bank conflicts)
+	float* slab = sh_slab + wv * 64 * RFP;
+	float* row = slab + lane * RFP;
 	if (RF > 0) {
 		const float* src = (SPLIT ? shs_rest : shs) + (size_t)g0 * RF;
 		if (vm) gs_wave_rows_to_lds<RFA>(src, nrows, vm, slab, lane);
@@ -848,8 +856,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 			float* ddc = dL_dsh + 3 * (size_t)idx;
 			ddc[0] = ddc[1] = ddc[2] = 0.f;
 		}
+		if (RF % 4 == 0) {
 #pragma unroll
-		for (int i = 0; i < RF; i++) row[i] = 0.f;
+			for (int i = 0; i < RF / 4; i++) reinterpret_cast<float4*>(row)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		} else {
+#pragma unroll
+			for (int i = 0; i < RF; i++) row[i] = 0.f;
+		}
 	}
 	if (RF > 0) {
 		__builtin_amdgcn_wave_barrier();
@@ -974,7 +987,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 		                  (!split || NCd == 1 || (stream_in != nullptr && stream_out != nullptr));
 #define GSR_LAUNCH_SHC(DEG, SPL)                                                                                  \
 	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL>), grid, block,                                       \
-	                   sizeof(float) * 256 * (SPL ? ((DEG + 1) * (DEG + 1) - 1) * 3 : (DEG + 1) * (DEG + 1) * 3), s, sh_g0, sh_end, \
+	                   sizeof(float) * 256 * gs_row_stride<gs_sh_row_floats(DEG, SPL)>(), s, sh_g0, sh_end, \
 	                   a.means3D, a.radii, a.shs, a.shs_rest, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
 		if (coop && split) {
 			switch (a.D) {
