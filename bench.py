@@ -334,12 +334,15 @@ def main():
             achieved = alg_bytes / (comp_ms * 1e-3) / 1e9
             roof = {"kernel": "composite_fwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                    "traffic_upper": (counters or {}).get("composite_fwd", {}).get("traffic_upper_bytes"),
                     "algorithmic_bytes": alg_bytes, "avg_ms": round(comp_ms, 4),
                     "algorithmic_bytes_with_reference_R": R_ref * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8),
                     "valu": valu_issue(counters, "composite_fwd", comp_ms),
-                    "note": "algorithmic bytes use the instances actually staged (tight binning); the kernel is VALU-issue "
-                            "bound (256 pixel evaluations per staged 48-B record): `valu.issue_frac` is the fraction of the "
-                            "SIMDs' issue cycles its VALU instructions fill, see DESIGN.md s4"}
+                    "note": "algorithmic bytes use the instances actually staged (tight binning); `traffic` = FETCH_SIZE + "
+                            "WRITE_SIZE of the committed PMC passes with the access-pattern calibration of "
+                            "profiles/r02_fetch_write_calibration.txt (`traffic_upper` = 2*FETCH + WRITE); the kernel is "
+                            "VALU-issue bound (256 pixel evaluations per staged 48-B record): `valu.issue_frac` is the "
+                            "fraction of the SIMDs' issue cycles its VALU instructions fill, see DESIGN.md s4"}
         line = {
             "metric": "Mpixels/s fwd+bwd @1M Gaussians 1920x1080" if a.workload == "C3" and not a.fwd_only
                       else f"Mpixels/s {'fwd' if a.fwd_only else 'fwd+bwd'} @{a.workload}",
