@@ -123,36 +123,9 @@ __device__ __forceinline__ bool gs_tight_rect(float px, float py, float ca, floa
 	return rmaxx > rminx && rmaxy > rminy;
 }
 
+// two-component FP32 vector and its fused multiply-add (v_pk_fma_f32): composite_fwd blends (R, G) and (B, depth)
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-// gs_exp on two values at once: the same IEEE operations per element as gs_exp (bit-identical results),
-// issued as packed FP32 instructions.  Arguments far below -80 give garbage that callers mask.
-// A packed instruction takes at most one scalar (SGPR / literal) source, so two of the constants have to sit in VGPRs;
-// a caller with a hot loop passes them in as loop-invariant registers (GS_EXP2_CONSTANTS) instead of having them
-// re-materialised by two v_mov per evaluation.
-#define GS_EXP2_CONSTANTS(magic, c5)                                                   \
-	v2f magic = {12582912.0f, 12582912.0f}, c5 = {0x1.5c08e6p-10f, 0x1.5c08e6p-10f};   \
-	asm volatile("" : "+v"(magic), "+v"(c5))
-__device__ __forceinline__ v2f gs_exp2(v2f p, v2f MAGIC, v2f C5)
-{
-	const v2f LOG2E = {0x1.715476p+0f, 0x1.715476p+0f};
-	const v2f tm = vfma(p, LOG2E, MAGIC);
-	const v2f nf = tm - MAGIC;
-	const v2f f = vfma(p, LOG2E, -nf);
-	v2f y = C5;
-	y = vfma(y, f, v2f{0x1.3d0c52p-7f, 0x1.3d0c52p-7f});
-	y = vfma(y, f, v2f{0x1.c6b6e4p-5f, 0x1.c6b6e4p-5f});
-	y = vfma(y, f, v2f{0x1.ebf918p-3f, 0x1.ebf918p-3f});
-	y = vfma(y, f, v2f{0x1.62e428p-1f, 0x1.62e428p-1f});
-	y = vfma(y, f, v2f{0x1.000002p+0f, 0x1.000002p+0f});
-	const v2i r = __builtin_bit_cast(v2i, y) + (__builtin_bit_cast(v2i, tm) << 23);
-	return __builtin_bit_cast(v2f, r);
-}
-__device__ __forceinline__ v2f gs_exp2(v2f p)
-{
-	return gs_exp2(p, v2f{12582912.0f, 12582912.0f}, v2f{0x1.5c08e6p-10f, 0x1.5c08e6p-10f});
-}
 
 struct M3 { float m[3][3]; };   // m[col][row]
 
@@ -296,11 +269,9 @@ __device__ __forceinline__ void cov2d_common(const float3 mean, float fx, float 
 // ---------------------------------------------------------------------------------------------
 // Pixel <-> slot mapping of the tile-major per-pixel state (final_T, n_contrib): slot s of a 16x16 tile is
 // pixel (lx, ly) of 8x8 quadrant q = s>>6 = (ly>>3)*2 + (lx>>3), lane l = s&63 = (ly&7)*8 + (lx&7).
-// composite_fwd runs 4 wave64 per tile, wave q on quadrant q (slot = thread id); composite_bwd runs 2
-// wave64 per tile: wave w owns the 8-wide, 16-tall half tile (columns 8w..8w+7) and lane l owns the two
-// pixels (8w + (l&7), l>>3) and (8w + (l&7), (l>>3) + 8), i.e. slots w*64 + l and (2 + w)*64 + l.
-// (A 2-pixel-per-lane forward was measured too: 0.55 ms vs 0.46 ms at C3 -- the forward has no cross-lane
-// reduction to amortise and the larger culling box costs more than packed arithmetic saves.)
+// composite_fwd and composite_bwd both run 4 wave64 per tile, wave q on quadrant q (slot = thread id).
+// (A 2-pixel-per-lane forward was measured in round 1: 0.55 ms vs 0.46 ms at C3 -- the larger culling box costs
+// more than packed arithmetic saves; round 2 moved the backward to this layout as well)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gs_pixel_of_thread(int tid, int& lx, int& ly)
 {

@@ -1,9 +1,10 @@
 // gsr_kernels_bwd.hip -- backward kernels of libgsrast for gfx950 (MI355X, wave64).
 //
-//   composite_bwd    one workgroup of two wave64 per tile, two pixels per lane (packed FP32), back-to-front; per
-//                    (wave, instance) the ten gradient components are reduced over the lanes with lane swaps +
-//                    four DPP steps and added to the instance's LDS row; each (tile, Gaussian) instance leaves one
-//                    plain-stored 48-B row in Gaussian-major order -- no global atomics
+//   composite_bwd    one workgroup of four wave64 per tile, one pixel per lane, back to front; per (wave, instance)
+//                    pair two per-pixel scalars go through an LDS slab and are turned into the ten per-Gaussian
+//                    sums by lanes re-mapped to (pair, pixel row) -- a transposition instead of a cross-lane
+//                    reduction tree; each (tile, Gaussian) instance leaves one plain-stored 48-B row in
+//                    Gaussian-major order -- no atomics of any kind
 //                    (replaces backward.cu:415-610 renderCUDA: 11-12 atomicAdd per (pixel, Gaussian))
 //   (row offsets goff: per-block sums in preprocess_fwd + tile_scan block 1 + goff_apply, gsr_kernels_fwd.hip)
 //   preprocess_bwd   one lane per Gaussian: fixed-order sum of its rows (fetched wave-cooperatively through LDS),
@@ -24,36 +25,12 @@ __device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
                                             0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                             -0.5900435899266435f};
 
-// Cross-lane reduction of the per-pixel gradient contributions of one (wave, Gaussian) pair.
-// Every VALU instruction of a wave64 costs 4 cycles on gfx950, so the reduction is built to need as
-// few instructions as possible:
-//   row_sum16      4 fused v_add_f32_dpp: sum over each 16-lane row, valid in every lane of the row;
-//   half/row_swap  v_permlane32_swap / v_permlane16_swap + add: fold the two halves / the row pairs of TWO
-//                  quantities into one register (see below).
-// One lane per row then issues ONE ds_add_f32 for four quantities at once.
-__device__ __forceinline__ float row_sum16(float v)
-{
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-	v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
-	return v;
-}
-// half_swap_sum(a, b): lanes 0-31 get a[l] + a[l+32], lanes 32-63 get b[l-32] + b[l]   (1 swap + 1 add for
-// two quantities); row_swap_sum(p, q): rows (0,1,2,3) get p.r0+p.r1, q.r0+q.r1, p.r2+p.r3, q.r2+q.r3.
-// Doing these "transposing" cross-row steps FIRST shrinks ten per-lane quantities to three registers
-// (each 16-lane row carrying a different quantity) before the four within-row DPP steps, so the whole
-// 64-lane reduction of ten quantities costs 8 swaps + 8 adds + 12 DPP adds instead of 60 DPP adds.
-// three independent row sums, interleaved step by step: a DPP read needs two wait states after the VALU
-// write of its source, which the other two chains fill (no s_nop)
+// Lane-swap folds used by phase 2 of composite_bwd (lanes that belong to the same pair sit 8, 16 and 32 lanes apart):
+//   half_swap_sum(a, b): lanes 0-31 get a[l] + a[l+32], lanes 32-63 get b[l-32] + b[l]   (1 swap + 1 add for two
+//   quantities); row_swap_sum(p, q): 16-lane rows (0,1,2,3) get p.r0+p.r1, q.r0+q.r1, p.r2+p.r3, q.r2+q.r3.
+// Doing these "transposing" steps on pairs of quantities shrinks ten per-lane quantities to three registers whose
+// rows carry different quantities; GSR_DPP_ADD(v, ctrl) is a fused v_add_f32_dpp.
 #define GSR_DPP_ADD(v, ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
-__device__ __forceinline__ void row_sum16x3(float& a, float& b, float& c)
-{
-	GSR_DPP_ADD(a, 0xB1); GSR_DPP_ADD(b, 0xB1); GSR_DPP_ADD(c, 0xB1);      // quad_perm [1,0,3,2]
-	GSR_DPP_ADD(a, 0x4E); GSR_DPP_ADD(b, 0x4E); GSR_DPP_ADD(c, 0x4E);      // quad_perm [2,3,0,1]
-	GSR_DPP_ADD(a, 0x141); GSR_DPP_ADD(b, 0x141); GSR_DPP_ADD(c, 0x141);   // row_half_mirror
-	GSR_DPP_ADD(a, 0x140); GSR_DPP_ADD(b, 0x140); GSR_DPP_ADD(c, 0x140);   // row_mirror
-}
 __device__ __forceinline__ float half_swap_sum(float a, float b)
 {
 	// v_permlane32_swap(X, Y): X.rows23 <-> Y.rows01
