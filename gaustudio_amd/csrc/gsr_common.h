@@ -123,6 +123,21 @@ __device__ __forceinline__ bool gs_tight_rect(float px, float py, float ca, floa
 	return rmaxx > rminx && rmaxy > rminy;
 }
 
+// Streaming accesses (read once / written once, never re-read by the same kernel): the nontemporal hint keeps
+// them from displacing the records, keys and rows that ARE re-read in L2 / Infinity Cache.  Measured at C3: SH
+// backward + the next forward's preprocess -0.015 ms together.
+typedef float gs_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gs_ld_stream(const float4* p)
+{
+	const gs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const gs_f4v*>(p));
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gs_st_stream(float4* p, const float4 v)
+{
+	__builtin_nontemporal_store(gs_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<gs_f4v*>(p));
+}
+__device__ __forceinline__ void gs_st_stream(float* p, const float v) { __builtin_nontemporal_store(v, p); }
+
 // two-component FP32 vector and its fused multiply-add (v_pk_fma_f32): composite_fwd blends (R, G) and (B, depth)
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -342,7 +357,7 @@ __device__ __forceinline__ void gs_wave_rows_to_lds(const float* __restrict__ ch
 			const int r0 = (4 * j) / RF, r1 = (4 * j + 3) / RF;
 			if (((mask >> r0) | (mask >> r1)) & 1ull) {
 				const int at = (RFP == RF) ? 4 * j : r0 * RFP + (4 * j - r0 * RF);   // RF % 4 == 0: a float4 stays inside its row
-				*reinterpret_cast<float4*>(slab + at) = reinterpret_cast<const float4*>(chunk)[j];
+				*reinterpret_cast<float4*>(slab + at) = gs_ld_stream(reinterpret_cast<const float4*>(chunk) + j);
 			}
 		}
 	}
@@ -362,7 +377,7 @@ __device__ __forceinline__ void gs_wave_lds_to_rows(float* __restrict__ chunk, i
 		if (j < nv) {
 			const int r0 = (4 * j) / RF;
 			const int at = (RFP == RF) ? 4 * j : r0 * RFP + (4 * j - r0 * RF);
-			reinterpret_cast<float4*>(chunk)[j] = *reinterpret_cast<const float4*>(slab + at);
+			gs_st_stream(reinterpret_cast<float4*>(chunk) + j, *reinterpret_cast<const float4*>(slab + at));
 		}
 	}
 	const int t = (nv << 2) + lane;

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 #pragma unroll
 			for (int it = 0; it < (GSR_SUM_SLAB * 3 + 63) / 64; it++) {
 				const uint32_t j = it * 64 + lane;
-				if (j < cnt * 3 && (!flagged || fl[j / 3])) slab[j] = src[j];   // unwritten rows are not fetched
+				if (j < cnt * 3 && (!flagged || fl[j / 3])) slab[j] = gs_ld_stream(src + j);   // unwritten rows are not fetched; read once
 			}
 			__builtin_amdgcn_wave_barrier();
 			const uint32_t lo = max(b, base), hi = min(e, base + cnt);
@@ -666,12 +666,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] = dmean[i];
+	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] = dmean[i];   // the SH stage adds to it next: stays cached
 #pragma unroll
-	for (int i = 0; i < 6; i++) dL_dcov[6 * (size_t)idx + i] = dcov[i];
+	for (int i = 0; i < 6; i++) gs_st_stream(dL_dcov + 6 * (size_t)idx + i, dcov[i]);
 #pragma unroll
-	for (int i = 0; i < 3; i++) dL_dscale[3 * (size_t)idx + i] = dscale[i];
-	*reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+	for (int i = 0; i < 3; i++) gs_st_stream(dL_dscale + 3 * (size_t)idx + i, dscale[i]);
+	gs_st_stream(reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx), make_float4(dq[0], dq[1], dq[2], dq[3]));
 }
 
 // ------------------------------------------------------------------------------------------------

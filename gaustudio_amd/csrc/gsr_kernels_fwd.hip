@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 					if (sh_vec4 && (NC * 3) % 4 == 0) {
 #pragma unroll
 						for (int i = 0; i < NC * 3 / 4; i++) {
-							const float4 v = reinterpret_cast<const float4*>(shp)[i];
+							const float4 v = reinterpret_cast<const float4*>(shp)[i];   // (not nontemporal: a lane's 12 loads share cache lines)
 							sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
 						}
 					} else {
