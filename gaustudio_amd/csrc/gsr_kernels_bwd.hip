@@ -124,7 +124,7 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 //         9 sum w dL_ddepth + (median gradient of the pixels whose median this Gaussian is)
 // tab: per pixel (sx, row) two float4 at [row * GSR_TAB_ROW + 2 sx]: {dL_dpixel rgb, dL_ddepth}, {dL_dopacity,
 // dL_dmedian, med_pos bits, -}.
-__device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restrict__ slab, const int unit_j,
+__device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restrict__ slab, const unsigned long long unit_js,
                                               const float4* __restrict__ sA, const float4* __restrict__ tab, const float fbx,
                                               const float fby, const int top, float* __restrict__ plane, const int lane)
 {
@@ -132,7 +132,8 @@ __device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restr
 	constexpr int PPL = GSR_BWD_UNITS;          // pixels per lane
 	const int u = lane & (GSR_BWD_UNITS - 1), g = lane / GSR_BWD_UNITS;
 	const bool act = u < n;
-	const int j = act ? unit_j : 0;             // batch index of the lane's pair (kept per lane by phase 1)
+	// batch indices of the slab's pairs, 8 bits each, packed by phase 1 with scalar instructions (wave-uniform)
+	const int j = act ? (int)((unit_js >> (8 * u)) & 0xffull) : 0;
 	const float2 ctr = *reinterpret_cast<const float2*>(&sA[j]);   // Gaussian centre
 	const uint32_t pos1 = (uint32_t)(top - j);   // list position + 1 of the pair's instance
 	const int prow = NG == 8 ? g : (g >> 1), pcol0 = NG == 8 ? 0 : ((g & 1) << 2);   // first pixel of the lane's group
@@ -320,8 +321,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		if (lane < cnt && top - 1 - lane < wmax) hit = gs_box_may_touch(sA[lane], sB[lane], fbx, fby, bx1, by1);
 		unsigned long long m = __ballot(hit);
 		int nu = 0;        // pairs in the slab (wave-uniform)
-		int unit_j = 0;    // lane u + UNITS*g: batch index of pair u of the slab
-		const int lane_u = lane & (GSR_BWD_UNITS - 1);
+		unsigned long long unit_js = 0ull;   // batch indices of the slab's pairs, 8 bits each (wave-uniform: SGPRs)
 		// one (wave, instance) pair; returns with the pair's (q, w) in the slab, or without a trace if no pixel is live
 		auto pair = [&](const float4 A, const float4 B, const float4 Cc, const int j) {
 			const int pos = top - 1 - j;   // == `contributor` after decrement (backward.cu:520)
@@ -353,14 +353,15 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 			S = FMA(alpha, diff, S);
 			T_ = TSEL ? (live ? test_T : T_) : test_T;
 			slab[nu * GSR_SLAB_STRIDE + lane] = make_float2(q, w);
-			unit_j = (lane_u == nu) ? j : unit_j;
+			unit_js |= (unsigned long long)j << (8 * nu);
 			nu++;
 			if (nu == GSR_BWD_UNITS) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
-				gs_bwd_phase2(GSR_BWD_UNITS, slab, unit_j, sA, s_tab[wv], fbx, fby, top, plane, lane);
+				gs_bwd_phase2(GSR_BWD_UNITS, slab, unit_js, sA, s_tab[wv], fbx, fby, top, plane, lane);
 				__builtin_amdgcn_wave_barrier();
 				nu = 0;
+				unit_js = 0ull;
 			}
 		};
 		// the record of the NEXT surviving instance is read (wave-uniform LDS reads) while the current pair computes:
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		if (nu > 0) {
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-			gs_bwd_phase2(nu, slab, unit_j, sA, s_tab[wv], fbx, fby, top, plane, lane);
+			gs_bwd_phase2(nu, slab, unit_js, sA, s_tab[wv], fbx, fby, top, plane, lane);
 		}
 		// flush: one thread per staged instance adds the four planes in fixed order and stores the 48-B row (plain
 		// stores, no global atomics), zeros included: every row of the scratch is written exactly once per backward,
