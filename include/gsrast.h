@@ -41,7 +41,10 @@ extern "C" {
 #define GSR_ERR_ALLOC (-4)       /* an allocator callback returned NULL */
 
 /* Replaces std::function<char*(size_t)> (rasterizer.h:38-40): must return device memory of at
- * least `bytes` bytes, 256-byte aligned, that stays valid until the matching backward has run. */
+ * least `bytes` bytes, 256-byte aligned, that stays valid until the matching backward has run.
+ * gsr_forward may call the BINNING allocator twice (first with its remembered capacity, then -- only if that turned
+ * out too small -- with the exact size; the second result replaces the first, which may be released in stream
+ * order, as torch's resize_ does). */
 typedef char* (*gsr_alloc_fn)(void* ctx, size_t bytes);
 
 /* ABI version of this header (bumped on any signature change). */
