@@ -36,7 +36,7 @@ ms = e0.elapsed_time(e1) / reps
 c, t, w, s = vol.export_voxels()
 updates = int(w.sum().item()) // (reps + 1)
 print(f"integrate: {N} points, {updates} voxel updates ({updates / N:.1f} per ray), {ms:.3f} ms = {N / ms / 1e3:.0f} Mpoints/s, "
-      f"{updates / ms / 1e6:.2f} G atomic updates/s; {vol.occupied_blocks()[0].shape[0]} blocks, {c.shape[0]} voxels")
+      f"{updates / ms / 1e6:.2f} G voxel updates/s (pre-aggregated per workgroup in LDS); {vol.occupied_blocks()[0].shape[0]} blocks, {c.shape[0]} voxels")
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 V, T = vol.extract_triangle_mesh_device(min_weight=5)
