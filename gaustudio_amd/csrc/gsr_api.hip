@@ -134,6 +134,7 @@ std::atomic<int> g_opt_tight{env_int("GSR_TIGHT_BINNING", 1)};     // bin into g
 std::atomic<int> g_opt_cull{env_int("GSR_CULL", 1)};               // composite_fwd wave culling + pcut pre-test
 std::atomic<int> g_opt_bwd_variant{env_int("GSR_BWD_VARIANT", -1)};   // -1: from gsr_selftest; bit 0: select on T
 std::atomic<int> g_opt_speculative{env_int("GSR_SPECULATIVE", 1)}; // launch binning + compositing before R is known
+std::atomic<int> g_opt_band_lo{0}, g_opt_band_hi{0};               // tile rows [lo, hi) this process renders (hi <= 0: all)
 // per device: capacity (instances) the binning buffer is allocated with while R is still in flight, and whether
 // the last frame had a tile list long enough for the radix path (which needs the second key buffer)
 struct DevState {
@@ -378,6 +379,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.prefiltered = prefiltered;
 	a.shs_rest = shs_rest; a.act = activation_flags;
 	a.tight = g_opt_tight.load() != 0;
+	a.band_lo = g_opt_band_lo.load();
+	a.band_hi = g_opt_band_hi.load();
 
 	tm.mark();
 	uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + gl.tiles_touched);
@@ -655,6 +658,8 @@ int gsr_set_option(const char* name, int value)
 	else if (n == "cull") g_opt_cull.store(value);
 	else if (n == "bwd_variant") g_opt_bwd_variant.store(value);
 	else if (n == "speculative") g_opt_speculative.store(value);
+	else if (n == "tile_row_lo") g_opt_band_lo.store(value > 0 ? value : 0);
+	else if (n == "tile_row_hi") g_opt_band_hi.store(value);
 	else if (n == "bin_capacity") {   // capacity assumed for the NEXT forward on the current device (tests: force the re-launch path)
 		DevState& ds = dev_state();
 		ds.cap.store(value > 0 ? (uint32_t)value : 0u);
@@ -671,6 +676,8 @@ int gsr_get_option(const char* name)
 	if (n == "cull") return g_opt_cull.load();
 	if (n == "bwd_variant") return g_opt_bwd_variant.load();
 	if (n == "speculative") return g_opt_speculative.load();
+	if (n == "tile_row_lo") return g_opt_band_lo.load();
+	if (n == "tile_row_hi") return g_opt_band_hi.load();
 	if (n == "bin_capacity") return (int)dev_state().cap.load();
 	return -1;
 }

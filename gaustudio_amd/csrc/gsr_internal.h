@@ -87,6 +87,7 @@ struct FwdArgs {
 	const float* shs_rest;   // f1: SH given as [P,1,3] (shs) + [P,M-1,3] (shs_rest); nullptr = shs holds all M
 	int act;                 // f1: GSR_ACT_* flags
 	int tight;               // 1: bin into the tight rect (gs_tight_rect); 0: the reference's square (A/B, debugging)
+	int band_lo, band_hi;    // only tile rows [band_lo, band_hi) are binned (tile-grid sharding of one view); hi <= 0: all
 };
 
 // --- launchers (gsr_kernels_fwd.hip) ---

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, int act_arg, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const GsCam* __restrict__ cam, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-    int gx, int gy, int prefiltered, int sh_vec4, int tight, int* __restrict__ radii, GsRec* __restrict__ recs,
+    int gx, int gy, int prefiltered, int sh_vec4, int tight, int band_lo, int band_hi, int* __restrict__ radii,
+    GsRec* __restrict__ recs,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ bsums, uint32_t* __restrict__ refsums,
     uint32_t* __restrict__ tile_count, GsCtl* __restrict__ ctl)
 {
@@ -245,6 +246,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 		// reference's definition); a Gaussian that cannot reach alpha >= 1/255 anywhere is binned nowhere
 		if (tight && !gs_tight_rect(pix_x, pix_y, conic_x, conic_y, conic_z, op, gx, gy, rminx, rminy, rmaxx, rmaxy))
 			rminx = rminy = rmaxx = rmaxy = 0;
+		// tile-grid sharding of one view across GPUs (gsr_set_option("tile_row_lo" / "tile_row_hi")): this process only
+		// bins -- and therefore only composites and differentiates -- the tile rows of its band
+		rminy = max(rminy, band_lo);
+		rmaxy = min(rmaxy, band_hi);
+		if (rmaxy <= rminy) rminx = rminy = rmaxx = rmaxy = 0;
 		my_tiles = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
 		// pcut: power < pcut  ==>  op*exp(power) < 1/255 with a 1e-3 margin, so skipping the pair is
 		// bit-identical to evaluating it and failing `alpha < 1/255` (forward.cu:346).  Clamped to the
@@ -299,7 +305,8 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 	hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, RAW>), grid, block, 0, s, a.P, a.M, a.means3D, a.scales,        \
 	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.shs_rest, a.act, a.cov3D_precomp,       \
 	                   a.colors_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, focal_x, focal_y, il.gx, il.gy,     \
-	                   a.prefiltered, sh_vec4, a.tight, radii, recs, tiles_touched, bsums, refsums, tile_count, ctl)
+	                   a.prefiltered, sh_vec4, a.tight, a.band_lo, a.band_hi > 0 ? a.band_hi : il.gy, radii, recs,          \
+	                   tiles_touched, bsums, refsums, tile_count, ctl)
 #define GSR_LAUNCH_PRE_D(RAW)                          \
 	switch (D) {                                       \
 		case 0: GSR_LAUNCH_PRE(0, RAW); break;         \

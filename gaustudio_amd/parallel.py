@@ -226,3 +226,44 @@ def render_views_and_reduce(render_fn, views: Iterable, bucket: FlatGradBucket,
             bucket.disarm()     # nothing consumed it (no backward ran): do not leak into a later step
     allreduce_gaussian_grads(bucket, group)
     return outs
+
+
+# ---- tile-grid sharding of ONE view ("additionally possible" for a single 4K view) ------------------
+def tile_row_band(height: int, rank: Optional[int] = None, world_size: Optional[int] = None):
+    """The 16-pixel tile rows [lo, hi) of an image of `height` pixels that rank `rank` renders when one view is
+    split across `world_size` processes (contiguous bands of equal height, the last one possibly shorter)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rows = (height + 15) // 16
+    per = (rows + world_size - 1) // world_size
+    return min(rows, rank * per), min(rows, (rank + 1) * per)
+
+
+class tile_band:
+    """Context manager: inside it the rasterizer of THIS process bins, composites and differentiates only the tile rows
+    [lo, hi) of every view (libgsrast option "tile_row_lo" / "tile_row_hi").  Preprocessing stays replicated (every
+    rank projects every Gaussian: 0.06 ms per million), there is no exchange in the forward; pixels outside the band
+    come back as an empty scene's, and the per-Gaussian gradients are the band's partial sums -- the same flat
+    all-reduce as for view sharding (allreduce_gaussian_grads) completes them.  A loss must only use the band's rows
+    (band_rows())."""
+
+    def __init__(self, lo: int, hi: int):
+        self.lo, self.hi = int(lo), int(hi)
+
+    def band_rows(self, height: int):
+        return slice(min(height, 16 * self.lo), min(height, 16 * self.hi))
+
+    def __enter__(self):
+        from . import _C
+        self._old = (_C.get_option("tile_row_lo"), _C.get_option("tile_row_hi"))
+        _C.set_option("tile_row_lo", self.lo)
+        _C.set_option("tile_row_hi", self.hi if self.hi > 0 else -1)
+        return self
+
+    def __exit__(self, *exc):
+        from . import _C
+        _C.set_option("tile_row_lo", self._old[0])
+        _C.set_option("tile_row_hi", self._old[1])
+        return False

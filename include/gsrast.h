@@ -163,13 +163,17 @@ int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int
                        float* dL_dscale, float* dL_drot, char* scratch, int debug, void* stream);
 
 /* Process-wide tunables (also read from the environment at load: GSR_TIGHT_BINNING, GSR_CULL, GSR_BWD_VARIANT,
- * GSR_SPECULATIVE).  None of them changes a result bit; they exist for A/B measurements and parity tests:
+ * GSR_SPECULATIVE).  The first five never change a result bit; they exist for A/B measurements and parity tests:
  *   "tight_binning" 1|0  bin each Gaussian into the tight sub-rect of the reference's getRect square (default 1);
  *   "cull"          1|0  wave-level culling + pcut pre-test in composite_fwd (default 1);
  *   "speculative"   1|0  enqueue binning + compositing before the host has read the instance count (default 1);
  *   "bwd_variant"   -1 = auto (gsr_selftest), bit 0 = keep the select on T in composite_bwd;
  *   "bin_capacity"  n    binning capacity (instances) assumed by the next gsr_forward on the current device
- *                        (0 = forget; tests use a small n to force the re-allocate-and-relaunch path). */
+ *                        (0 = forget; tests use a small n to force the re-allocate-and-relaunch path);
+ *   "tile_row_lo", "tile_row_hi"  tile-grid sharding of ONE view across processes: only the 16-pixel
+ *                        tile rows [lo, hi) are binned, composited and differentiated; pixels outside the band come
+ *                        back as an empty scene's, gradients are the band's partial sums (SUM them over the ranks);
+ *                        radii and num_rendered keep describing the whole view.  hi <= 0: the whole image. */
 int gsr_set_option(const char* name, int value);
 int gsr_get_option(const char* name);
 

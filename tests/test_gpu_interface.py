@@ -7,7 +7,7 @@ import torch
 
 from gaustudio_amd import scenes
 
-from util import hip_forward, scene_kwargs, to_np
+from util import hip_backward_raw, hip_forward, scene_kwargs, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -199,3 +199,39 @@ def test_grad_arena_gradients_are_born_in_the_flat_bucket():
     (c, _, d, m, o), leaves3, _ = _render(sc, cam, rs)
     torch.autograd.backward([c, d, m, o], g)
     assert all(p.grad.data_ptr() != v.data_ptr() for p, v in zip(leaves3.values(), views))
+
+
+def test_tile_band_sharding_of_one_view():
+    """one view split by tile rows across processes (emulated here by rendering the bands one after the
+    other).  Inside its band every output bit equals the full render's, outside it the image is an empty scene's,
+    radii / num_rendered describe the whole view, and the bands' per-Gaussian gradients SUM to the full view's."""
+    from gaustudio_amd import parallel
+    cam = scenes.make_camera(640, 360)                      # 23 tile rows
+    sc = scenes.make_scene(60000, cam, seed=14)
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam)
+    full = hip_forward(sc, cam, 3, kw)
+    gfull = hip_backward_raw(full, sc, cam, 3, kw, grads)
+    assert parallel.tile_row_band(360, 0, 2) == (0, 12) and parallel.tile_row_band(360, 1, 2) == (12, 23)
+    acc = None
+    covered = torch.zeros(360, dtype=torch.bool)
+    for rank in range(2):
+        lo, hi = parallel.tile_row_band(cam.height, rank, 2)
+        with parallel.tile_band(lo, hi) as band:
+            part = hip_forward(sc, cam, 3, kw)
+            gpart = hip_backward_raw(part, sc, cam, 3, kw, grads)
+        rows = band.band_rows(cam.height)
+        covered[rows] = True
+        assert part["num_rendered"] == full["num_rendered"] and torch.equal(part["radii"], full["radii"])
+        assert part["num_binned"] < full["num_binned"]
+        for k in ("color", "depth", "median", "opacity"):
+            assert torch.equal(part[k][:, rows], full[k][:, rows]), k
+        outside = torch.ones(360, dtype=torch.bool)
+        outside[rows] = False
+        assert float(part["color"][:, outside].abs().sum()) == 0.0 and float(part["opacity"][:, outside].abs().sum()) == 0.0
+        assert bool((part["median"][0][outside] == 15.0).all())
+        acc = {k: v.clone() for k, v in gpart.items()} if acc is None else {k: acc[k] + gpart[k] for k in acc}
+    assert bool(covered.all())
+    for k, v in gfull.items():
+        scale = float(v.abs().max())
+        assert float((acc[k] - v).abs().max()) <= 1e-5 * scale, k       # two partial sums instead of one: fp32 re-association only
