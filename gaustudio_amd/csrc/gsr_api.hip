@@ -132,6 +132,7 @@ int env_int(const char* name, int dflt)
 }
 std::atomic<int> g_opt_tight{env_int("GSR_TIGHT_BINNING", 1)};     // bin into gs_tight_rect (0: the reference's squares)
 std::atomic<int> g_opt_cull{env_int("GSR_CULL", 1)};               // composite_fwd wave culling + pcut pre-test
+std::atomic<int> g_opt_fwd_variant{env_int("GSR_FWD_VARIANT", 0)}; // 0: per-quarter (4x4) instance lists, 1: per-wave (8x8)
 std::atomic<int> g_opt_bwd_variant{env_int("GSR_BWD_VARIANT", -1)};   // -1: from gsr_selftest; bit 0: select on T
 std::atomic<int> g_opt_speculative{env_int("GSR_SPECULATIVE", 1)}; // launch binning + compositing before R is known
 std::atomic<int> g_opt_band_lo{0}, g_opt_band_hi{0};               // tile rows [lo, hi) this process renders (hi <= 0: all)
@@ -413,6 +414,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 
 	DevState& ds = dev_state();
 	const bool nocull = g_opt_cull.load() == 0;
+	const bool wave_lists = g_opt_fwd_variant.load() == 1;
 	auto launch_rest = [&](uint32_t cap, bool with_long) -> int {
 		const BinLayout bl((size_t)cap, with_long);
 		char* bin = binning_alloc(binning_ctx, bl.total);
@@ -434,7 +436,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 		}
 		tm.mark();
 		launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
-		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap, with_long ? 0xffffffffu : GSR_SORT_LDS_MAX, nocull, s);
+		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap, with_long ? 0xffffffffu : GSR_SORT_LDS_MAX, nocull, wave_lists, s);
 		STAGE_CHECK("composite_fwd", debug, s);
 		tm.mark();
 		return 0;
@@ -656,6 +658,7 @@ int gsr_set_option(const char* name, int value)
 	const std::string n(name);
 	if (n == "tight_binning") g_opt_tight.store(value);
 	else if (n == "cull") g_opt_cull.store(value);
+	else if (n == "fwd_variant") g_opt_fwd_variant.store(value);
 	else if (n == "bwd_variant") g_opt_bwd_variant.store(value);
 	else if (n == "speculative") g_opt_speculative.store(value);
 	else if (n == "tile_row_lo") g_opt_band_lo.store(value > 0 ? value : 0);
@@ -674,6 +677,7 @@ int gsr_get_option(const char* name)
 	const std::string n(name);
 	if (n == "tight_binning") return g_opt_tight.load();
 	if (n == "cull") return g_opt_cull.load();
+	if (n == "fwd_variant") return g_opt_fwd_variant.load();
 	if (n == "bwd_variant") return g_opt_bwd_variant.load();
 	if (n == "speculative") return g_opt_speculative.load();
 	if (n == "tile_row_lo") return g_opt_band_lo.load();

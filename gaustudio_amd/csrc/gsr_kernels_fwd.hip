@@ -1135,18 +1135,248 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 	med_pos_out[(size_t)tile * GSR_TILE_PIX + tid] = med_final;
 }
 
+// ------------------------------------------------------------------------------------------------
+// composite_fwd with per-quarter instance lists.  In the kernel above a wave (one 8x8 pixel block) walks every staged
+// instance that may touch its block, and within such a block only about half of the lanes are live.  Here every
+// 16-lane quarter of the wave owns a 4x4 pixel block and walks ITS OWN list of instances: the staging thread, which
+// holds the record in registers anyway, tests it against the tile's sixteen 4x4 blocks at once (gs_quarter_mask), each
+// wave compacts the four lists of its quarters (ballot + mbcnt) and the walk then takes list entry i of every quarter
+// in the same instruction -- records come from LDS with per-quarter addresses, which a b128 read serves in its four
+// 16-lane passes at no extra cost.  A wave walks max over its quarters instead of the 8x8 count: 0.725x the iterations
+// at C3 (census: tools/scene_stats.py), quarters re-synchronise once per 256-instance batch.  Exhausted quarters read a
+// sentinel record of opacity 0.  Per pixel the sequence of applied instances is unchanged: results are bit-identical.
+#define GSR_FWD_PLANE 257                      // records per staged plane (256 + the sentinel)
+#define GSR_FWD_SENT_OFF (256 * 16)            // byte offset of the sentinel record inside a plane
+#define GSR_FWD_LIST 264                       // list entries per quarter (u16 byte offsets): 256 + two groups of sentinels
+#define GSR_FWD_NONE 0xffffu
+
+// Which of the tile's sixteen 4x4 pixel blocks (bit 4*row + col) can hold a pixel with 0 >= power >= pcut?  Conservative
+// like gs_box_may_touch, organised by rows of blocks: for the band of dy a block row spans, the dx-extent
+// [lo, hi] of the region {power >= pc} is found in closed form (the roots of the quadratic in dx at the band's two
+// ends, plus the region's extreme points in x when they lie in the band -- the extent is a concave/convex function of
+// dy, so those three candidates contain its extremum); a block is hit iff its dx range meets [lo, hi].  pc = pcut minus
+// a slack of 0.05 + 1e-5 * (largest |term| over the tile), the ranges are widened by 0.01 px.
+__device__ __forceinline__ uint32_t gs_quarter_mask(const float4 A, const float4 B, float tx0, float ty0, uint32_t allq)
+{
+	const float ha = A.z, nb = A.w, hc = B.x, pcut = B.w;
+	if (!(pcut <= 0.f)) return 0u;               // opacity < 1/255
+	const float hh = 4.f * ha * hc;
+	const float D = hh - nb * nb;
+	if (!(ha < 0.f && hc < 0.f && D > 1e-4f * hh)) return allq;   // not (safely) negative definite: keep everywhere
+	// d = centre - pixel relative to the tile's first pixel; block column i spans dx in [rx - (4i + 3), rx - 4i]
+	// (blocks cut by the image border are tested whole: conservative, and the constants stay literals)
+	const float rx = A.x - tx0, ry = A.y - ty0;
+	const float Dx = fmaxf(fabsf(rx), fabsf(rx - 15.f)), Dy = fmaxf(fabsf(ry), fabsf(ry - 15.f));
+	const float mag = fabsf(ha) * Dx * Dx + fabsf(hc) * Dy * Dy + fabsf(nb) * Dx * Dy;
+	const float pc = pcut - (0.05f + 1e-5f * mag);
+	const float rD = __builtin_amdgcn_rcpf(D);
+	const float c4 = 4.f * ha * pc;                                        // > 0
+	const float ex = __builtin_amdgcn_sqrtf(4.f * pc * hc * rD);           // half extent in dx of {power >= pc}
+	const float dys = -0.5f * nb * ex * __builtin_amdgcn_rcpf(hc);         // dy where dx = +ex is reached
+	const float r = -0.5f * __builtin_amdgcn_rcpf(ha);                     // 1 / (2|ha|)
+	const float BIG = 3.0e38f;
+	uint32_t mask = 0;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const float Y0 = ry - (4.f * j + 3.f), Y1 = ry - 4.f * j;           // dy over the block row
+		const float d0 = FMA(-D * Y0, Y0, c4), d1 = FMA(-D * Y1, Y1, c4);   // discriminants / 1 at both ends
+		const float s0 = __builtin_amdgcn_sqrtf(fmaxf(d0, 0.f)), s1 = __builtin_amdgcn_sqrtf(fmaxf(d1, 0.f));
+		const float u0 = nb * Y0, u1 = nb * Y1;
+		const float h0 = d0 >= 0.f ? (u0 + s0) * r : -BIG, l0 = d0 >= 0.f ? (u0 - s0) * r : BIG;
+		const float h1 = d1 >= 0.f ? (u1 + s1) * r : -BIG, l1 = d1 >= 0.f ? (u1 - s1) * r : BIG;
+		const float hs = (Y0 <= dys && dys <= Y1) ? ex : -BIG;
+		const float ls = (Y0 <= -dys && -dys <= Y1) ? -ex : BIG;
+		const float hi = fmaxf(fmaxf(h0, h1), hs) - rx;   // compared against -(4i + 3) - 0.01 <= hi - rx, ...
+		const float lo = fminf(fminf(l0, l1), ls) - rx;
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			mask |= (-(4.f * i + 3.01f) <= hi && -(4.f * i - 0.01f) >= lo) ? (1u << (4 * j + i)) : 0u;
+	}
+	return mask & allq;
+}
+
+template <bool NOCULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void composite_fwd_quarter_kernel(
+    int T, int chunk, int gx, int W, int H, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
+    float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ med_pos_out,
+    const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted)
+{
+	__shared__ float4 sRec[3 * GSR_FWD_PLANE];   // planes A, B, C (as above), slot 256 of each = the sentinel
+	__shared__ uint16_t sMask[256];
+	__shared__ __attribute__((aligned(16))) uint16_t sList[4][4][GSR_FWD_LIST];
+	if (ctl->num_binned > cap || ctl->max_tile_count > max_sorted) return;   // see composite_fwd_kernel
+	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, w = tid >> 6, q = lane >> 4;
+	const int tx = tile % gx, ty = tile / gx;
+	// lane -> pixel: quarter q of wave w is the 4x4 block (2*(w&1) + (q&1), 2*(w>>1) + (q>>1)) of the tile
+	const int lx = ((w & 1) << 3) + ((q & 1) << 2) + (lane & 3);
+	const int ly = ((w >> 1) << 3) + ((q >> 1) << 2) + ((lane >> 2) & 3);
+	const int slot = (w << 6) + ((ly & 7) << 3) + (lx & 7);   // this pixel's place in the tile-major per-pixel arrays
+	const int px = tx * GSR_BLOCK_X + lx, py = ty * GSR_BLOCK_Y + ly;
+	const bool inside = px < W && py < H;
+	const float pixfx = (float)px, pixfy = (float)py;
+	const float tx0 = (float)(tx * GSR_BLOCK_X), ty0 = (float)(ty * GSR_BLOCK_Y);
+	uint32_t allq = 0;   // 4x4 blocks of this tile that hold at least one pixel of the image
+#pragma unroll
+	for (int b = 0; b < 16; b++)
+		if (tx * GSR_BLOCK_X + 4 * (b & 3) < W && ty * GSR_BLOCK_Y + 4 * (b >> 2) < H) allq |= 1u << b;
+	const uint2 range = ranges[tile];
+	const int total = (int)(range.y - range.x);
+	bool done = !inside;
+	float T_ = 1.0f;
+	uint32_t last_contributor = 0;
+	v2f acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+	uint32_t med_pos = 0;
+	float med_T = 0.f;
+	if (tid < 3) sRec[tid * GSR_FWD_PLANE + 256] = make_float4(0.f, 0.f, 0.f, 0.f);   // opacity 0: alpha = 0, never valid
+	const char* rec_base = reinterpret_cast<const char*>(sRec);
+	const uint16_t* my_list = &sList[w][q][0];
+
+	for (int base = 0; base < total; base += 256) {
+		if (__syncthreads_and(done)) break;
+		const int cnt = min(256, total - base);
+		uint32_t mk = 0;
+		if (tid < cnt) {
+			const uint32_t id = point_list[range.x + base + tid];
+			const GsRec* rr = recs + id;
+			const float4 a = rr->q0;
+			float4 b = rr->q1;
+			float4 c = rr->q2;
+			mk = NOCULL ? allq : gs_quarter_mask(a, b, tx0, ty0, allq);
+			c.w = b.z;
+			b.z = __int_as_float((int)id);
+			sRec[tid] = a;
+			sRec[GSR_FWD_PLANE + tid] = b;
+			sRec[2 * GSR_FWD_PLANE + tid] = c;
+		}
+		sMask[tid] = (uint16_t)mk;
+		// this wave's four lists: all sentinels, then the hits of each quarter in list order
+		{
+			uint4* l4 = reinterpret_cast<uint4*>(&sList[w][0][0]);
+			const uint32_t ss = GSR_FWD_SENT_OFF | (GSR_FWD_SENT_OFF << 16);
+			for (int k = lane; k < 4 * GSR_FWD_LIST / 8; k += 64) l4[k] = make_uint4(ss, ss, ss, ss);
+		}
+		__syncthreads();
+		int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+		const int wbit = 8 * (w >> 1) + 2 * (w & 1);   // bit of this wave's quarter 0; quarters 1, 2, 3 are bits +1, +4, +5
+		for (int sub = 0; sub < cnt; sub += 64) {
+			const uint32_t m16 = (uint32_t)sMask[sub + lane] >> wbit;
+			const uint32_t off = (uint32_t)(sub + lane) << 4;
+#define GSR_APPEND(QQ, SH, CNT)                                                                          \
+	{                                                                                                    \
+		const bool h = (m16 >> (SH)) & 1u;                                                               \
+		const unsigned long long bm = __ballot(h);                                                       \
+		const int pos = CNT + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)); \
+		if (h) sList[w][QQ][pos] = (uint16_t)off;                                                        \
+		CNT += __popcll(bm);                                                                             \
+	}
+			GSR_APPEND(0, 0, c0)
+			GSR_APPEND(1, 1, c1)
+			GSR_APPEND(2, 4, c2)
+			GSR_APPEND(3, 5, c3)
+#undef GSR_APPEND
+		}
+		__builtin_amdgcn_wave_barrier();
+		const int n = max(max(c0, c1), max(c2, c3));
+		uint32_t last_off = GSR_FWD_NONE, med_off = GSR_FWD_NONE;
+		// four list entries per step, fetched one step ahead of their use.  The read is inline assembly: the compiler
+		// sinks an ordinary prefetch load down to its use (exposing a full LDS latency per step); the wait in front of the
+		// use is ours too (LDS returns in order, so the compiler's own counted waits stay sufficient).
+		uint2 pk;
+		{
+			const uint32_t la = (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)my_list;
+			asm volatile("ds_read_b64 %0, %1" : "=v"(pk) : "v"(la));
+		}
+		for (int i = 0; i < n; i += 4) {
+			if ((i & 31) == 0 && __ballot(!done) == 0ull) break;   // every pixel of this wave has saturated
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pk));
+			const uint32_t offs[4] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
+			{
+				const uint32_t la = (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)(my_list + i + 4);
+				asm volatile("ds_read_b64 %0, %1" : "=v"(pk) : "v"(la));
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t off = offs[k];
+				const float4 A = *reinterpret_cast<const float4*>(rec_base + off);
+				const float4 B = *reinterpret_cast<const float4*>(rec_base + off + GSR_FWD_PLANE * 16);
+				const float4 Cc = *reinterpret_cast<const float4*>(rec_base + off + 2 * GSR_FWD_PLANE * 16);
+				const float dx = A.x - pixfx, dy = A.y - pixfy;
+				const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
+				const float alpha = fminf(0.99f, B.y * gs_exp(power));
+				const bool valid = (!done) & (power <= 0.0f) & (power >= (NOCULL ? -80.0f : B.w)) & (!(alpha < 1.0f / 255.0f));
+				const float test_T = T_ * (1 - alpha);
+				const bool stop = valid & (test_T < 0.0001f);
+				done = done | stop;
+				const bool apply = valid & (!stop);
+				const float wgt = apply ? alpha * T_ : 0.f;
+				acc01 = vfma(v2f{Cc.x, Cc.y}, v2f{wgt, wgt}, acc01);
+				acc23 = vfma(v2f{Cc.z, Cc.w}, v2f{wgt, wgt}, acc23);
+				const bool medc = apply & (T_ > 0.5f);
+				med_off = medc ? off : med_off;
+				med_T = medc ? T_ : med_T;
+				T_ = apply ? test_T : T_;
+				last_off = apply ? off : last_off;
+			}
+		}
+		if (last_off != GSR_FWD_NONE) last_contributor = (uint32_t)base + (last_off >> 4) + 1u;
+		if (med_off != GSR_FWD_NONE) med_pos = (uint32_t)base + (med_off >> 4) + 1u;
+	}
+	final_T[(size_t)tile * GSR_TILE_PIX + slot] = T_;
+	n_contrib[(size_t)tile * GSR_TILE_PIX + slot] = last_contributor;
+	uint32_t med_final = 0;
+	if (inside) {
+		float median_D = 15.0f, median_weight = 0.f;
+		int median_id = 0;
+		if (med_pos != 0) {
+			const uint32_t id = point_list[range.x + med_pos - 1];
+			const GsRec* rr = recs + id;
+			const float4 A = rr->q0, B = rr->q1;
+			const float dx = A.x - pixfx, dy = A.y - pixfy;
+			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
+			const float alpha = fminf(0.99f, B.y * gs_exp(power));
+			if (med_T * (1 - alpha) < 0.5f) {
+				median_D = B.z;
+				median_weight = alpha * med_T;
+				median_id = (int)id;
+				med_final = med_pos;
+			}
+		}
+		const size_t HW = (size_t)H * W;
+		const size_t pix_id = (size_t)W * py + px;
+		out_color[pix_id] = acc01.x;
+		out_color[HW + pix_id] = acc01.y;
+		out_color[2 * HW + pix_id] = acc23.x;
+		out_depth[pix_id] = acc23.y;
+		out_median[pix_id] = median_D;
+		out_median[HW + pix_id] = median_weight;
+		out_median[2 * HW + pix_id] = (float)median_id;
+		out_opacity[pix_id] = 1 - T_;
+	}
+	med_pos_out[(size_t)tile * GSR_TILE_PIX + slot] = med_final;
+}
+
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
                           float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, const GsCtl* ctl,
-                          uint32_t cap, uint32_t max_sorted, bool nocull, hipStream_t s)
+                          uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
-	if (nocull)
-		hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges,
-		                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted);
-	else
-		hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges,
-		                   point_list, recs, out_color, out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted);
+#define GSR_LAUNCH_FWD(K)                                                                                              \
+	hipLaunchKernelGGL(K, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges, point_list, recs, out_color, \
+	                   out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted)
+	if (wave_lists) {
+		if (nocull) GSR_LAUNCH_FWD(composite_fwd_kernel<true>);
+		else GSR_LAUNCH_FWD(composite_fwd_kernel<false>);
+	} else {
+		if (nocull) GSR_LAUNCH_FWD(composite_fwd_quarter_kernel<true>);
+		else GSR_LAUNCH_FWD(composite_fwd_quarter_kernel<false>);
+	}
+#undef GSR_LAUNCH_FWD
 }
 
 }  // namespace gsr

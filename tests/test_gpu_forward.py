@@ -237,6 +237,25 @@ def test_culling_and_tight_binning_change_no_bit(P, W, H, D):
         assert torch.equal(a[k], b[k]), k          # same binning, only the cull differs
 
 
+@pytest.mark.parametrize("P,W,H,D,sig", [(20000, 400, 400, 3, None), (30000, 333, 217, 1, 6.0), (3000, 131, 77, 0, 25.0),
+                                         (1_000_000, 1920, 1080, 3, None)], ids=["small", "odd", "wide", "C3"])
+def test_forward_variants_agree_bit_for_bit(P, W, H, D, sig):
+    """composite_fwd with per-quarter (4x4) instance lists (default) against the per-wave (8x8) walk and against the
+    walk without any culling: every output and the per-pixel state are bit-identical (image sizes that are not
+    multiples of 16 or 4 included: clipped quarters)."""
+    cam = scenes.make_camera(W, H)
+    sc = scenes.make_scene(P, cam, seed=1, **({} if sig is None else {"sigma_px_median": sig}))
+    kw = scene_kwargs(sc, True, False)
+    a = hip_forward(sc, cam, D, kw)
+    with _with_options(fwd_variant=1):
+        b = hip_forward(sc, cam, D, kw)
+    with _with_options(cull=0):
+        c = hip_forward(sc, cam, D, kw)
+    for other in (b, c):
+        for k in ("color", "depth", "median", "opacity", "radii", "final_T", "n_contrib", "point_list", "ranges"):
+            assert torch.equal(a[k], other[k]), k
+
+
 def test_speculative_launch_overflow_is_retried():
     """The kernels behind the instance count are enqueued against the remembered binning capacity before the host
     has read the count; when the capacity is too small (forced here) they leave without touching memory and the host

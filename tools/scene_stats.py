@@ -74,3 +74,40 @@ for t in tiles.tolist():
         hit816 += int(box_test(xy[ids], co[ids], bx0, by0, min(bx0 + 7, W - 1), min(by0 + 15, H - 1)).sum())
     tot += ids.numel()
 print(f"kernel box test pass rate: 8x8 {hit88 / (4 * tot):.3f} (exact any-live {tot_blockhit / (4 * tot_inst):.3f}); 8x16 {hit816 / (2 * tot):.3f}")
+
+# ---- what would per-quarter (4x4) instance lists inside a wave buy composite_fwd?  walk length of a wave =
+# instances passing its 8x8 box test (now) vs max over its four 4x4 quarters of their own pass counts, the quarters
+# re-synchronising every `batch` list entries (the staged batch).  Depth: the block's deepest n_contrib. ----
+ncp = ncpad.view(-1, 16, gx, 16).permute(0, 2, 1, 3).reshape(-1, 16, 16)   # [tile][y][x]
+it8 = 0; it4 = {64: 0, 256: 0, 1 << 30: 0}; it4_mean = 0; it2 = {256: 0}
+for t in tiles.tolist():
+    a, b = int(r[t, 0]), int(r[t, 1])
+    if b <= a: continue
+    ids = pl[a:b]; tx, ty = t % gx, t // gx
+    for blk in range(4):
+        bx0 = tx * 16 + (blk & 1) * 8; by0 = ty * 16 + (blk >> 1) * 8
+        depth = int(ncp[t, (blk >> 1) * 8:(blk >> 1) * 8 + 8, (blk & 1) * 8:(blk & 1) * 8 + 8].max())
+        depth = min(len(ids), (depth + 63) // 64 * 64)    # saturation is checked per 64-entry sub-batch
+        if depth == 0: continue
+        sel = ids[:depth]
+        h8 = box_test(xy[sel], co[sel], bx0, by0, min(bx0 + 7, W - 1), min(by0 + 7, H - 1))
+        it8 += int(h8.sum())
+        hq = []
+        for q in range(4):
+            qx0 = bx0 + (q & 1) * 4; qy0 = by0 + (q >> 1) * 4
+            if qx0 > W - 1 or qy0 > H - 1: hq.append(torch.zeros_like(h8)); continue
+            hq.append(box_test(xy[sel], co[sel], qx0, qy0, min(qx0 + 3, W - 1), min(qy0 + 3, H - 1)) & h8)
+        hq = torch.stack(hq).long()                          # [4][depth]
+        it4_mean += float(hq.sum()) / 4
+        for bs in it4:
+            if bs >= depth: it4[bs] += int(hq.sum(1).max())
+            else:
+                pad = (-depth) % bs
+                hp = torch.nn.functional.pad(hq, (0, pad)).view(4, -1, bs).sum(2)
+                it4[bs] += int(hp.max(0).values.sum())
+        hh = torch.stack([hq[0] | hq[1], hq[2] | hq[3]])     # two 8x4 halves
+        pad = (-depth) % 256
+        it2[256] += int(torch.nn.functional.pad(hh, (0, pad)).view(2, -1, 256).sum(2).max(0).values.sum())
+print(f"wave walk length, 8x8 lists: {it8}; 4x4 quarter lists: mean-of-quarters {it4_mean:.0f} ({it4_mean / it8:.3f}), "
+      + ", ".join(f"resync/{k if k < 1 << 30 else 'never'} {v} ({v / it8:.3f})" for k, v in it4.items())
+      + f"; 8x4 halves resync/256 {it2[256]} ({it2[256] / it8:.3f})")
