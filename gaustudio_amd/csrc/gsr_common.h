@@ -331,6 +331,53 @@ __device__ __forceinline__ bool gs_box_may_touch(const float4 A, const float4 B,
 	return best >= pcut - (0.05f + 1e-5f * mag);
 }
 
+// Which of the NB x NB 4x4-pixel blocks (bit NB*row + col) of the square of pixels starting at (tx0, ty0) can hold a
+// pixel with 0 >= power >= pcut?  (NB = 4: the 16x16 tile, composite_fwd; NB = 2: a wave's 8x8 block, composite_bwd.)  Conservative
+// like gs_box_may_touch, organised by rows of blocks: for the band of dy a block row spans, the dx-extent
+// [lo, hi] of the region {power >= pc} is found in closed form (the roots of the quadratic in dx at the band's two
+// ends, plus the region's extreme points in x when they lie in the band -- the extent is a concave/convex function of
+// dy, so those three candidates contain its extremum); a block is hit iff its dx range meets [lo, hi].  pc = pcut minus
+// a slack of 0.05 + 1e-5 * (largest |term| over the tile), the ranges are widened by 0.01 px.
+template <int NB>
+__device__ __forceinline__ uint32_t gs_quarter_mask(const float4 A, const float4 B, float tx0, float ty0, uint32_t allq)
+{
+	const float ha = A.z, nb = A.w, hc = B.x, pcut = B.w;
+	if (!(pcut <= 0.f)) return 0u;               // opacity < 1/255
+	const float hh = 4.f * ha * hc;
+	const float D = hh - nb * nb;
+	if (!(ha < 0.f && hc < 0.f && D > 1e-4f * hh)) return allq;   // not (safely) negative definite: keep everywhere
+	// d = centre - pixel relative to the tile's first pixel; block column i spans dx in [rx - (4i + 3), rx - 4i]
+	// (blocks cut by the image border are tested whole: conservative, and the constants stay literals)
+	const float rx = A.x - tx0, ry = A.y - ty0;
+	const float Dx = fmaxf(fabsf(rx), fabsf(rx - (4.f * NB - 1.f))), Dy = fmaxf(fabsf(ry), fabsf(ry - (4.f * NB - 1.f)));
+	const float mag = fabsf(ha) * Dx * Dx + fabsf(hc) * Dy * Dy + fabsf(nb) * Dx * Dy;
+	const float pc = pcut - (0.05f + 1e-5f * mag);
+	const float rD = __builtin_amdgcn_rcpf(D);
+	const float c4 = 4.f * ha * pc;                                        // > 0
+	const float ex = __builtin_amdgcn_sqrtf(4.f * pc * hc * rD);           // half extent in dx of {power >= pc}
+	const float dys = -0.5f * nb * ex * __builtin_amdgcn_rcpf(hc);         // dy where dx = +ex is reached
+	const float r = -0.5f * __builtin_amdgcn_rcpf(ha);                     // 1 / (2|ha|)
+	const float BIG = 3.0e38f;
+	uint32_t mask = 0;
+#pragma unroll
+	for (int j = 0; j < NB; j++) {
+		const float Y0 = ry - (4.f * j + 3.f), Y1 = ry - 4.f * j;           // dy over the block row
+		const float d0 = FMA(-D * Y0, Y0, c4), d1 = FMA(-D * Y1, Y1, c4);   // discriminants / 1 at both ends
+		const float s0 = __builtin_amdgcn_sqrtf(fmaxf(d0, 0.f)), s1 = __builtin_amdgcn_sqrtf(fmaxf(d1, 0.f));
+		const float u0 = nb * Y0, u1 = nb * Y1;
+		const float h0 = d0 >= 0.f ? (u0 + s0) * r : -BIG, l0 = d0 >= 0.f ? (u0 - s0) * r : BIG;
+		const float h1 = d1 >= 0.f ? (u1 + s1) * r : -BIG, l1 = d1 >= 0.f ? (u1 - s1) * r : BIG;
+		const float hs = (Y0 <= dys && dys <= Y1) ? ex : -BIG;
+		const float ls = (Y0 <= -dys && -dys <= Y1) ? -ex : BIG;
+		const float hi = fmaxf(fmaxf(h0, h1), hs) - rx;   // compared against -(4i + 3) - 0.01 <= hi - rx, ...
+		const float lo = fminf(fminf(l0, l1), ls) - rx;
+#pragma unroll
+		for (int i = 0; i < NB; i++)
+			mask |= (-(4.f * i + 3.01f) <= hi && -(4.f * i - 0.01f) >= lo) ? (1u << (NB * j + i)) : 0u;
+	}
+	return mask & allq;
+}
+
 // ---- wave-cooperative row staging (SH rows: 192 B per Gaussian at degree 3) -------------------------------
 // A lane that reads "its" row with per-lane dwordx4 loads makes every load instruction touch 64 different rows
 // (16 B out of each); staged through LDS instead, the wave copies its 64 consecutive rows as ONE contiguous

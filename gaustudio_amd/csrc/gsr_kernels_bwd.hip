@@ -424,6 +424,333 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// composite_bwd with per-quarter instance lists (the default; the kernel above is kept as variant bit 1 for A/B).
+// Same transposition idea, finer granularity -- the forward's (composite_fwd_quarter_kernel): every 16-lane quarter
+// of a wave owns a 4x4 pixel block and walks its OWN list of the staged instances, compacted from a per-instance
+// 4-bit mask (gs_quarter_mask<2> against the wave's four blocks, cut by each quarter's own last_contributor bound).
+//   phase 1 (lane = pixel): list step i of all four quarters in one instruction stream; (q, w) go to the slab row of
+//           (quarter, step);
+//   phase 2 (every GSR_BWQ_U steps; lane = (quarter, step u, pixel row r)): the lane accumulates the 4 pixels of its
+//           row -- their upstream gradients live in REGISTERS (20 VGPRs; with 8 pixels per lane they had to be
+//           re-read from an LDS table for every pair: 80 % of phase 2's LDS traffic), folds the 4 rows with two DPP
+//           butterflies and adds the ten sums to the instance's slot in the wave's plane with LDS float atomics
+//           (quarters of a wave may meet in an instance; LDS executes a wave's instructions in order and resolves
+//           equal addresses inside one instruction in lane order, so the sums stay reproducible; across waves there
+//           are four planes, added by the flush in fixed order as before).
+// A wave walks max over its quarters (C3: 0.73x the steps of the 8x8 walk), and phase 2 touches only hit quarters.
+// The median-depth gradient is added by phase 1 at the one step whose list position the forward recorded.
+#define GSR_BWQ_U 4          // list steps per transposed reduction
+#define GSR_BWQ_LIST 72      // bytes per quarter list: 64 entries + 8 sentinels
+#define GSR_BWQ_SENT 64      // batch index of the sentinel record (opacity 0)
+#define GSR_BWQ_QSTRIDE 66   // float2 per quarter in the slab: 4 steps x 16 pixels + 2 pad (16-B aligned, banks shifted)
+
+template <bool FLAGS, bool TSEL>
+__global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_quarter_kernel(
+    int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ med_pos,
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
+    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags)
+{
+	__shared__ float4 sA[GSR_BWD_BATCH + 1];   // q0: px, py, -a/2, -b        (slot 64: the sentinel)
+	__shared__ float4 sB[GSR_BWD_BATCH + 1];   // q1: -c/2, opacity, depth, pcut
+	__shared__ float4 sC[GSR_BWD_BATCH + 1];   // q2: r, g, b, -
+	__shared__ uint32_t s_row[GSR_BWD_BATCH];
+	__shared__ __attribute__((aligned(16))) float s_plane[4][GSR_BWD_BATCH * GSR_PLANE_STRIDE];
+	__shared__ __attribute__((aligned(16))) float2 s_slab[4][4 * GSR_BWQ_QSTRIDE];
+	__shared__ __attribute__((aligned(16))) uint8_t s_list[4][4][GSR_BWQ_LIST];
+	__shared__ int s_max[4];
+	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wv = tid >> 6, qd = lane >> 4;
+	const int tx = tile % gx, ty = tile / gx;
+	// lane -> pixel as in composite_fwd_quarter_kernel: quarter qd of wave wv is one 4x4 block
+	const int lx = ((wv & 1) << 3) + ((qd & 1) << 2) + (lane & 3);
+	const int ly = ((wv >> 1) << 3) + ((qd >> 1) << 2) + ((lane >> 2) & 3);
+	const int px = tx * GSR_BLOCK_X + lx, py = ty * GSR_BLOCK_Y + ly;
+	const bool inside = px < W && py < H;
+	const float pixfx = (float)px, pixfy = (float)py;
+	const float fbx = (float)(tx * GSR_BLOCK_X + ((wv & 1) << 3)), fby = (float)(ty * GSR_BLOCK_Y + ((wv >> 1) << 3));
+	const uint2 range = ranges[tile];
+
+	const size_t sidx = (size_t)tile * GSR_TILE_PIX + (wv << 6) + ((ly & 7) << 3) + (lx & 7);   // tile-major pixel state
+	const float T_final = inside ? final_T[sidx] : 0.f;
+	const int lc = inside ? (int)n_contrib[sidx] : 0;          // last_contributor
+	float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLo = 0.f, dLm = 0.f;
+	uint32_t mpos = 0u;
+	if (inside) {
+		const size_t HW = (size_t)H * W;
+		const size_t pix_id = (size_t)W * py + px;
+		dLp0 = dL_dpix[pix_id];
+		dLp1 = dL_dpix[HW + pix_id];
+		dLp2 = dL_dpix[2 * HW + pix_id];
+		dLd = dL_dpix_depth[pix_id];
+		dLm = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
+		dLo = dL_dpix_opacity[pix_id];
+		mpos = med_pos[sidx];
+	}
+	float2* slab = s_slab[wv];
+	float* plane = s_plane[wv];
+	// phase-2 role of this lane: step u2 of its own quarter, pixel row r2 of the 4x4 block; the upstream gradients of
+	// that row's four pixels move into registers once, through the (still unused) slab
+	const int u2 = (lane >> 2) & 3, r2 = lane & 3;
+	float4 g_pix[4];   // dL_dpixel rgb, dL_ddepth of pixel (sx, r2)
+	float g_op[4];     // dL_dopacity
+	{
+		float4* tmp = reinterpret_cast<float4*>(slab);   // 64 pixels x 2 float4 = 2 KiB <= the wave's slab
+		tmp[2 * lane] = make_float4(dLp0, dLp1, dLp2, dLd);
+		tmp[2 * lane + 1] = make_float4(dLo, 0.f, 0.f, 0.f);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int sx = 0; sx < 4; sx++) {
+			const int pl = (qd << 4) + (r2 << 2) + sx;   // lane that owns pixel (sx, r2) of this quarter
+			g_pix[sx] = tmp[2 * pl];
+			g_op[sx] = tmp[2 * pl + 1].x;
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	const float y2 = fby + (float)(((qd >> 1) << 2) + r2), x2 = fbx + (float)((qd & 1) << 2);   // first pixel of that row
+	// bg . dL_dpixel (backward.cu:584-586), loop invariant
+	const float bg_dot = FMA(bg[2], dLp2, FMA(bg[1], dLp1, FMA(bg[0], dLp0, 0.f)));
+	const bool any_bg = __ballot(bg_dot != 0.f) != 0ull;
+	float T_ = T_final;
+	float S = 0.f;   // <accum_rec, dL_dpixel>, see composite_bwd_kernel
+
+	// quarter / block / tile maxima of last_contributor: list entries at or beyond them are dead there
+	int qmax = lc;
+	qmax = max(qmax, __shfl_xor(qmax, 1, 64));
+	qmax = max(qmax, __shfl_xor(qmax, 2, 64));
+	qmax = max(qmax, __shfl_xor(qmax, 4, 64));
+	qmax = max(qmax, __shfl_xor(qmax, 8, 64));
+	const int qm0 = __builtin_amdgcn_readlane(qmax, 0), qm1 = __builtin_amdgcn_readlane(qmax, 16);
+	const int qm2 = __builtin_amdgcn_readlane(qmax, 32), qm3 = __builtin_amdgcn_readlane(qmax, 48);
+	const int wmax = max(max(qm0, qm1), max(qm2, qm3));
+	if (lane == 0) s_max[wv] = wmax;
+	if (tid < 3) (tid == 0 ? sA : tid == 1 ? sB : sC)[GSR_BWQ_SENT] = make_float4(0.f, 0.f, 0.f, 0.f);
+	__syncthreads();
+	const int bmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+	// rows of list entries no pixel of the tile reaches (short-list regime; see composite_bwd_kernel)
+	for (int i = bmax + tid; !FLAGS && i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
+		const uint32_t id = point_list[range.x + i];
+		const uint4 q3 = recs[id].q3;
+		const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
+		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx))) * GSR_ROW_STRIDE);
+		dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+	// ---- software-pipelined staging (as in composite_bwd_kernel) ----
+	const int srec = tid >> 2, spart = tid & 3;
+	auto load_id = [&](int t) -> uint32_t {
+		return (t > 0 && srec < min(GSR_BWD_BATCH, t)) ? point_list[range.x + (uint32_t)(t - 1 - srec)] : 0u;
+	};
+	auto load_part = [&](int t, uint32_t id) -> float4 {
+		float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (t > 0 && srec < min(GSR_BWD_BATCH, t)) {
+			v = reinterpret_cast<const float4*>(recs + id)[spart];
+			if (spart == 3) v.w = __uint_as_float(goff[id]);
+		}
+		return v;
+	};
+	uint32_t id_next = load_id(bmax - GSR_BWD_BATCH);
+	float4 part_cur = load_part(bmax, load_id(bmax));
+	const uint8_t* my_list = &s_list[wv][qd][0];
+	const char* recA = reinterpret_cast<const char*>(sA);
+	const char* recB = reinterpret_cast<const char*>(sB);
+	const char* recC = reinterpret_cast<const char*>(sC);
+	float2* my_slab_w = slab + qd * GSR_BWQ_QSTRIDE + (lane & 15);                      // + 16 * step
+	const float4* my_slab_r = reinterpret_cast<const float4*>(slab + qd * GSR_BWQ_QSTRIDE + u2 * 16 + r2 * 4);
+
+	for (int top = bmax; top > 0; top -= GSR_BWD_BATCH) {
+		const int cnt = min(GSR_BWD_BATCH, top);
+		__syncthreads();   // the previous flush has read sA / sB / the planes
+		if (srec < cnt) {
+			if (spart == 0) sA[srec] = part_cur;
+			else if (spart == 1) sB[srec] = part_cur;
+			else if (spart == 2) sC[srec] = part_cur;
+			else {
+				const uint32_t q3x = __float_as_uint(part_cur.x), q3y = __float_as_uint(part_cur.y), q3w = __float_as_uint(part_cur.w);
+				const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
+				s_row[srec] = q3w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
+			}
+		}
+		const float4 part_next = load_part(top - GSR_BWD_BATCH, id_next);
+		id_next = load_id(top - 2 * GSR_BWD_BATCH);
+		for (int i = tid; i < 4 * GSR_BWD_BATCH * GSR_PLANE_STRIDE / 4; i += GSR_BWD_THREADS)
+			reinterpret_cast<float4*>(&s_plane[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		// this wave's four lists: sentinels, then (below) the hits of each quarter in list order
+		if (lane < 4 * GSR_BWQ_LIST / 16) {
+			const uint32_t ss = GSR_BWQ_SENT * 0x01010101u;
+			reinterpret_cast<uint4*>(&s_list[wv][0][0])[lane] = make_uint4(ss, ss, ss, ss);
+		}
+		__syncthreads();
+		// median-depth gradient (backward.cu:566-569): to the Gaussian the forward recorded as this pixel's median
+		// (list position mpos, 1-based), when it is in this batch -- once per pixel per backward
+		if (mpos != 0u && dLm != 0.f && (uint32_t)top >= mpos && (uint32_t)top - mpos < (uint32_t)cnt)
+			atomicAdd(&plane[((uint32_t)top - mpos) * GSR_PLANE_STRIDE + 9], dLm);
+		// lane l: which of the wave's four 4x4 blocks can staged instance l touch, and is it still in front of the
+		// quarter's last contributor
+		uint32_t mk = 0;
+		if (lane < cnt) {
+			mk = gs_quarter_mask<2>(sA[lane], sB[lane], fbx, fby, 0xfu);
+			const int pos = top - 1 - lane;
+			mk &= (pos < qm0 ? 1u : 0u) | (pos < qm1 ? 2u : 0u) | (pos < qm2 ? 4u : 0u) | (pos < qm3 ? 8u : 0u);
+		}
+		int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#define GSR_APPEND(QQ, CNT)                                                                                          \
+	{                                                                                                                \
+		const bool h = (mk >> (QQ)) & 1u;                                                                            \
+		const unsigned long long bm = __ballot(h);                                                                   \
+		const int pos_ = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)); \
+		if (h) s_list[wv][QQ][pos_] = (uint8_t)lane;                                                                 \
+		CNT = __popcll(bm);                                                                                          \
+	}
+		GSR_APPEND(0, c0)
+		GSR_APPEND(1, c1)
+		GSR_APPEND(2, c2)
+		GSR_APPEND(3, c3)
+#undef GSR_APPEND
+		__builtin_amdgcn_wave_barrier();
+		const int n = max(max(c0, c1), max(c2, c3));
+		const int my_cnt = qd == 0 ? c0 : qd == 1 ? c1 : qd == 2 ? c2 : c3;
+		// one list step of every quarter: (q, w) of the lane's pixel for the quarter's entry, into slab row `st`
+		auto step = [&](const uint32_t j, const int st) {
+			const float4 A = *reinterpret_cast<const float4*>(recA + j * 16);
+			const float4 B = *reinterpret_cast<const float4*>(recB + j * 16);
+			const float4 Cc = *reinterpret_cast<const float4*>(recC + j * 16);
+			const int pos = top - 1 - (int)j;   // == `contributor` after decrement (backward.cu:520)
+			const float dx = A.x - pixfx, dy = A.y - pixfy;
+			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
+			const float G = gs_exp(power);
+			const float a0 = B.y * G;
+			const bool live = (pos < lc) & (power <= 0.0f) & (power >= B.w) & (!(a0 < 1.0f / 255.0f));
+			// a dead pixel (and the sentinel of an exhausted quarter) is carried through with G masked to 0: alpha = 0,
+			// 1/(1-alpha) = 1 (gsr_selftest), w = 0, q = 0, S <- fma(0, ., S)
+			const float Gm = live ? G : 0.f;
+			const float alpha = fminf(0.99f, B.y * Gm);
+			const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+			const float test_T = T_ * rinv;
+			const float w = alpha * test_T;
+			const float cd = FMA(Cc.x, dLp0, FMA(Cc.y, dLp1, FMA(Cc.z, dLp2, FMA(B.z, dLd, dLo))));
+			const float diff = cd - S;
+			float dL_dalpha = diff * test_T;
+			if (any_bg) {                                                         // backward.cu:584-587
+				asm volatile("");
+				dL_dalpha = FMA(-(T_final * rinv), bg_dot, dL_dalpha);
+			}
+			const float q = Gm * dL_dalpha;
+			S = FMA(alpha, diff, S);
+			T_ = TSEL ? (live ? test_T : T_) : test_T;
+			my_slab_w[16 * st] = make_float2(q, w);
+		};
+		// four list entries per read, fetched one group ahead of their use; the scheduling barrier keeps the read up
+		// here (left alone, the scheduler sinks it to its use and exposes a full LDS latency per group)
+		// The sums of a (quarter, instance) go into the instance's slot of the wave's plane; quarters may meet in an
+		// instance, so the four quarters take turns (LDS float atomics would serialise every lane: measured 2x the
+		// kernel time): the results of one phase 2 stay pending and are added by quarter k around step k of the NEXT
+		// group -- plain read / add / write, the read's latency hidden behind the step, program order between the turns.
+		float pn0 = 0.f, pn1 = 0.f, pn2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
+		float* pn_dst = plane;
+		bool pn_act = false;
+		const bool r2_hi = (r2 & 2) != 0;
+		auto turn_read = [&](const int qq) {
+			if (pn_act & (qd == qq)) {
+				t0 = pn_dst[0];
+				t1 = pn_dst[4];
+				if (!r2_hi) t2 = pn_dst[8];
+			}
+		};
+		auto turn_write = [&](const int qq) {
+			if (pn_act & (qd == qq)) {
+				pn_dst[0] = t0 + pn0;
+				pn_dst[4] = t1 + pn1;
+				if (!r2_hi) pn_dst[8] = t2 + pn2;
+			}
+		};
+		uint32_t pk = *reinterpret_cast<const uint32_t*>(my_list);
+		for (int i = 0; i < n; i += GSR_BWQ_U) {
+			const uint32_t cur = pk;
+			pk = *reinterpret_cast<const uint32_t*>(my_list + i + GSR_BWQ_U);
+			__builtin_amdgcn_sched_barrier(0);
+			turn_read(0); step(cur & 0xffu, 0); turn_write(0);
+			turn_read(1); step((cur >> 8) & 0xffu, 1); turn_write(1);
+			turn_read(2); step((cur >> 16) & 0xffu, 2); turn_write(2);
+			turn_read(3); step(cur >> 24, 3); turn_write(3);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			// ---- phase 2: lane = (quarter qd, step u2, pixel row r2) ----
+			{
+				const bool act = i + u2 < my_cnt;
+				const uint32_t j = act ? (cur >> (8 * u2)) & 0xffu : 0u;
+				const float2 ctr = *reinterpret_cast<const float2*>(recA + j * 16);
+				const float4 v01 = my_slab_r[0], v23 = my_slab_r[1];   // (q, w) of the row's four pixels
+				const float dy = ctr.y - y2, X = ctr.x - x2;
+				const float qv[4] = {v01.x, v01.z, v23.x, v23.z}, wv_[4] = {v01.y, v01.w, v23.y, v23.w};
+				float S0 = 0.f, a0 = 0.f, a2 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f, a9 = 0.f;
+#pragma unroll
+				for (int sx = 0; sx < 4; sx++) {
+					const float dx = X - (float)sx;
+					const float t = qv[sx] * dx;
+					S0 += qv[sx];
+					a0 += t;
+					a2 = FMA(t, dx, a2);
+					a5 = FMA(wv_[sx], g_op[sx], a5);                  // backward.cu:575 (+ :607 below: + sum q)
+					a6 = FMA(wv_[sx], g_pix[sx].x, a6);
+					a7 = FMA(wv_[sx], g_pix[sx].y, a7);
+					a8 = FMA(wv_[sx], g_pix[sx].z, a8);
+					a9 = FMA(wv_[sx], g_pix[sx].w, a9);
+				}
+				a5 += S0;
+				float a1 = dy * S0, a3 = dy * a0;
+				float a4 = dy * a1;
+				// fold the four rows (lanes r2 = 0..3 of the same quarter and step): quad butterflies
+				GSR_DPP_ADD(a0, 0xB1); GSR_DPP_ADD(a1, 0xB1); GSR_DPP_ADD(a2, 0xB1); GSR_DPP_ADD(a3, 0xB1); GSR_DPP_ADD(a4, 0xB1);
+				GSR_DPP_ADD(a5, 0xB1); GSR_DPP_ADD(a6, 0xB1); GSR_DPP_ADD(a7, 0xB1); GSR_DPP_ADD(a8, 0xB1); GSR_DPP_ADD(a9, 0xB1);
+				GSR_DPP_ADD(a0, 0x4E); GSR_DPP_ADD(a1, 0x4E); GSR_DPP_ADD(a2, 0x4E); GSR_DPP_ADD(a3, 0x4E); GSR_DPP_ADD(a4, 0x4E);
+				GSR_DPP_ADD(a5, 0x4E); GSR_DPP_ADD(a6, 0x4E); GSR_DPP_ADD(a7, 0x4E); GSR_DPP_ADD(a8, 0x4E); GSR_DPP_ADD(a9, 0x4E);
+				// lane r2 takes sums r2, 4 + r2 and (r2 < 2) 8 + r2 to the instance's slot of the wave's plane (pending)
+				const bool lo1 = (r2 & 1) != 0;
+				pn0 = r2_hi ? (lo1 ? a3 : a2) : (lo1 ? a1 : a0);
+				pn1 = r2_hi ? (lo1 ? a7 : a6) : (lo1 ? a5 : a4);
+				pn2 = lo1 ? a9 : a8;
+				pn_act = act;
+				pn_dst = plane + j * GSR_PLANE_STRIDE + r2;
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+#pragma unroll
+		for (int qq = 0; qq < 4; qq++) {   // the last group's sums
+			turn_read(qq);
+			turn_write(qq);
+		}
+		// flush: one thread per staged instance adds the four planes in fixed order and stores the 48-B row
+		__syncthreads();
+		if (tid < cnt) {
+			float v[10];
+#pragma unroll
+			for (int k = 0; k < 10; k++)
+				v[k] = ((s_plane[0][tid * GSR_PLANE_STRIDE + k] + s_plane[1][tid * GSR_PLANE_STRIDE + k]) +
+				        s_plane[2][tid * GSR_PLANE_STRIDE + k]) + s_plane[3][tid * GSR_PLANE_STRIDE + k];
+			const float4 A = sA[tid], B = sB[tid];
+			const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x, op = B.y;
+			const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[4];
+			const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
+			const uint32_t my_row = s_row[tid];
+			float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row * GSR_ROW_STRIDE);
+			dst[0] = make_float4(-(op * FMA(cb, M01, ca * M10)) * ddelx_dx, -(op * FMA(cb, M10, cc * M01)) * ddely_dy,
+			                     -0.5f * op * M20, -0.5f * op * M11);
+			dst[1] = make_float4(-0.5f * op * M02, v[5], v[6], v[7]);
+			dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
+			if (FLAGS) row_flags[my_row] = 1;
+		}
+		part_cur = part_next;
+	}
+}
+
 // v_rcp_f32(1.0) == 1.0 (and a few neighbours behave): composite_bwd relies on it to carry dead pixels through
 // without a select on T (TSEL = false).  Checked once per process by gsr_selftest; a failing device gets TSEL = true.
 __global__ void bwd_selftest_kernel(const float* __restrict__ in, uint32_t* __restrict__ out)
@@ -448,16 +775,19 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
                           int variant, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
-	const bool tsel = (variant & 1) != 0;
-#define GSR_LAUNCH_CB(FL, TS)                                                                                      \
-	hipLaunchKernelGGL((composite_bwd_kernel<FL, TS>), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, \
+	const bool tsel = (variant & 1) != 0, wave_lists = (variant & 2) != 0;
+#define GSR_LAUNCH_CB(K, FL, TS)                                                                                   \
+	hipLaunchKernelGGL((K<FL, TS>), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H,        \
 	                   bg, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix, dL_dpix_depth, dL_dpix_median,      \
 	                   dL_dpix_opacity, rows, row_flags)
-	if (row_flags != nullptr) {
-		if (tsel) GSR_LAUNCH_CB(true, true); else GSR_LAUNCH_CB(true, false);
-	} else {
-		if (tsel) GSR_LAUNCH_CB(false, true); else GSR_LAUNCH_CB(false, false);
+#define GSR_LAUNCH_CB2(K)                                                                                          \
+	if (row_flags != nullptr) {                                                                                    \
+		if (tsel) GSR_LAUNCH_CB(K, true, true); else GSR_LAUNCH_CB(K, true, false);                                \
+	} else {                                                                                                       \
+		if (tsel) GSR_LAUNCH_CB(K, false, true); else GSR_LAUNCH_CB(K, false, false);                              \
 	}
+	if (wave_lists) { GSR_LAUNCH_CB2(composite_bwd_kernel) } else { GSR_LAUNCH_CB2(composite_bwd_quarter_kernel) }
+#undef GSR_LAUNCH_CB2
 #undef GSR_LAUNCH_CB
 }
 

@@ -1150,51 +1150,6 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 #define GSR_FWD_LIST 264                       // list entries per quarter (u16 byte offsets): 256 + two groups of sentinels
 #define GSR_FWD_NONE 0xffffu
 
-// Which of the tile's sixteen 4x4 pixel blocks (bit 4*row + col) can hold a pixel with 0 >= power >= pcut?  Conservative
-// like gs_box_may_touch, organised by rows of blocks: for the band of dy a block row spans, the dx-extent
-// [lo, hi] of the region {power >= pc} is found in closed form (the roots of the quadratic in dx at the band's two
-// ends, plus the region's extreme points in x when they lie in the band -- the extent is a concave/convex function of
-// dy, so those three candidates contain its extremum); a block is hit iff its dx range meets [lo, hi].  pc = pcut minus
-// a slack of 0.05 + 1e-5 * (largest |term| over the tile), the ranges are widened by 0.01 px.
-__device__ __forceinline__ uint32_t gs_quarter_mask(const float4 A, const float4 B, float tx0, float ty0, uint32_t allq)
-{
-	const float ha = A.z, nb = A.w, hc = B.x, pcut = B.w;
-	if (!(pcut <= 0.f)) return 0u;               // opacity < 1/255
-	const float hh = 4.f * ha * hc;
-	const float D = hh - nb * nb;
-	if (!(ha < 0.f && hc < 0.f && D > 1e-4f * hh)) return allq;   // not (safely) negative definite: keep everywhere
-	// d = centre - pixel relative to the tile's first pixel; block column i spans dx in [rx - (4i + 3), rx - 4i]
-	// (blocks cut by the image border are tested whole: conservative, and the constants stay literals)
-	const float rx = A.x - tx0, ry = A.y - ty0;
-	const float Dx = fmaxf(fabsf(rx), fabsf(rx - 15.f)), Dy = fmaxf(fabsf(ry), fabsf(ry - 15.f));
-	const float mag = fabsf(ha) * Dx * Dx + fabsf(hc) * Dy * Dy + fabsf(nb) * Dx * Dy;
-	const float pc = pcut - (0.05f + 1e-5f * mag);
-	const float rD = __builtin_amdgcn_rcpf(D);
-	const float c4 = 4.f * ha * pc;                                        // > 0
-	const float ex = __builtin_amdgcn_sqrtf(4.f * pc * hc * rD);           // half extent in dx of {power >= pc}
-	const float dys = -0.5f * nb * ex * __builtin_amdgcn_rcpf(hc);         // dy where dx = +ex is reached
-	const float r = -0.5f * __builtin_amdgcn_rcpf(ha);                     // 1 / (2|ha|)
-	const float BIG = 3.0e38f;
-	uint32_t mask = 0;
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		const float Y0 = ry - (4.f * j + 3.f), Y1 = ry - 4.f * j;           // dy over the block row
-		const float d0 = FMA(-D * Y0, Y0, c4), d1 = FMA(-D * Y1, Y1, c4);   // discriminants / 1 at both ends
-		const float s0 = __builtin_amdgcn_sqrtf(fmaxf(d0, 0.f)), s1 = __builtin_amdgcn_sqrtf(fmaxf(d1, 0.f));
-		const float u0 = nb * Y0, u1 = nb * Y1;
-		const float h0 = d0 >= 0.f ? (u0 + s0) * r : -BIG, l0 = d0 >= 0.f ? (u0 - s0) * r : BIG;
-		const float h1 = d1 >= 0.f ? (u1 + s1) * r : -BIG, l1 = d1 >= 0.f ? (u1 - s1) * r : BIG;
-		const float hs = (Y0 <= dys && dys <= Y1) ? ex : -BIG;
-		const float ls = (Y0 <= -dys && -dys <= Y1) ? -ex : BIG;
-		const float hi = fmaxf(fmaxf(h0, h1), hs) - rx;   // compared against -(4i + 3) - 0.01 <= hi - rx, ...
-		const float lo = fminf(fminf(l0, l1), ls) - rx;
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			mask |= (-(4.f * i + 3.01f) <= hi && -(4.f * i - 0.01f) >= lo) ? (1u << (4 * j + i)) : 0u;
-	}
-	return mask & allq;
-}
-
 template <bool NOCULL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void composite_fwd_quarter_kernel(
     int T, int chunk, int gx, int W, int H, const uint2* __restrict__ ranges,
@@ -1246,7 +1201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 			const float4 a = rr->q0;
 			float4 b = rr->q1;
 			float4 c = rr->q2;
-			mk = NOCULL ? allq : gs_quarter_mask(a, b, tx0, ty0, allq);
+			mk = NOCULL ? allq : gs_quarter_mask<4>(a, b, tx0, ty0, allq);
 			c.w = b.z;
 			b.z = __int_as_float((int)id);
 			sRec[tid] = a;
@@ -1283,22 +1238,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 		__builtin_amdgcn_wave_barrier();
 		const int n = max(max(c0, c1), max(c2, c3));
 		uint32_t last_off = GSR_FWD_NONE, med_off = GSR_FWD_NONE;
-		// four list entries per step, fetched one step ahead of their use.  The read is inline assembly: the compiler
-		// sinks an ordinary prefetch load down to its use (exposing a full LDS latency per step); the wait in front of the
-		// use is ours too (LDS returns in order, so the compiler's own counted waits stay sufficient).
-		uint2 pk;
-		{
-			const uint32_t la = (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)my_list;
-			asm volatile("ds_read_b64 %0, %1" : "=v"(pk) : "v"(la));
-		}
+		// four list entries per step, fetched one step ahead of their use; the scheduling barrier keeps the read up here
+		// (left alone, the scheduler sinks it to its use and exposes a full LDS latency per step)
+		uint2 pk = *reinterpret_cast<const uint2*>(my_list);
 		for (int i = 0; i < n; i += 4) {
 			if ((i & 31) == 0 && __ballot(!done) == 0ull) break;   // every pixel of this wave has saturated
-			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pk));
 			const uint32_t offs[4] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
-			{
-				const uint32_t la = (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)(my_list + i + 4);
-				asm volatile("ds_read_b64 %0, %1" : "=v"(pk) : "v"(la));
-			}
+			pk = *reinterpret_cast<const uint2*>(my_list + i + 4);
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
 				const uint32_t off = offs[k];

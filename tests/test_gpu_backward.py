@@ -134,9 +134,10 @@ def test_autograd_function_end_to_end(oracle):
 
 
 def test_backward_is_run_to_run_deterministic():
-    """The reference's float atomicAdd makes its gradients order-dependent.  Here every sum has a fixed order:
-    DPP / lane-swap tree inside a wave, exactly two waves meeting per (tile, Gaussian) in LDS (a + b == b + a),
-    per-Gaussian rows added in ascending tile order -> bit-identical gradients on every run."""
+    """The reference's float atomicAdd makes its gradients order-dependent.  Here every sum has a fixed order: FMAs
+    and a DPP butterfly inside a lane group, the quarters of a wave meeting in an instance through LDS adds that the
+    wave issues in program order, the four waves of a tile in four planes added in fixed order, per-Gaussian rows
+    added in ascending tile order -> bit-identical gradients on every run."""
     cam = scenes.make_camera(800, 800)
     sc = scenes.make_scene(300000, cam, seed=2)
     kw = scene_kwargs(sc, True, False)
@@ -173,10 +174,12 @@ def test_backward_baseline_configs(oracle, name, P, W, H, D):
     _check(oracle, sc, cam, D, scene_kwargs(sc, True, False))
 
 
-def test_backward_variants_of_the_kernel_agree_bit_for_bit():
+def test_backward_variants_of_the_kernel_agree():
     """composite_bwd carries dead pixels through arithmetically (G masked to 0, 1/(1-0) == 1); the variant that keeps
-    an explicit select on T must give the same bits, and so must a run on the reference's square binning (the extra
-    instances contribute exact zeros)."""
+    an explicit select on T must give the same bits.  The per-wave (8x8) kernel of round 2a (variant bit 1) and a run
+    on the reference's square binning (the extra instances contribute exact zeros, but shift the 64-instance batches
+    and with them the order in which the quarters of a wave meet in an instance) add the same terms in another order:
+    equal within the fp32 summation tolerance of every tensor's scale."""
     from gaustudio_amd import _C
     cam = scenes.make_camera(640, 360)
     sc = scenes.make_scene(120000, cam, seed=12)
@@ -188,10 +191,15 @@ def test_backward_variants_of_the_kernel_agree_bit_for_bit():
     try:
         _C.set_option("bwd_variant", 1)
         b = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+        _C.set_option("bwd_variant", 2)
+        w0 = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+        _C.set_option("bwd_variant", 3)
+        w1 = hip_backward_raw(hs, sc, cam, 3, kw, grads)
     finally:
         _C.set_option("bwd_variant", old)
     for k in GRAD_KEYS + ("acc",):
         assert torch.equal(a[k], b[k]), k
+        assert torch.equal(w0[k], w1[k]), k
     try:
         _C.set_option("tight_binning", 0)
         hs0 = hip_forward(sc, cam, 3, kw)
@@ -199,5 +207,10 @@ def test_backward_variants_of_the_kernel_agree_bit_for_bit():
     finally:
         _C.set_option("tight_binning", 1)
     assert hs0["num_binned"] > hs["num_binned"]
-    for k in GRAD_KEYS + ("acc",):
-        assert torch.equal(a[k], c[k]), k
+    for other in (w0, c):
+        for k in GRAD_KEYS + ("acc",):
+            x, y = a[k].double(), other[k].double()
+            if x.numel() == 0:
+                continue
+            scale = float(y.abs().max())
+            assert float((x - y).abs().max()) <= 2e-5 * scale + 1e-30, (k, float((x - y).abs().max()), scale)
