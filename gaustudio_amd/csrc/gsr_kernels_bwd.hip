@@ -1,10 +1,11 @@
 // gsr_kernels_bwd.hip -- backward kernels of libgsrast for gfx950 (MI355X, wave64).
 //
-//   composite_bwd    one workgroup of four wave64 per tile, one pixel per lane, back to front; per (wave, instance)
-//                    pair two per-pixel scalars go through an LDS slab and are turned into the ten per-Gaussian
-//                    sums by lanes re-mapped to (pair, pixel row) -- a transposition instead of a cross-lane
-//                    reduction tree; each (tile, Gaussian) instance leaves one plain-stored 48-B row in
-//                    Gaussian-major order -- no atomics of any kind
+//   composite_bwd    one workgroup of four wave64 per tile, one pixel per lane, back to front; every 16-lane quarter
+//                    of a wave (a 4x4 pixel block) walks its own list of the staged instances; two per-pixel
+//                    scalars per (pixel, instance) go through an LDS slab and are turned into the ten per-Gaussian
+//                    sums by lanes re-mapped to (quarter, list step, pixel row) -- a transposition instead of a
+//                    cross-lane reduction tree; each (tile, Gaussian) instance leaves one plain-stored 48-B row in
+//                    Gaussian-major order -- no global atomics
 //                    (replaces backward.cu:415-610 renderCUDA: 11-12 atomicAdd per (pixel, Gaussian))
 //   (row offsets goff: per-block sums in preprocess_fwd + tile_scan block 1 + goff_apply, gsr_kernels_fwd.hip)
 //   preprocess_bwd   one lane per Gaussian: fixed-order sum of its rows (fetched wave-cooperatively through LDS),
@@ -434,12 +435,18 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 //   phase 2 (every GSR_BWQ_U steps; lane = (quarter, step u, pixel row r)): the lane accumulates the 4 pixels of its
 //           row -- their upstream gradients live in REGISTERS (20 VGPRs; with 8 pixels per lane they had to be
 //           re-read from an LDS table for every pair: 80 % of phase 2's LDS traffic), folds the 4 rows with two DPP
-//           butterflies and adds the ten sums to the instance's slot in the wave's plane with LDS float atomics
-//           (quarters of a wave may meet in an instance; LDS executes a wave's instructions in order and resolves
-//           equal addresses inside one instruction in lane order, so the sums stay reproducible; across waves there
-//           are four planes, added by the flush in fixed order as before).
+//           butterflies and adds the ten sums to the instance's slot in the wave's plane.  Quarters of a wave may
+//           meet in an instance, so the four quarters take turns with plain read / add / write around the steps of
+//           the NEXT group (program order between the turns, the read's latency hidden behind a step); across waves
+//           there are four planes, added by the flush in fixed order as before: bit-reproducible from run to run.
+//   Measured and not kept: LDS float atomics for the plane update (they serialise their lanes: 1.13 ms, the LDS pipe
+//   2.4x as busy); 8 steps per reduction with 8 pixels per lane (halves the fold, needs 165 VGPRs: 0.68 ms at 3
+//   waves/SIMD against 0.59 ms at 4); one float4 per lane and turn instead of three floats (spills: 0.69 ms); a fused
+//   v_add_f32_dpp fold by inline assembly and skipping the steps past the longest list (no change: the kernel is
+//   bound by latency at 4 waves/SIMD, not by its VALU count).
 // A wave walks max over its quarters (C3: 0.73x the steps of the 8x8 walk), and phase 2 touches only hit quarters.
-// The median-depth gradient is added by phase 1 at the one step whose list position the forward recorded.
+// The median-depth gradient (one Gaussian per pixel, the list position the forward recorded) is added once per pixel,
+// by an LDS atomic before the walk of the batch that position falls into.
 #define GSR_BWQ_U 4          // list steps per transposed reduction
 #define GSR_BWQ_LIST 72      // bytes per quarter list: 64 entries + 8 sentinels
 #define GSR_BWQ_SENT 64      // batch index of the sentinel record (opacity 0)
