@@ -33,18 +33,22 @@ doc = {"_comment": "per-launch counters of the benchmark-sized dispatches (large
                    "factors calibrated in profiles/r02_fetch_write_calibration.txt for these kernels' access patterns (64-B record "
                    "gather: 1.0), traffic_upper_bytes = 2*FETCH + WRITE (the coalesced-stream factor applied to every read)",
        "workload": wl}
-for name in ("composite_fwd_kernel", "composite_bwd_kernel", "preprocess_fwd_kernel", "preprocess_bwd_kernel",
-             "preprocess_bwd_sh_coop_kernel", "bin_chunk_kernel", "tile_sort_kernel"):
+# (the per-quarter compositing kernels are the default ones; the per-wave variants only show up in A/B runs)
+for name in ("composite_fwd_quarter_kernel", "composite_bwd_quarter_kernel", "composite_fwd_kernel", "composite_bwd_kernel",
+             "preprocess_fwd_kernel", "preprocess_bwd_kernel", "preprocess_bwd_sh_coop_kernel", "bin_chunk_kernel",
+             "tile_sort_kernel"):
     grids = [g for (n, g) in sq if n == name]
     if not grids:
         continue
     g = max(grids)
     s, f, w = sq.get((name, g), {}), fe.get((name, g), {}), wr.get((name, g), {})
-    key = name.replace("_kernel", "")
+    key = name.replace("_quarter_kernel", "").replace("_kernel", "")
+    if key in doc:
+        continue
     doc[key] = {"grid": g, "fetch_size_kb": f.get("FETCH_SIZE"), "write_size_kb": w.get("WRITE_SIZE"),
                 "traffic_bytes": int((f.get("FETCH_SIZE", 0) + w.get("WRITE_SIZE", 0)) * 1024),
                 "traffic_upper_bytes": int((2 * f.get("FETCH_SIZE", 0) + w.get("WRITE_SIZE", 0)) * 1024),
                 "valu_insts": int(s.get("SQ_INSTS_VALU", 0)), "salu_insts": int(s.get("SQ_INSTS_SALU", 0)),
-                "lds_insts": int(s.get("SQ_INSTS_LDS", 0)), "valu_cycles_per_inst_model": 2.7}
+                "lds_insts": int(s.get("SQ_INSTS_LDS", 0)), "valu_cycles_per_inst_model": 2.7, "kernel": name}
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps(doc, indent=1)[:1500])
