@@ -162,12 +162,15 @@ int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int
                        float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                        float* dL_dscale, float* dL_drot, char* scratch, int debug, void* stream);
 
-/* Process-wide tunables (also read from the environment at load: GSR_TIGHT_BINNING, GSR_CULL, GSR_BWD_VARIANT,
- * GSR_SPECULATIVE).  The first five never change a result bit; they exist for A/B measurements and parity tests:
+/* Process-wide tunables (also read from the environment at load: GSR_TIGHT_BINNING, GSR_CULL, GSR_FWD_VARIANT,
+ * GSR_BWD_VARIANT, GSR_SPECULATIVE).  The first five never change a bit of the forward (the backward variants add the
+ * same terms in another order); they exist for A/B measurements and parity tests:
  *   "tight_binning" 1|0  bin each Gaussian into the tight sub-rect of the reference's getRect square (default 1);
- *   "cull"          1|0  wave-level culling + pcut pre-test in composite_fwd (default 1);
+ *   "cull"          1|0  block-level culling + pcut pre-test in composite_fwd (default 1);
+ *   "fwd_variant"   0 = composite_fwd with per-quarter (4x4 pixel) instance lists (default), 1 = per-wave (8x8) walk;
  *   "speculative"   1|0  enqueue binning + compositing before the host has read the instance count (default 1);
- *   "bwd_variant"   -1 = auto (gsr_selftest), bit 0 = keep the select on T in composite_bwd;
+ *   "bwd_variant"   -1 = auto (gsr_selftest), bit 0 = keep the select on T in composite_bwd, bit 1 = the per-wave
+ *                        (8x8) kernel instead of the per-quarter one;
  *   "bin_capacity"  n    binning capacity (instances) assumed by the next gsr_forward on the current device
  *                        (0 = forget; tests use a small n to force the re-allocate-and-relaunch path);
  *   "tile_row_lo", "tile_row_hi"  tile-grid sharding of ONE view across processes: only the 16-pixel
