@@ -448,8 +448,13 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 // The median-depth gradient (one Gaussian per pixel, the list position the forward recorded) is added once per pixel,
 // by an LDS atomic before the walk of the batch that position falls into.
 #define GSR_BWQ_U 4          // list steps per transposed reduction
-#define GSR_BWQ_LIST 72      // bytes per quarter list: 64 entries + 8 sentinels
-#define GSR_BWQ_SENT 64      // batch index of the sentinel record (opacity 0)
+#ifndef GSR_BWQ_BATCH
+#define GSR_BWQ_BATCH 128    // instances staged per round (64 or 128): the four waves and their quarters re-synchronise
+                             // once per round -- census at C3: 30.1 k workgroup steps at 64, 28.3 k at 128 (20.9 k ideal)
+#endif
+#define GSR_BWQ_HALVES (GSR_BWQ_BATCH / 64)
+#define GSR_BWQ_LIST (GSR_BWQ_BATCH + 8)   // bytes per quarter list: the entries + 8 sentinels
+#define GSR_BWQ_SENT GSR_BWQ_BATCH         // batch index of the sentinel record (opacity 0)
 #define GSR_BWQ_QSTRIDE 66   // float2 per quarter in the slab: 4 steps x 16 pixels + 2 pad (16-B aligned, banks shifted)
 
 template <bool FLAGS, bool TSEL>
@@ -460,11 +465,11 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
     const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags)
 {
-	__shared__ float4 sA[GSR_BWD_BATCH + 1];   // q0: px, py, -a/2, -b        (slot 64: the sentinel)
-	__shared__ float4 sB[GSR_BWD_BATCH + 1];   // q1: -c/2, opacity, depth, pcut
-	__shared__ float4 sC[GSR_BWD_BATCH + 1];   // q2: r, g, b, -
-	__shared__ uint32_t s_row[GSR_BWD_BATCH];
-	__shared__ __attribute__((aligned(16))) float s_plane[4][GSR_BWD_BATCH * GSR_PLANE_STRIDE];
+	__shared__ float4 sA[GSR_BWQ_BATCH + 1];   // q0: px, py, -a/2, -b        (last slot: the sentinel)
+	__shared__ float4 sB[GSR_BWQ_BATCH + 1];   // q1: -c/2, opacity, depth, pcut
+	__shared__ float4 sC[GSR_BWQ_BATCH + 1];   // q2: r, g, b, -
+	__shared__ uint32_t s_row[GSR_BWQ_BATCH];
+	__shared__ __attribute__((aligned(16))) float s_plane[4][GSR_BWQ_BATCH * GSR_PLANE_STRIDE];
 	__shared__ __attribute__((aligned(16))) float2 s_slab[4][4 * GSR_BWQ_QSTRIDE];
 	__shared__ __attribute__((aligned(16))) uint8_t s_list[4][4][GSR_BWQ_LIST];
 	__shared__ int s_max[4];
@@ -551,20 +556,27 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
 	// ---- software-pipelined staging (as in composite_bwd_kernel) ----
+	// thread t fetches 16-B part (t & 3) of the records of staged instances (t >> 2) + 64 h
 	const int srec = tid >> 2, spart = tid & 3;
-	auto load_id = [&](int t) -> uint32_t {
-		return (t > 0 && srec < min(GSR_BWD_BATCH, t)) ? point_list[range.x + (uint32_t)(t - 1 - srec)] : 0u;
+	auto load_id = [&](int t, int h) -> uint32_t {   // id of list position t-1-(srec + 64 h) (0 when outside the walk)
+		const int sr = srec + 64 * h;
+		return (t > 0 && sr < min(GSR_BWQ_BATCH, t)) ? point_list[range.x + (uint32_t)(t - 1 - sr)] : 0u;
 	};
-	auto load_part = [&](int t, uint32_t id) -> float4 {
+	auto load_part = [&](int t, int h, uint32_t id) -> float4 {
 		float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-		if (t > 0 && srec < min(GSR_BWD_BATCH, t)) {
+		if (t > 0 && srec + 64 * h < min(GSR_BWQ_BATCH, t)) {
 			v = reinterpret_cast<const float4*>(recs + id)[spart];
 			if (spart == 3) v.w = __uint_as_float(goff[id]);
 		}
 		return v;
 	};
-	uint32_t id_next = load_id(bmax - GSR_BWD_BATCH);
-	float4 part_cur = load_part(bmax, load_id(bmax));
+	uint32_t id_next[GSR_BWQ_HALVES];
+	float4 part_cur[GSR_BWQ_HALVES];
+#pragma unroll
+	for (int h = 0; h < GSR_BWQ_HALVES; h++) {
+		id_next[h] = load_id(bmax - GSR_BWQ_BATCH, h);
+		part_cur[h] = load_part(bmax, h, load_id(bmax, h));
+	}
 	const uint8_t* my_list = &s_list[wv][qd][0];
 	const char* recA = reinterpret_cast<const char*>(sA);
 	const char* recB = reinterpret_cast<const char*>(sB);
@@ -572,22 +584,30 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	float2* my_slab_w = slab + qd * GSR_BWQ_QSTRIDE + (lane & 15);                      // + 16 * step
 	const float4* my_slab_r = reinterpret_cast<const float4*>(slab + qd * GSR_BWQ_QSTRIDE + u2 * 16 + r2 * 4);
 
-	for (int top = bmax; top > 0; top -= GSR_BWD_BATCH) {
-		const int cnt = min(GSR_BWD_BATCH, top);
+	for (int top = bmax; top > 0; top -= GSR_BWQ_BATCH) {
+		const int cnt = min(GSR_BWQ_BATCH, top);
 		__syncthreads();   // the previous flush has read sA / sB / the planes
-		if (srec < cnt) {
-			if (spart == 0) sA[srec] = part_cur;
-			else if (spart == 1) sB[srec] = part_cur;
-			else if (spart == 2) sC[srec] = part_cur;
-			else {
-				const uint32_t q3x = __float_as_uint(part_cur.x), q3y = __float_as_uint(part_cur.y), q3w = __float_as_uint(part_cur.w);
-				const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
-				s_row[srec] = q3w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
+#pragma unroll
+		for (int h = 0; h < GSR_BWQ_HALVES; h++) {
+			const int sr = srec + 64 * h;
+			if (sr < cnt) {
+				if (spart == 0) sA[sr] = part_cur[h];
+				else if (spart == 1) sB[sr] = part_cur[h];
+				else if (spart == 2) sC[sr] = part_cur[h];
+				else {
+					const uint32_t q3x = __float_as_uint(part_cur[h].x), q3y = __float_as_uint(part_cur[h].y), q3w = __float_as_uint(part_cur[h].w);
+					const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
+					s_row[sr] = q3w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
+				}
 			}
 		}
-		const float4 part_next = load_part(top - GSR_BWD_BATCH, id_next);
-		id_next = load_id(top - 2 * GSR_BWD_BATCH);
-		for (int i = tid; i < 4 * GSR_BWD_BATCH * GSR_PLANE_STRIDE / 4; i += GSR_BWD_THREADS)
+		float4 part_next[GSR_BWQ_HALVES];
+#pragma unroll
+		for (int h = 0; h < GSR_BWQ_HALVES; h++) {
+			part_next[h] = load_part(top - GSR_BWQ_BATCH, h, id_next[h]);
+			id_next[h] = load_id(top - 2 * GSR_BWQ_BATCH, h);
+		}
+		for (int i = tid; i < 4 * GSR_BWQ_BATCH * GSR_PLANE_STRIDE / 4; i += GSR_BWD_THREADS)
 			reinterpret_cast<float4*>(&s_plane[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 		// this wave's four lists: sentinels, then (below) the hits of each quarter in list order
 		if (lane < 4 * GSR_BWQ_LIST / 16) {
@@ -599,27 +619,32 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		// (list position mpos, 1-based), when it is in this batch -- once per pixel per backward
 		if (mpos != 0u && dLm != 0.f && (uint32_t)top >= mpos && (uint32_t)top - mpos < (uint32_t)cnt)
 			atomicAdd(&plane[((uint32_t)top - mpos) * GSR_PLANE_STRIDE + 9], dLm);
-		// lane l: which of the wave's four 4x4 blocks can staged instance l touch, and is it still in front of the
-		// quarter's last contributor
-		uint32_t mk = 0;
-		if (lane < cnt) {
-			mk = gs_quarter_mask<2>(sA[lane], sB[lane], fbx, fby, 0xfu);
-			const int pos = top - 1 - lane;
-			mk &= (pos < qm0 ? 1u : 0u) | (pos < qm1 ? 2u : 0u) | (pos < qm2 ? 4u : 0u) | (pos < qm3 ? 8u : 0u);
-		}
+		// lane l: which of the wave's four 4x4 blocks can staged instance l + 64 h touch, and is it still in front of
+		// the quarter's last contributor; the hits of each quarter are appended to its list in list order
 		int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #define GSR_APPEND(QQ, CNT)                                                                                          \
 	{                                                                                                                \
-		const bool h = (mk >> (QQ)) & 1u;                                                                            \
-		const unsigned long long bm = __ballot(h);                                                                   \
-		const int pos_ = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)); \
-		if (h) s_list[wv][QQ][pos_] = (uint8_t)lane;                                                                 \
-		CNT = __popcll(bm);                                                                                          \
+		const bool h_ = (mk >> (QQ)) & 1u;                                                                           \
+		const unsigned long long bm = __ballot(h_);                                                                  \
+		const int pos_ = CNT + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)); \
+		if (h_) s_list[wv][QQ][pos_] = (uint8_t)jl;                                                                  \
+		CNT += __popcll(bm);                                                                                         \
 	}
-		GSR_APPEND(0, c0)
-		GSR_APPEND(1, c1)
-		GSR_APPEND(2, c2)
-		GSR_APPEND(3, c3)
+#pragma unroll
+		for (int h = 0; h < GSR_BWQ_HALVES; h++) {
+			const int jl = lane + 64 * h;
+			if (64 * h >= cnt) break;
+			uint32_t mk = 0;
+			if (jl < cnt) {
+				mk = gs_quarter_mask<2>(sA[jl], sB[jl], fbx, fby, 0xfu);
+				const int pos = top - 1 - jl;
+				mk &= (pos < qm0 ? 1u : 0u) | (pos < qm1 ? 2u : 0u) | (pos < qm2 ? 4u : 0u) | (pos < qm3 ? 8u : 0u);
+			}
+			GSR_APPEND(0, c0)
+			GSR_APPEND(1, c1)
+			GSR_APPEND(2, c2)
+			GSR_APPEND(3, c3)
+		}
 #undef GSR_APPEND
 		__builtin_amdgcn_wave_barrier();
 		const int n = max(max(c0, c1), max(c2, c3));
@@ -736,17 +761,17 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		}
 		// flush: one thread per staged instance adds the four planes in fixed order and stores the 48-B row
 		__syncthreads();
-		if (tid < cnt) {
+		for (int fj = tid; fj < cnt; fj += GSR_BWD_THREADS) {
 			float v[10];
 #pragma unroll
 			for (int k = 0; k < 10; k++)
-				v[k] = ((s_plane[0][tid * GSR_PLANE_STRIDE + k] + s_plane[1][tid * GSR_PLANE_STRIDE + k]) +
-				        s_plane[2][tid * GSR_PLANE_STRIDE + k]) + s_plane[3][tid * GSR_PLANE_STRIDE + k];
-			const float4 A = sA[tid], B = sB[tid];
+				v[k] = ((s_plane[0][fj * GSR_PLANE_STRIDE + k] + s_plane[1][fj * GSR_PLANE_STRIDE + k]) +
+				        s_plane[2][fj * GSR_PLANE_STRIDE + k]) + s_plane[3][fj * GSR_PLANE_STRIDE + k];
+			const float4 A = sA[fj], B = sB[fj];
 			const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x, op = B.y;
 			const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[4];
 			const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
-			const uint32_t my_row = s_row[tid];
+			const uint32_t my_row = s_row[fj];
 			float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row * GSR_ROW_STRIDE);
 			dst[0] = make_float4(-(op * FMA(cb, M01, ca * M10)) * ddelx_dx, -(op * FMA(cb, M10, cc * M01)) * ddely_dy,
 			                     -0.5f * op * M20, -0.5f * op * M11);
@@ -754,7 +779,8 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
 			if (FLAGS) row_flags[my_row] = 1;
 		}
-		part_cur = part_next;
+#pragma unroll
+		for (int h = 0; h < GSR_BWQ_HALVES; h++) part_cur[h] = part_next[h];
 	}
 }
 

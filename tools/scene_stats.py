@@ -111,3 +111,32 @@ for t in tiles.tolist():
 print(f"wave walk length, 8x8 lists: {it8}; 4x4 quarter lists: mean-of-quarters {it4_mean:.0f} ({it4_mean / it8:.3f}), "
       + ", ".join(f"resync/{k if k < 1 << 30 else 'never'} {v} ({v / it8:.3f})" for k, v in it4.items())
       + f"; 8x4 halves resync/256 {it2[256]} ({it2[256] / it8:.3f})")
+
+# ---- composite_bwd with per-quarter lists: steps of a workgroup per batch of B staged instances = max over its four
+# waves of (max over the wave's quarters of its hits in the batch); walked back to front from the tile's deepest
+# n_contrib, every quarter cut at its own deepest n_contrib. ----
+res = {B: [0, 0, 0.0] for B in (32, 64, 128, 256)}   # [sum over batches of max_w n_w, sum of mean_w n_w, sum of mean over 16 quarters]
+for t in tiles.tolist():
+    a, b = int(r[t, 0]), int(r[t, 1])
+    if b <= a: continue
+    ids = pl[a:b]; tx, ty = t % gx, t // gx
+    bmax = min(int(ncp[t].max()), len(ids))
+    if bmax == 0: continue
+    sel = ids[:bmax]
+    H16 = torch.zeros(16, bmax, dtype=torch.long, device=xy.device)
+    pos = torch.arange(bmax, device=xy.device)
+    for blk in range(4):
+        bx0 = tx * 16 + (blk & 1) * 8; by0 = ty * 16 + (blk >> 1) * 8
+        for q in range(4):
+            qx0 = bx0 + (q & 1) * 4; qy0 = by0 + (q >> 1) * 4
+            if qx0 > W - 1 or qy0 > H - 1: continue
+            qmax = int(ncp[t, qy0 - ty * 16:qy0 - ty * 16 + 4, qx0 - tx * 16:qx0 - tx * 16 + 4].max())
+            H16[blk * 4 + q] = (box_test(xy[sel], co[sel], qx0, qy0, min(qx0 + 3, W - 1), min(qy0 + 3, H - 1)) & (pos < qmax)).long()
+    Hr = torch.flip(H16, dims=[1])           # back to front
+    for B in res:
+        pad = (-bmax) % B
+        hb = torch.nn.functional.pad(Hr, (0, pad)).view(4, 4, -1, B).sum(3)      # [wave][quarter][batch]
+        nw = hb.max(1).values                                                     # [wave][batch]
+        res[B][0] += int(nw.max(0).values.sum()); res[B][1] += float(nw.float().mean(0).sum()); res[B][2] += float(hb.float().mean((0, 1)).sum())
+print("composite_bwd quarter-list census (steps per workgroup): " + "; ".join(
+    f"B={B}: max-wave {v[0]}, mean-wave {v[1]:.0f} (max/mean {v[0] / v[1]:.3f}), mean-quarter {v[2]:.0f} (wave/quarter {v[1] / v[2]:.3f})" for B, v in res.items()))
