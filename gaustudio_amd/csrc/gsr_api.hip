@@ -601,7 +601,8 @@ static int backward_impl(int parts, int sh_g0, int sh_g1, int P, int D, int M, i
 	tm.mark();
 	if (R > 0) {
 		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix,
-		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags, bwd_variant(s), s);
+		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags,
+		                     reinterpret_cast<const GsCtl*>(image_buffer + il.ctl), bwd_variant(s), s);
 		STAGE_CHECK("composite_bwd", debug, s);
 	}
 	tm.mark();

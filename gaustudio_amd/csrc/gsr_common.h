@@ -47,8 +47,19 @@ struct GsCtl {
 	uint32_t err_prefiltered;
 	uint32_t err_overflow;   // the reference-defined count does not fit the reference's int num_rendered
 	uint32_t ref_rendered;   // the reference's num_rendered: sum of getRect areas (rasterizer_impl.cu:280-284)
-	uint32_t pad[3];
+	uint32_t has_qmask;      // composite_fwd left one 16-bit block mask per list entry behind the list (see gs_qmask_ptr)
+	uint32_t pad[2];
 };
+
+// Per-instance block masks of the forward (bit 4*row + col: which 4x4 pixel blocks of the tile the instance can touch,
+// gs_quarter_mask<4>), kept for the backward: u16 per list entry, in the binning buffer right behind the list's
+// num_binned ids (256-B aligned) -- over the sort keys, which are dead once the lists are sorted (6 B per instance of a
+// buffer that holds at least 12).
+__device__ __forceinline__ uint16_t* gs_qmask_ptr(const uint32_t* point_list, uint32_t num_binned)
+{
+	const size_t off = ((size_t)num_binned * 4 + 255) / 256 * 256;
+	return reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(const_cast<uint32_t*>(point_list)) + off);
+}
 
 __device__ __forceinline__ float gs_exp(float p)
 {

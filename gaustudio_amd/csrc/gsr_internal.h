@@ -117,7 +117,7 @@ void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* range
                       uint32_t* point_list, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, const GsCtl* ctl,
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl,
                           uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, hipStream_t s);
 
 // --- launchers (gsr_kernels_bwd.hip) ---
@@ -161,7 +161,7 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const uint32_t* med_pos, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
-                          int variant, hipStream_t s);
+                          const GsCtl* ctl, int variant, hipStream_t s);
 // parts: GSR_PART_GEOM = the per-Gaussian geometry kernel (all P Gaussians); GSR_PART_SH = the SH kernel over
 // the Gaussians [sh_g0, sh_g1) (a multiple-of-256 start; lets a caller interleave a collective per chunk)
 #define GSR_PART_GEOM 1

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ med_pos,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
-    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags)
+    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags,
+    const GsCtl* __restrict__ ctl)
 {
 	__shared__ float4 sA[GSR_BWD_BATCH];   // q0: px, py, -a/2, -b
 	__shared__ float4 sB[GSR_BWD_BATCH];   // q1: -c/2, opacity, depth, pcut
@@ -463,12 +464,14 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ med_pos,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
-    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags)
+    const float* __restrict__ dL_dpix_opacity, float* __restrict__ rows, uint8_t* __restrict__ row_flags,
+    const GsCtl* __restrict__ ctl)
 {
 	__shared__ float4 sA[GSR_BWQ_BATCH + 1];   // q0: px, py, -a/2, -b        (last slot: the sentinel)
 	__shared__ float4 sB[GSR_BWQ_BATCH + 1];   // q1: -c/2, opacity, depth, pcut
 	__shared__ float4 sC[GSR_BWQ_BATCH + 1];   // q2: r, g, b, -
 	__shared__ uint32_t s_row[GSR_BWQ_BATCH];
+	__shared__ uint16_t s_qmask[GSR_BWQ_BATCH];   // the forward's block masks of the staged instances (when it left them)
 	__shared__ __attribute__((aligned(16))) float s_plane[4][GSR_BWQ_BATCH * GSR_PLANE_STRIDE];
 	__shared__ __attribute__((aligned(16))) float2 s_slab[4][4 * GSR_BWQ_QSTRIDE];
 	__shared__ __attribute__((aligned(16))) uint8_t s_list[4][4][GSR_BWQ_LIST];
@@ -486,6 +489,9 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	const float pixfx = (float)px, pixfy = (float)py;
 	const float fbx = (float)(tx * GSR_BLOCK_X + ((wv & 1) << 3)), fby = (float)(ty * GSR_BLOCK_Y + ((wv >> 1) << 3));
 	const uint2 range = ranges[tile];
+	// the forward's per-instance block masks (gs_qmask_ptr), if it left them: the cull below then costs two shifts
+	const bool have_qmask = ctl->has_qmask != 0u;
+	const uint16_t* __restrict__ qmask = gs_qmask_ptr(point_list, ctl->num_binned);
 
 	const size_t sidx = (size_t)tile * GSR_TILE_PIX + (wv << 6) + ((ly & 7) << 3) + (lx & 7);   // tile-major pixel state
 	const float T_final = inside ? final_T[sidx] : 0.f;
@@ -566,7 +572,10 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 		if (t > 0 && srec + 64 * h < min(GSR_BWQ_BATCH, t)) {
 			v = reinterpret_cast<const float4*>(recs + id)[spart];
-			if (spart == 3) v.w = __uint_as_float(goff[id]);
+			if (spart == 3) {   // q3 = {rect min, rect max, clamp bits, tiles}: .w <- first row, .z <- the forward's block mask
+				v.w = __uint_as_float(goff[id]);
+				if (have_qmask) v.z = __uint_as_float((uint32_t)qmask[range.x + (uint32_t)(t - 1 - (srec + 64 * h))]);
+			}
 		}
 		return v;
 	};
@@ -598,6 +607,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 					const uint32_t q3x = __float_as_uint(part_cur[h].x), q3y = __float_as_uint(part_cur[h].y), q3w = __float_as_uint(part_cur[h].w);
 					const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
 					s_row[sr] = q3w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
+					s_qmask[sr] = (uint16_t)__float_as_uint(part_cur[h].z);
 				}
 			}
 		}
@@ -636,7 +646,12 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			if (64 * h >= cnt) break;
 			uint32_t mk = 0;
 			if (jl < cnt) {
-				mk = gs_quarter_mask<2>(sA[jl], sB[jl], fbx, fby, 0xfu);
+				if (have_qmask) {   // bits 4*row + col of the tile's blocks -> bits 2*row + col of this wave's
+					const uint32_t m16 = (uint32_t)s_qmask[jl] >> (8 * (wv >> 1) + 2 * (wv & 1));
+					mk = (m16 & 3u) | ((m16 >> 2) & 12u);
+				} else {
+					mk = gs_quarter_mask<2>(sA[jl], sB[jl], fbx, fby, 0xfu);
+				}
 				const int pos = top - 1 - jl;
 				mk &= (pos < qm0 ? 1u : 0u) | (pos < qm1 ? 2u : 0u) | (pos < qm2 ? 4u : 0u) | (pos < qm3 ? 8u : 0u);
 			}
@@ -805,14 +820,14 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const uint32_t* med_pos, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
-                          int variant, hipStream_t s)
+                          const GsCtl* ctl, int variant, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
 	const bool tsel = (variant & 1) != 0, wave_lists = (variant & 2) != 0;
 #define GSR_LAUNCH_CB(K, FL, TS)                                                                                   \
 	hipLaunchKernelGGL((K<FL, TS>), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H,        \
 	                   bg, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix, dL_dpix_depth, dL_dpix_median,      \
-	                   dL_dpix_opacity, rows, row_flags)
+	                   dL_dpix_opacity, rows, row_flags, ctl)
 #define GSR_LAUNCH_CB2(K)                                                                                          \
 	if (row_flags != nullptr) {                                                                                    \
 		if (tsel) GSR_LAUNCH_CB(K, true, true); else GSR_LAUNCH_CB(K, true, false);                                \

@@ -1156,12 +1156,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ med_pos_out,
-    const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted)
+    GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted)
 {
 	__shared__ float4 sRec[3 * GSR_FWD_PLANE];   // planes A, B, C (as above), slot 256 of each = the sentinel
 	__shared__ uint16_t sMask[256];
 	__shared__ __attribute__((aligned(16))) uint16_t sList[4][4][GSR_FWD_LIST];
-	if (ctl->num_binned > cap || ctl->max_tile_count > max_sorted) return;   // see composite_fwd_kernel
+	const uint32_t num_binned = ctl->num_binned;
+	if (num_binned > cap || ctl->max_tile_count > max_sorted) return;   // see composite_fwd_kernel
+	// the block masks computed below stay behind for composite_bwd (gs_qmask_ptr)
+	uint16_t* __restrict__ qmask = gs_qmask_ptr(point_list, num_binned);
+	if (!NOCULL && blockIdx.x == 0 && threadIdx.x == 0) ctl->has_qmask = 1u;
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
@@ -1202,6 +1206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 			float4 b = rr->q1;
 			float4 c = rr->q2;
 			mk = NOCULL ? allq : gs_quarter_mask<4>(a, b, tx0, ty0, allq);
+			if (!NOCULL) qmask[range.x + base + tid] = (uint16_t)mk;
 			c.w = b.z;
 			b.z = __int_as_float((int)id);
 			sRec[tid] = a;
@@ -1309,7 +1314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, const GsCtl* ctl,
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl_,
                           uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
@@ -1317,9 +1322,11 @@ void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges
 	hipLaunchKernelGGL(K, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges, point_list, recs, out_color, \
 	                   out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted)
 	if (wave_lists) {
+		const GsCtl* ctl = ctl_;
 		if (nocull) GSR_LAUNCH_FWD(composite_fwd_kernel<true>);
 		else GSR_LAUNCH_FWD(composite_fwd_kernel<false>);
 	} else {
+		GsCtl* ctl = ctl_;
 		if (nocull) GSR_LAUNCH_FWD(composite_fwd_quarter_kernel<true>);
 		else GSR_LAUNCH_FWD(composite_fwd_quarter_kernel<false>);
 	}

@@ -207,7 +207,15 @@ def test_backward_variants_of_the_kernel_agree():
     finally:
         _C.set_option("tight_binning", 1)
     assert hs0["num_binned"] > hs["num_binned"]
-    for other in (w0, c):
+    # the default backward takes its per-block cull from the masks composite_fwd left behind the lists; after a forward
+    # that leaves none (per-wave walk) it computes its own, slightly different conservative masks: same live terms
+    try:
+        _C.set_option("fwd_variant", 1)
+        hs1 = hip_forward(sc, cam, 3, kw)
+        d = hip_backward_raw(hs1, sc, cam, 3, kw, grads)
+    finally:
+        _C.set_option("fwd_variant", 0)
+    for other in (w0, c, d):
         for k in GRAD_KEYS + ("acc",):
             x, y = a[k].double(), other[k].double()
             if x.numel() == 0:
