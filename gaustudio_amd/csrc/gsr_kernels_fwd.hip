@@ -678,16 +678,38 @@ __device__ __forceinline__ void gs_wave_sort_tile(const uint64_t* __restrict__ k
 				if ((e & j) == 0) gs_cex(k[e], k[e | j], (e & size) == 0);
 		}
 	}
-	// sizes KPL << ls, ls = 0 .. 6: direction = bit ls of the lane (0 for the final merge)
+	// sizes KPL << ls, ls = 0 .. 6: direction = bit ls of the lane (0 for the final merge).  Fully unrolled so that
+	// the partner exchange of the 18 (of 21) stages with lane strides 1, 2, 4 and 8 is a DPP move (quad permute / row
+	// rotate) instead of a ds_bpermute (a trip through the LDS crossbar); strides 16 and 32 keep the bpermute.
+#pragma unroll
 	for (int ls = 0; ls <= 6; ls++) {
 		const bool asc = ((lane >> ls) & 1) == 0;
+#pragma unroll
 		for (int m = (1 << ls) >> 1; m > 0; m >>= 1) {   // cross-lane strides m*KPL
 			const bool keep_min = ((lane & m) == 0) == asc;
 			const int src = (lane ^ m) << 2;
 #pragma unroll
 			for (int e = 0; e < KPL; e++) {
-				const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)k[e]);
-				const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(k[e] >> 32));
+				uint32_t olo, ohi;
+				if (m == 1) {
+					olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k[e], 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+					ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k[e] >> 32), 0xB1, 0xF, 0xF, true);
+				} else if (m == 2) {
+					olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k[e], 0x4E, 0xF, 0xF, true);          // quad_perm [2,3,0,1]
+					ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k[e] >> 32), 0x4E, 0xF, 0xF, true);
+				} else if (m == 4) {
+					// lane ^ 4 inside a 16-lane row: rotate by 4 for one half of the lanes, by 12 for the other (the second
+					// move only writes the banks -- groups of four lanes -- with bit 2 of the lane set)
+					const int lo_ = (int)(uint32_t)k[e], hi_ = (int)(uint32_t)(k[e] >> 32);
+					olo = (uint32_t)__builtin_amdgcn_update_dpp(__builtin_amdgcn_update_dpp(0, lo_, 0x12C, 0xF, 0xF, true), lo_, 0x124, 0xF, 0xA, false);
+					ohi = (uint32_t)__builtin_amdgcn_update_dpp(__builtin_amdgcn_update_dpp(0, hi_, 0x12C, 0xF, 0xF, true), hi_, 0x124, 0xF, 0xA, false);
+				} else if (m == 8) {
+					olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k[e], 0x128, 0xF, 0xF, true);          // row_ror:8
+					ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k[e] >> 32), 0x128, 0xF, 0xF, true);
+				} else {
+					olo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)k[e]);
+					ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(k[e] >> 32));
+				}
 				const uint64_t o = ((uint64_t)ohi << 32) | olo;
 				k[e] = ((o < k[e]) == keep_min) ? o : k[e];
 			}
