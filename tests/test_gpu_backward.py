@@ -174,6 +174,16 @@ def test_backward_baseline_configs(oracle, name, P, W, H, D):
     _check(oracle, sc, cam, D, scene_kwargs(sc, True, False))
 
 
+@pytest.mark.parametrize("kind", ["needles", "blobs", "threshold", "borders"])
+def test_backward_on_adversarial_scenes(oracle, kind):
+    """The backward's per-quarter lists come from the forward's block masks: on scenes built to stress the conservative
+    culls the sums must still meet the oracle's summation bounds (a wrongly culled live pixel would drop a term)."""
+    from test_gpu_forward import _adversarial_scene
+    cam = scenes.make_camera(331, 203)
+    sc = _adversarial_scene(5000 if kind != "blobs" else 1200, cam, seed=33, kind=kind)
+    _check(oracle, sc, cam, 2, scene_kwargs(sc, True, False))
+
+
 def test_backward_variants_of_the_kernel_agree():
     """composite_bwd carries dead pixels through arithmetically (G masked to 0, 1/(1-0) == 1); the variant that keeps
     an explicit select on T must give the same bits.  The per-wave (8x8) kernel of round 2a (variant bit 1) and a run

@@ -256,6 +256,59 @@ def test_forward_variants_agree_bit_for_bit(P, W, H, D, sig):
             assert torch.equal(a[k], other[k]), k
 
 
+def _adversarial_scene(P, cam, seed, kind):
+    """Scenes aimed at the conservative block culls (gs_quarter_mask / gs_box_may_touch / gs_tight_rect): needles
+    (axis ratios up to 1:300, every orientation), pancakes seen edge-on, screen-filling blobs, opacities hugging the
+    1/255 visibility threshold and the 0.99 alpha clamp, and centres sitting on block and tile borders."""
+    g = torch.Generator().manual_seed(seed)
+    sc = scenes.make_scene(P, cam, seed=seed, sigma_px_median=4.0)
+    scales, opac, means = sc.scales.clone(), sc.opacities.clone(), sc.means3D.clone()
+    if kind == "needles":
+        scales[:, 0] *= torch.exp(torch.rand(P, generator=g) * 5.7)            # up to x300 along one axis
+        scales[:, 1] *= 0.2
+    elif kind == "pancakes":
+        scales[:, 2] *= 0.003
+        scales[:, :2] *= 4.0
+    elif kind == "blobs":
+        scales *= torch.exp(torch.rand(P, 1, generator=g) * 4.0)               # up to x55: many tiles per Gaussian
+    elif kind == "threshold":
+        u = torch.rand(P, 1, generator=g)
+        opac = torch.where(u < 0.5, 1.0 / 255.0 * (0.9 + 0.4 * torch.rand(P, 1, generator=g)),   # 0.9 .. 1.3 / 255
+                           1.0 - 0.02 * torch.rand(P, 1, generator=g))                           # 0.98 .. 1.0
+    elif kind == "borders":
+        # snap the projected centres onto multiples of 4 pixels (+- half a pixel): block and tile borders
+        z = means[:, 2]
+        fx, fy = cam.width / (2 * cam.tanfovx), cam.height / (2 * cam.tanfovy)
+        px = means[:, 0] / z * fx + cam.width / 2 - 0.5
+        py = means[:, 1] / z * fy + cam.height / 2 - 0.5
+        px = torch.round(px / 4) * 4 + (torch.randint(0, 3, (P,), generator=g) - 1) * 0.5
+        py = torch.round(py / 4) * 4 + (torch.randint(0, 3, (P,), generator=g) - 1) * 0.5
+        means[:, 0] = (px + 0.5 - cam.width / 2) / fx * z
+        means[:, 1] = (py + 0.5 - cam.height / 2) / fy * z
+    return sc._replace(scales=scales.contiguous(), opacities=opac.contiguous(), means3D=means.contiguous())
+
+
+@pytest.mark.parametrize("kind", ["needles", "pancakes", "blobs", "threshold", "borders"])
+def test_block_culls_are_conservative_on_adversarial_scenes(oracle, kind):
+    """The per-quarter walk (default), the per-wave walk and the walk without any culling give the same bits on scenes
+    built to stress the culls; the default is also compared with the CPU oracle (which has no cull at all)."""
+    W, H = 331, 203
+    cam = scenes.make_camera(W, H)
+    sc = _adversarial_scene(6000 if kind != "blobs" else 1500, cam, seed=31, kind=kind)
+    kw = scene_kwargs(sc, True, False)
+    a = hip_forward(sc, cam, 2, kw)
+    with _with_options(fwd_variant=1):
+        b = hip_forward(sc, cam, 2, kw)
+    with _with_options(cull=0):
+        c = hip_forward(sc, cam, 2, kw)
+    with _with_options(cull=0, tight_binning=0):
+        d = hip_forward(sc, cam, 2, kw)
+    for other in (b, c, d):
+        for k in ("color", "depth", "median", "opacity", "radii", "final_T"):
+            assert torch.equal(a[k], other[k]), (kind, k)
+    compare_forward_exact(a, oracle_forward(oracle, sc, cam, 2, kw))
+
+
 def test_speculative_launch_overflow_is_retried():
     """The kernels behind the instance count are enqueued against the remembered binning capacity before the host
     has read the count; when the capacity is too small (forced here) they leave without touching memory and the host
