@@ -107,7 +107,9 @@ size_t gsr_image_bytes(int width, int height);
 
 /* Replaces Rasterizer::backward (rasterizer.h:61-91; rasterizer_impl.cu:347-452).
  * R = num_rendered returned by the matching gsr_forward; geom/binning/image buffers are the ones its
- * allocators returned, unmodified.  Outputs (all fully overwritten, rows of culled Gaussians = 0):
+ * allocators returned, unmodified and in full (besides the sorted lists the binning buffer carries the forward's
+ * 16-bit block mask of every list entry, which the compositing backward reads instead of recomputing a cull; a
+ * flag in the image buffer says whether the forward left them).  Outputs (all fully overwritten, rows of culled Gaussians = 0):
  *   dL_dmean2D[P,3] (xy used, already scaled by 0.5*W / 0.5*H, backward.cu:493-494,598-599),
  *   dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3] (may be NULL if M==0),
  *   dL_dscale[P,3], dL_drot[P,4].
