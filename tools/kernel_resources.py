@@ -7,7 +7,10 @@ f = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
        "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-munsafe-fp-atomics",
+       "-fno-slp-vectorize",   # as in csrc/Makefile for the kernel files
        "-I" + os.path.dirname(os.path.abspath(f)), "-Rpass-analysis=kernel-resource-usage", "-c", f, "-o", "/dev/null"]
+if "kernels_bwd" in f:
+    cmd[1:1] = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for l in out.splitlines():
