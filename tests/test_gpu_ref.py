@@ -55,10 +55,13 @@ def _image_close(name, a, b, quantum, recorded):
 
 def _compare(hs, ref, config):
     recorded = _recorded_flips(config)
-    assert hs["num_rendered"] == ref["num_rendered"]
     radii = to_np(hs["radii"])
     assert (radii != ref["radii"].numpy()).sum() <= 1e-5 * radii.size
-    stats = {"radii_differ": int((radii != ref["radii"].numpy()).sum())}
+    # a radius that lands on the other side of a ceil() (the reference binary contracts FMAs differently from the pinned
+    # contraction shared by the oracle and this library) changes that Gaussian's getRect area: the counts follow the radii
+    assert abs(hs["num_rendered"] - ref["num_rendered"]) <= 1e-5 * ref["num_rendered"]
+    stats = {"radii_differ": int((radii != ref["radii"].numpy()).sum()),
+             "num_rendered": [int(hs["num_rendered"]), int(ref["num_rendered"])]}
     stats["color"] = _image_close("color", to_np(hs["color"]), ref["color"].numpy(), 6e-3, recorded)
     stats["opacity"] = _image_close("opacity", to_np(hs["opacity"]), ref["opacity"].numpy(), 6e-3, recorded)
     # depth in scene units (2 .. 20 here), 1e-5 ABSOLUTE like colour; a flipped contributor moves it by alpha*T*depth
@@ -83,10 +86,13 @@ def _dump_parity(config, stats):
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("P,W,H,D", [(10000, 400, 400, 0), (300000, 800, 800, 3), (1000000, 1920, 1080, 3)],
-                         ids=["C1", "C2", "C3"])
+@pytest.mark.parametrize("P,W,H,D", [(10000, 400, 400, 0), (300000, 800, 800, 3), (1000000, 1920, 1080, 3),
+                                     (5000000, 1297, 840, 3), (2500000, 3840, 2160, 3)],
+                         ids=["C1", "C2", "C3", "C4", "C5"])
 def test_hip_vs_reference_kernels_at_baseline_configs(request, P, W, H, D):
-    """BASELINE configs C1, C2 and the full-size headline C3, forward and backward, against the reference's own kernels.
+    """BASELINE configs C1, C2, the full-size headline C3 and one view of the C4 / C5 sizes (5 M Gaussians with ~3.7 k
+    entries per tile: the long-list sort and row-flag regime; a 4K frame), forward and backward, against the reference's
+    own kernels.
     oracle/_ref/libgsref.so is built in the dev container (oracle/build_ref.sh) and travels with the snapshot: its
     absence on a GPU box is a FAILURE, not a skip -- this comparison is what pins the parity claim."""
     if not ref_util.available():
