@@ -165,9 +165,11 @@ def test_backward_long_lists_row_flag_regime(oracle, P, sigma):
     _check(oracle, sc, cam, 2, kw, seed=3)
 
 
-@pytest.mark.parametrize("name,P,W,H,D", [("C2", 300_000, 800, 800, 3), ("C3", 1_000_000, 1920, 1080, 3)])
+@pytest.mark.parametrize("name,P,W,H,D", [("C2", 300_000, 800, 800, 3), ("C3", 1_000_000, 1920, 1080, 3),
+                                            ("C4-view", 5_000_000, 1297, 840, 3), ("C5-view", 2_500_000, 3840, 2160, 3)])
 def test_backward_baseline_configs(oracle, name, P, W, H, D):
-    """BASELINE configs C2 and full-size C3: composite-stage sums inside the rigorous fp32 summation bound, the
+    """BASELINE configs C2, full-size C3 and one view of the C4 / C5 sizes (the long-list regime with row validity
+    flags; a 4K frame): composite-stage sums inside the rigorous fp32 summation bound, the
     per-Gaussian stage bit-exact given the same sums, end-to-end gradients within 2e-4 of each tensor's scale."""
     cam = scenes.make_camera(W, H)
     sc = scenes.make_scene(P, cam, seed=0)

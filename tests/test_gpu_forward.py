@@ -188,10 +188,12 @@ def test_single_tile_list_lengths_around_the_sort_size_classes(oracle, P):
 
 
 @pytest.mark.parametrize("name,P,W,H,D", [("C2", 300_000, 800, 800, 3), ("C3", 1_000_000, 1920, 1080, 3),
-                                            ("C3-D0", 1_000_000, 1920, 1080, 0)])
+                                            ("C3-D0", 1_000_000, 1920, 1080, 0), ("C4-view", 5_000_000, 1297, 840, 3),
+                                            ("C5-view", 2_500_000, 3840, 2160, 3)])
 def test_baseline_configs_bit_exact_vs_oracle(oracle, name, P, W, H, D):
-    """BASELINE configs C2 and the full-size headline C3 (SH degree 3 and 0): every output and every intermediate of
-    the HIP path equals the CPU oracle's to the bit -- not just within the 1e-5 of the north star."""
+    """BASELINE configs C2, the full-size headline C3 (SH degree 3 and 0) and one view of the C4 / C5 sizes (20 M
+    instances, ~3.7 k per tile: the long-list sort; a 4K frame): every output and every intermediate of the HIP path
+    equals the CPU oracle's to the bit -- not just within the 1e-5 of the north star."""
     hs, os_ = _run(oracle, P, W, H, D)
     assert hs["num_binned"] < hs["num_rendered"]          # the tight binning dropped instances, the images did not notice
 
