@@ -148,9 +148,109 @@ int setup(const float* intrinsics, const float* world_to_camera, PostCam& c)
 	return GSR_OK;
 }
 
+// ---- masked bilateral filter of a depth map (gs-extract-pcd: extract_pcd.py:185-238 masked_bilateral_filter, which
+// round-trips through numpy + cv2.dilate + cv2.bilateralFilter on the CPU).  Three small kernels on the stream:
+//   1. new_mask = mask eroded by the d x d window (a pixel stays valid iff every in-image pixel of its window is valid:
+//      1 - cv2.dilate(1 - mask, ones(d, d)), border pixels of the dilation ignored) + min / max of depth over new_mask;
+//   2. bilateral filter (OpenCV's float32 algorithm: radius = max(d/2, 1), circular window r <= radius, BORDER_REFLECT_101,
+//      weights exp(-r^2 / (2 sigma_space^2)) * exp(-dv^2 / (2 sigma_color^2))) of the depth NORMALISED to [0, 1] over the
+//      valid region with everything outside it set to 0 -- the reference filters exactly that image, zeros included --
+//      de-normalised, invalid pixels restored to their input depth.
+// OpenCV evaluates the colour weight through a 4096-bin interpolated table; here it is expf directly (|dw| < 1e-7).
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+	const uint32_t u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // order-preserving float -> uint
+}
+__device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+__global__ __launch_bounds__(256) void bilateral_mask_minmax_kernel(const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                                                                    int W, int H, int d, uint8_t* __restrict__ new_mask,
+                                                                    uint32_t* __restrict__ mm)
+{
+	const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+	uint32_t lo = 0xffffffffu, hi = 0u;
+	if (x < W && y < H) {
+		const int r = d / 2;
+		bool ok = true;
+		for (int j = -r; j <= r; j++)
+			for (int i = -r; i <= r; i++) {
+				const int xx = x + i, yy = y + j;
+				if (xx >= 0 && xx < W && yy >= 0 && yy < H && mask[(size_t)yy * W + xx] == 0) ok = false;
+			}
+		new_mask[(size_t)y * W + x] = ok ? 1 : 0;
+		if (ok) lo = hi = f2ord(depth[(size_t)y * W + x]);
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+		hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+	}
+	if ((threadIdx.x & 63) == 0 && hi != 0u) {
+		atomicMin(&mm[0], lo);
+		atomicMax(&mm[1], hi);
+	}
+}
+
+__global__ __launch_bounds__(256) void bilateral_filter_kernel(const float* __restrict__ depth, const uint8_t* __restrict__ new_mask,
+                                                               int W, int H, int radius, float space_coeff, float color_coeff,
+                                                               const uint32_t* __restrict__ mm, float* __restrict__ out)
+{
+	const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (x >= W || y >= H) return;
+	const size_t p = (size_t)y * W + x;
+	const float d0 = depth[p];
+	if (mm[1] == 0u || !new_mask[p]) { out[p] = d0; return; }   // no valid pixel at all / invalid pixel: unchanged
+	const float vmin = ord2f(mm[0]), vmax = ord2f(mm[1]);
+	const float range = vmax - vmin;
+	auto norm_at = [&](int xx, int yy) -> float {   // the image cv2.bilateralFilter is handed, BORDER_REFLECT_101
+		xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+		yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+		xx = min(max(xx, 0), W - 1); yy = min(max(yy, 0), H - 1);   // (images narrower than the radius)
+		const size_t q = (size_t)yy * W + xx;
+		return new_mask[q] ? (depth[q] - vmin) / range : 0.f;
+	};
+	const float v0 = (d0 - vmin) / range;
+	// cv2: a constant image is copied through (|max - min| < FLT_EPSILON of the NORMALISED image: never for range > 0,
+	// and range == 0 makes the normalisation 0/0 -- the reference then returns NaNs; here the input depth)
+	if (!(range > 0.f)) { out[p] = d0; return; }
+	float sum = 0.f, wsum = 0.f;
+	for (int j = -radius; j <= radius; j++)
+		for (int i = -radius; i <= radius; i++) {
+			const float r2 = (float)(i * i + j * j);
+			if (r2 > (float)(radius * radius)) continue;   // circular window
+			const float v = norm_at(x + i, y + j);
+			const float dv = v - v0;
+			const float w = __expf(r2 * space_coeff) * __expf(dv * dv * color_coeff);
+			sum += v * w;
+			wsum += w;
+		}
+	out[p] = (sum / wsum) * range + vmin;
+}
+
 }  // namespace
 
 extern "C" {
+
+int gsr_masked_bilateral(const float* depth, const unsigned char* mask, int width, int height, int d, float sigma_color,
+                         float sigma_space, float* filtered, unsigned char* new_mask, unsigned int* scratch2, void* stream)
+{
+	if (!depth || !mask || !filtered || !new_mask || !scratch2 || width <= 0 || height <= 0) return GSR_ERR_ARG;
+	if (d != 0 && (d < 1 || (d & 1) == 0)) return GSR_ERR_ARG;   // odd window sizes (cv2's even sizes shift the anchor)
+	hipStream_t s = (hipStream_t)stream;
+	if (sigma_color <= 0.f) sigma_color = 1.f;
+	if (sigma_space <= 0.f) sigma_space = 1.f;
+	int radius = d <= 0 ? (int)lrintf(sigma_space * 1.5f) : d / 2;
+	if (radius < 1) radius = 1;
+	const int dw = d <= 0 ? 2 * radius + 1 : d;   // the dilation window of the reference is d x d
+	const uint32_t init[2] = {0xffffffffu, 0u};
+	if (hipMemcpyAsync(scratch2, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) return GSR_ERR_HIP;
+	const dim3 grid((width + 63) / 64, (height + 3) / 4);
+	hipLaunchKernelGGL(bilateral_mask_minmax_kernel, grid, dim3(256), 0, s, depth, mask, width, height, dw, new_mask, scratch2);
+	hipLaunchKernelGGL(bilateral_filter_kernel, grid, dim3(256), 0, s, depth, new_mask, width, height, radius,
+	                   -0.5f / (sigma_space * sigma_space), -0.5f / (sigma_color * sigma_color), scratch2, filtered);
+	return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
 
 int gsr_depth_to_points(const float* depth, int width, int height, const float* intrinsics,
                         const float* world_to_camera, float* points, void* stream)

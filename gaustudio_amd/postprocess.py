@@ -66,3 +66,25 @@ def depth_to_normals(depth, intrinsics, extrinsics=None, k=3, d_min=1e-3, d_max=
     if rc < 0:
         raise RuntimeError(f"gsr_depth_to_normals failed (rc={rc})")
     return out
+
+
+def masked_bilateral_filter(depth_map, mask, d=3, sigma_color=75, sigma_space=75):
+    """gaustudio/scripts/extract_pcd.py:185-238 masked_bilateral_filter, on the GPU (the reference goes through numpy and
+    cv2 on the CPU): returns (filtered_depth, new_mask), new_mask in `mask`'s dtype.  cv2 is restated from its published
+    float32 algorithm (parity unpinned: the library is not in this image)."""
+    depth = _check(depth_map)
+    H, W = depth.shape
+    if mask.shape != depth.shape:
+        raise ValueError("mask must have the depth map's shape")
+    m8 = (mask != 0).to(device=depth.device, dtype=torch.uint8).contiguous()
+    out = torch.empty_like(depth)
+    new_mask = torch.empty_like(m8)
+    scratch = torch.empty(2, dtype=torch.int32, device=depth.device)
+    L = _C.lib()
+    with torch.cuda.device(depth.device):
+        rc = L.gsr_masked_bilateral(_C._ptr(depth), _C._ptr(m8), ctypes.c_int(W), ctypes.c_int(H), ctypes.c_int(int(d)),
+                                    ctypes.c_float(float(sigma_color)), ctypes.c_float(float(sigma_space)), _C._ptr(out),
+                                    _C._ptr(new_mask), _C._ptr(scratch), _C._stream(depth.device))
+    if rc < 0:
+        raise RuntimeError(f"gsr_masked_bilateral failed (rc={rc}): d must be odd")
+    return out, new_mask.to(mask.dtype)

@@ -257,6 +257,16 @@ int gsr_depth_to_points(const float* depth, int width, int height, const float* 
 int gsr_depth_to_normals(const float* depth, int width, int height, const float* intrinsics, int k, float d_min,
                          float d_max, const float* world_to_camera, float* normals, void* stream);
 
+/* Replaces masked_bilateral_filter (gaustudio/scripts/extract_pcd.py:185-238: numpy + cv2.dilate + cv2.bilateralFilter
+ * on the CPU, between the render and depth2point in gs-extract-pcd).  mask[H,W] u8 (non-zero = valid) -> new_mask[H,W]
+ * u8 (valid iff the whole d x d window is valid), filtered[H,W]: the bilateral filter (OpenCV's float32 definition:
+ * radius max(d/2,1), circular window, reflect-101 border) of the depth normalised over new_mask with everything else
+ * set to 0, de-normalised; pixels outside new_mask keep their input depth.  d odd (or 0 = from sigma_space);
+ * scratch2 = 8 bytes of device memory.  Parity with cv2 is unpinned (the library is not in this image): restated
+ * from its published algorithm, colour weight by expf instead of cv2's 4096-bin interpolated table. */
+int gsr_masked_bilateral(const float* depth, const unsigned char* mask, int width, int height, int d, float sigma_color,
+                         float sigma_space, float* filtered, unsigned char* new_mask, unsigned int* scratch2, void* stream);
+
 /* ---- TSDF fusion + iso-surface extraction: what gs-extract-mesh does with the rendered
  * depth points (gaustudio/scripts/extract_mesh.py:86,115,145 -> vdbfusion.VDBVolume.integrate /
  * .extract_triangle_mesh, a CPU library the reference pip-installs).  Stateless: the volume is caller-owned device

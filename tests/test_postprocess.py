@@ -122,3 +122,47 @@ def test_epilogue_at_block_boundaries_against_numpy_restatement(W, H):
             ia, ib = _mask_eq(n, ref)
             assert np.array_equal(ia, ib), (k, w2c is not None)
             assert np.abs(n - ref)[~ia].max(initial=0.0) < 2e-4, (k, w2c is not None)
+
+
+def test_masked_bilateral_restatement_on_a_hand_checked_case():
+    """extract_pcd.py:185-238 restated (cv2 absent: its dilate / bilateralFilter follow OpenCV's published float32
+    algorithm).  With sigma = 75 on a [0, 1]-normalised image the weights are 1 to within 1e-4, so the filter is the
+    mean over the centre and its 4-neighbours (circular window of radius 1) of the normalised image in which everything
+    outside the eroded mask is 0."""
+    from oracle import post_oracle as po
+    d = np.arange(25, dtype=np.float32).reshape(5, 5) + 10.0
+    m = np.ones((5, 5), np.uint8); m[0, 0] = 0
+    out, nm = po.masked_bilateral_filter(d, m)
+    want = np.ones((5, 5), bool); want[:2, :2] = False          # the 3x3 windows that contain (0, 0)
+    assert np.array_equal(nm, want)
+    assert np.array_equal(out[~nm], d[~nm])                      # invalid pixels keep their depth
+    vmin, vmax = d[want].min(), d[want].max()
+    norm = np.where(want, (d - vmin) / (vmax - vmin), 0.0)
+    # interior pixel (2, 2): neighbours (1,2) (3,2) (2,1) (2,3) all valid
+    mean = (norm[2, 2] + norm[1, 2] + norm[3, 2] + norm[2, 1] + norm[2, 3]) / 5 * (vmax - vmin) + vmin
+    assert abs(out[2, 2] - mean) < 2e-3
+    # pixel (2, 1) has the invalidated (1, 1) as a neighbour: it enters the average as 0, as in the reference
+    mean = (norm[2, 1] + 0.0 + norm[3, 1] + norm[2, 0] + norm[2, 2]) / 5 * (vmax - vmin) + vmin
+    assert abs(out[2, 1] - mean) < 2e-3
+    # border pixel (4, 4): reflect-101 brings (3, 4) and (4, 3) in twice
+    mean = (norm[4, 4] + 2 * norm[3, 4] + 2 * norm[4, 3]) / 5 * (vmax - vmin) + vmin
+    assert abs(out[4, 4] - mean) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,d,sc,ss", [(97, 61, 3, 75.0, 75.0), (640, 360, 5, 0.05, 1.5), (33, 17, 7, 0.2, 3.0), (5, 4, 3, 75.0, 75.0)])
+def test_hip_masked_bilateral_matches_the_restatement(W, H, d, sc, ss):
+    from gaustudio_amd import postprocess as pp
+    from oracle import post_oracle as po
+    rng = np.random.default_rng(W * 7 + d)
+    depth = (2.0 + 3.0 * rng.random((H, W)) + 0.3 * np.sin(np.arange(W) / 5.0)[None, :]).astype(np.float32)
+    mask = rng.random((H, W)) > 0.03
+    ref, ref_mask = po.masked_bilateral_filter(depth, mask, d, sc, ss)
+    got, got_mask = pp.masked_bilateral_filter(torch.from_numpy(depth).cuda(), torch.from_numpy(mask).cuda(), d, sc, ss)
+    assert got_mask.dtype == torch.bool and np.array_equal(got_mask.cpu().numpy(), ref_mask)
+    assert np.abs(got.cpu().numpy() - ref).max() < 2e-5
+    # all-invalid mask and a constant image come back unchanged
+    z, zm = pp.masked_bilateral_filter(torch.from_numpy(depth).cuda(), torch.zeros(H, W, dtype=torch.bool).cuda(), d, sc, ss)
+    assert torch.equal(z.cpu(), torch.from_numpy(depth)) and not zm.any()
+    c, _ = pp.masked_bilateral_filter(torch.full((H, W), 3.5).cuda(), torch.ones(H, W, dtype=torch.bool).cuda(), d, sc, ss)
+    assert torch.equal(c.cpu(), torch.full((H, W), 3.5))
