@@ -124,6 +124,15 @@ def committed_counters(workload):
         t = json.load(open(f))
         if t.get("workload") == workload:
             t["_file"] = os.path.relpath(f, ROOT)
+            # do the committed counters belong to the kernels being run?  (fingerprint written by tools/make_traffic_json.py)
+            import hashlib
+            h = hashlib.sha1()
+            try:
+                for src in ("gsr_kernels_fwd.hip", "gsr_kernels_bwd.hip", "gsr_common.h", "Makefile"):
+                    h.update(open(os.path.join(ROOT, "gaustudio_amd", "csrc", src), "rb").read())
+                t["_matches_kernel_sources"] = t.get("_kernel_sources_sha1") == h.hexdigest()
+            except OSError:
+                t["_matches_kernel_sources"] = None
             return t
     return None
 
@@ -335,6 +344,7 @@ def main():
             roof = {"kernel": "composite_fwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                     "traffic_upper": (counters or {}).get("composite_fwd", {}).get("traffic_upper_bytes"),
+                    "traffic_counters_match_kernel_sources": (counters or {}).get("_matches_kernel_sources"),
                     "algorithmic_bytes": alg_bytes, "avg_ms": round(comp_ms, 4),
                     "algorithmic_bytes_with_reference_R": R_ref * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8),
                     "valu": valu_issue(counters, "composite_fwd", comp_ms),

@@ -50,5 +50,12 @@ for name in ("composite_fwd_quarter_kernel", "composite_bwd_quarter_kernel", "co
                 "traffic_upper_bytes": int((2 * f.get("FETCH_SIZE", 0) + w.get("WRITE_SIZE", 0)) * 1024),
                 "valu_insts": int(s.get("SQ_INSTS_VALU", 0)), "salu_insts": int(s.get("SQ_INSTS_SALU", 0)),
                 "lds_insts": int(s.get("SQ_INSTS_LDS", 0)), "valu_cycles_per_inst_model": 2.7, "kernel": name}
+# fingerprint of the kernel sources these counters were captured with: bench.py reports whether it still matches
+import hashlib, os
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha1()
+for f in ("gsr_kernels_fwd.hip", "gsr_kernels_bwd.hip", "gsr_common.h", "Makefile"):
+    h.update(open(os.path.join(root, "gaustudio_amd", "csrc", f), "rb").read())
+doc["_kernel_sources_sha1"] = h.hexdigest()
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps(doc, indent=1)[:1500])
