@@ -3,20 +3,25 @@
 
 Metric (BASELINE.json): Mpixels/s forward+backward at 1 M Gaussians, 1920x1080 (config C3), per-kernel
 fraction of the HBM roofline, 1 -> 8 GPU scaling.  A "step" = one forward + one backward of the
-operator over one camera per GPU (through GaussianRasterizer / the autograd Function, i.e. the path
-gaustudio/renderers/base.py takes), inputs resident in HBM; for N > 1 each rank renders its own camera
-of the replicated scene and the step ends with ONE RCCL all-reduce of the flat per-Gaussian gradient
-buffer (gaustudio_amd/parallel.py).  value = N * H * W / step_time.
+operator over `--views-per-rank` cameras per GPU (default 1; through GaussianRasterizer / the autograd Function,
+i.e. the path gaustudio/renderers/base.py takes), inputs resident in HBM; for N > 1 each rank renders its own
+cameras of the replicated scene and the step ends with ONE logical gradient exchange (`--exchange dense`: one RCCL
+all-reduce of the flat 236 B/Gaussian buffer; `--exchange factored`, the default at N > 1: all-gather of the per-view
+colour gradients + all-reduce of the 44 B/Gaussian geometry block, gaustudio_amd/parallel.py).
+value = N * V * H * W / step_time.
 
-    python bench.py                                  # N=1, C3
+    python bench.py                                  # N=1, C3: static camera (headline) + rotating-camera block + fast_exp block
+    python bench.py --workload C3-extract            # BASELINE config 3 as worded: depth+normal render (gs-extract-mesh path)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W [--views-per-rank V]
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant north-star kernel (composite_fwd):
 algorithmic bytes R*44 + T*8 + H*W*32 (+ H*W*8 training aux) over its mean duration,
 measured with HIP events on the launch stream during the timed steps.  `cpu_baseline` is the CPU
 oracle (a C restatement of the reference kernels -- the reference itself has no CPU renderer) timed on
-the host cores on a bounded sample of the same frame.
+the host cores on the same full frame.  `rotating`: the same step with a different camera every step (ring of K) and
+an Adam update of all parameters between the steps (excluded from the time, but its 2.8 GB of traffic evicts the
+caches as a training loop's would); `variants`: the opt-in fast_exp mode.
 """
 import argparse
 import json
@@ -57,9 +62,9 @@ def rank_camera(scenes, W, H, rank, world):
     return scenes.make_camera(W, H, R=R)
 
 
-def cpu_baseline(sc, cam, D, grads, budget_s=20.0):
-    """Times the CPU oracle (fwd+bwd) on every `tile_step`-th tile of the same frame; per-Gaussian
-    stages run in full.  tile_step is chosen from a pilot so that the run takes roughly budget_s."""
+def cpu_baseline(sc, cam, D, grads, budget_s=30.0):
+    """Times the CPU oracle (fwd+bwd) on the same FULL frame (every tile; per-Gaussian stages in full).  Only if a pilot
+    on every 32nd tile predicts more than budget_s seconds is the frame sub-sampled (and the line says so)."""
     from oracle import pyoracle as po   # test infrastructure, used here ONLY as the timed CPU baseline
     po.build()
     threads = po.num_threads()
@@ -83,10 +88,10 @@ def cpu_baseline(sc, cam, D, grads, budget_s=20.0):
     T = ((cam.width + 15) // 16) * ((cam.height + 15) // 16)
     tiles = len(range(0, T, step))
     pixels = cam.width * cam.height * tiles / T
+    what = "the same full frame" if step == 1 else f"every {step}th 16x16 tile of the same frame ({tiles}/{T} tiles), per-Gaussian stages in full"
     return {"value": round(pixels / t / 1e6, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "seconds": round(t, 2),
-            "sample": f"CPU restatement of the reference kernels (oracle/gsr_oracle.c, OpenMP x{threads}): fwd+bwd on "
-                      f"every {step}th 16x16 tile of the same frame ({tiles}/{T} tiles), per-Gaussian stages in full"}
+            "seconds": round(t, 2), "full_frame": step == 1,
+            "sample": f"CPU restatement of the reference kernels (oracle/gsr_oracle.c, OpenMP x{threads}): fwd+bwd on {what}"}
 
 
 def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
@@ -203,17 +208,155 @@ def reference_ab(sc, cam, D, grads_cpu, dev, steps=5):
         return f"unavailable: {type(e).__name__}: {e}"
 
 
+def ring_of_cameras(scenes, W, H, K, rank=0, world=1):
+    """K cameras for the rotating mode: yawed by 3 degrees per step around the scene's axis (the same kind of view as
+    rank_camera's, so every step has about the same amount of work), offset per rank."""
+    out = []
+    for k in range(K):
+        a = math.radians(3.0) * (k - (K - 1) / 2.0 + 0.37 * (rank - (world - 1) / 2.0))
+        R = np.array([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+        out.append(scenes.make_camera(W, H, R=R))
+    return out
+
+
+def run_extract(a, dev, scenes, _C):
+    """BASELINE config 3 as BASELINE.json words it: "1M synthetic Gaussians, 1920x1080, depth+normal render (gs-extract-mesh
+    path)".  One step = what gs-extract-mesh does per view (gaustudio/scripts/extract_mesh.py:95-115 with
+    gaustudio/datasets/__init__.py:307-380): no_grad forward -> opacity mask on the median depth -> depth2point (world)
+    + depth2normal -> TSDF integrate, every stage on the GPU; K ring cameras are cycled (each view of a real extraction is
+    integrated once; the first pass over the ring allocates the volume's blocks during warm-up)."""
+    from gaustudio_amd import postprocess as pp
+    from gaustudio_amd.tsdf import TSDFVolume
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    P, W, H, D, desc = WORKLOADS["C3"]
+    cam0 = scenes.make_camera(W, H)
+    sc = scenes.make_scene(P, cam0, seed=0)
+    K = max(1, a.rotate_cameras or 8)
+    cams = ring_of_cameras(scenes, W, H, K)
+    params = {k: getattr(sc, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    m2 = torch.zeros_like(params["means3D"])
+    rss, Ks, Es = [], [], []
+    for c in cams:
+        rss.append(GaussianRasterizationSettings(H, W, c.tanfovx, c.tanfovy, torch.zeros(3, device=dev), 1.0, c.viewmatrix.to(dev),
+                                                 c.projmatrix.to(dev), D, c.campos.to(dev), False, False))
+        f = W / (2 * c.tanfovx)
+        Ks.append(torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]))
+        Es.append(c.viewmatrix.t().contiguous())
+    # the synthetic cloud has no surfaces: its median depth is rough, so a frame touches many more 8^3 blocks than a real
+    # scene's would -- voxels of 4 cm (scene depth 2 .. 20) and 2^22 hash slots (16 GiB of the 288) hold it
+    vol = TSDFVolume(voxel_size=0.04, sdf_trunc=0.16, space_carving=False, device=dev, capacity_blocks=1 << 22)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    stage_names = ("render", "mask", "points", "normals", "compact", "integrate")
+    acc = {k: 0.0 for k in stage_names}
+    marks = []
+
+    def step(i, timed=False):
+        rs, Kc, E, c = rss[i % K], Ks[i % K], Es[i % K], cams[i % K]
+        e = [ev() for _ in range(7)] if timed else None
+        if timed: e[0].record()
+        with torch.no_grad():
+            _, _, _, median, opacity = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=m2, opacities=params["opacities"],
+                                                               shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
+        if timed: e[1].record()
+        invalid = opacity[0] < 0.5                                               # extract_mesh.py:104
+        depth = median[0].masked_fill(invalid, 0.0)                              # :107
+        if timed: e[2].record()
+        pts = pp.depth_to_points(depth, Kc, E, "world")                         # :109 Camera.depth2point(..., 'world')
+        if timed: e[3].record()
+        nrm = pp.depth_to_normals(depth, Kc, E, coordinate="world")             # Camera.depth2normal (gs-extract-pcd / normal maps)
+        if timed: e[4].record()
+        valid_pts = pts[~invalid]                                               # :110
+        if timed: e[5].record()
+        vol.integrate(valid_pts, c.campos)                                      # :115 vdb_volume.integrate
+        if timed:
+            e[6].record()
+            marks.append(e)
+        return nrm, valid_pts.shape[0]
+
+    for i in range(max(a.warmup, K)):                                           # at least one full ring: allocates the blocks
+        step(i)
+    torch.cuda.synchronize()
+    _C.set_profiling(True)
+    t0 = time.perf_counter()
+    n_valid = 0
+    for i in range(a.steps):
+        _, nv = step(i, timed=True)
+        n_valid += nv
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fwd_ms = _C.last_forward_ms()
+    _C.set_profiling(False)
+    for e in marks:
+        for k, (x, y) in zip(stage_names, zip(e[:-1], e[1:])):
+            acc[k] += x.elapsed_time(y)
+    stage_ms = {k: round(v / len(marks), 4) for k, v in acc.items()}
+    status = int(vol.status.item())
+    blocks = int((vol.keys != -1).sum().item())
+    HW = H * W
+    epi = {"points": {"ms": stage_ms["points"], "algorithmic_bytes": HW * 16},
+           "normals": {"ms": stage_ms["normals"], "algorithmic_bytes": HW * 16}}
+    for v in epi.values():
+        v["GB/s"] = round(v["algorithmic_bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+        v["frac_hbm"] = round(v["GB/s"] / 8000.0, 4)
+    # CPU baseline: the reference's own epilogue is torch on the host tensors it is given (datasets/__init__.py:307-380);
+    # timed here as its numpy restatement (oracle/post_oracle.py, pinned to the reference's outputs) on one frame
+    cpu = None
+    if not a.no_cpu_baseline:
+        from oracle import post_oracle as po
+        with torch.no_grad():
+            _, _, _, median, opacity = GaussianRasterizer(rss[0])(means3D=params["means3D"], means2D=m2, opacities=params["opacities"],
+                                                                   shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
+        d = median[0].masked_fill(opacity[0] < 0.5, 0.0).cpu().numpy()
+        Kn, En = Ks[0].numpy(), Es[0].numpy()
+        t1 = time.perf_counter()
+        po.depth2point(d, Kn, En)
+        po.depth2normal(d, Kn, En)
+        tc = time.perf_counter() - t1
+        cpu = {"value": round(HW / tc / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port", "seconds": round(tc, 2),
+               "sample": "numpy restatement (oracle/post_oracle.py, pinned to outputs of the reference's Camera class) of depth2point + "
+                         "depth2normal on one 1920x1080 frame; the render and the TSDF fusion have no CPU path in the reference "
+                         "(GPU rasterizer; vdbfusion is an un-vendored C++ dependency)"}
+    comp_ms = (fwd_ms or {}).get("composite")
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    line = {"metric": "Mpixels/s depth+normal render + TSDF integrate @1M Gaussians 1920x1080 (gs-extract-mesh path)",
+            "value": round(HW * a.steps / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, K),
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3-extract: 1M synthetic Gaussians, 1920x1080, SH degree 3, no_grad render -> median-depth mask -> "
+                                   "depth2point + depth2normal -> TSDF integrate (BASELINE config 3, gs-extract-mesh path)",
+                       "gaussians": P, "width": W, "height": H, "sh_degree": D, "cameras_cycled": K,
+                       "valid_points_per_frame": n_valid // max(1, a.steps), "tsdf": {"voxel_size": 0.04, "sdf_trunc": 0.16,
+                       "hash_slots": vol.capacity, "occupied_blocks": blocks, "status": status}},
+            "stage_ms": {"pipeline": stage_ms, "forward": fwd_ms},
+            "roofline": None if not comp_ms else {
+                "kernel": "composite_fwd", "bound": "hbm", "peak": 8000.0, "unit": "GB/s", "avg_ms": round(comp_ms, 4),
+                "note": "instances per frame vary with the camera: see the C3 line for the byte model; the epilogue kernels "
+                        "(HBM-bound streams) are in epilogue_roofline", "achieved": None, "frac": None, "traffic": None},
+            "epilogue_roofline": epi, "cpu_baseline": cpu}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS) + ["C3-extract"])
     ap.add_argument("--fwd-only", action="store_true", help="time the no_grad forward only (inference paths)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-ab", action="store_true", help="skip timing the hipified reference kernels (optional A/B)")
     ap.add_argument("--overlap-chunks", type=int, default=4,
-                    help="N > 1: SH-gradient ranges reduced from inside the backward (0/1 = one all-reduce after it)")
+                    help="N > 1, --exchange dense: SH-gradient ranges reduced from inside the backward (0/1 = one all-reduce after it)")
+    ap.add_argument("--exchange", default="factored", choices=["dense", "factored"],
+                    help="N > 1: dense = ONE all-reduce of the flat 236 B/Gaussian gradient buffer; factored = all-gather of the "
+                         "per-view colour gradients (12 B/Gaussian/view) + all-reduce of the 44 B/Gaussian geometry block, the SH "
+                         "gradient rebuilt locally (gaustudio_amd/parallel.py)")
+    ap.add_argument("--views-per-rank", type=int, default=1, help="cameras rendered (and accumulated) per rank and step")
+    ap.add_argument("--rotate-cameras", type=int, default=None,
+                    help="K: cycle a ring of K cameras (a different one every step) and apply an Adam update of every parameter "
+                         "between the steps; default: the headline is the static camera and a K=8 block is reported beside it")
+    ap.add_argument("--fast-exp", action="store_true", help="run the whole benchmark in the opt-in fast_exp mode")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rotating-camera and fast_exp blocks of the default line")
     ap.add_argument("--traffic", type=float, default=None,
                     help="measured HBM bytes per composite_fwd launch from a rocprofv3 --pmc pass; default: the "
                          "committed measurement in profiles/r*_traffic.json for this workload, else null")
@@ -240,56 +383,84 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    import gaustudio_amd
     from gaustudio_amd import _C, parallel, runtime, scenes
     from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
     # one-time process initialisation (not a benchmark step): load the gfx950 code objects with a 512-Gaussian
     # call and reserve an allocator pool, as a long-running trainer / server would at start-up
     runtime.warm_start(dev)
+    if a.workload == "C3-extract":
+        if world != 1:
+            raise SystemExit("C3-extract is a single-GPU workload")
+        return run_extract(a, dev, scenes, _C)
 
     P, W, H, D, desc = WORKLOADS[a.workload]
+    V = max(1, a.views_per_rank)
     cam0 = scenes.make_camera(W, H)
     sc = scenes.make_scene(P, cam0, seed=0)                 # identical on every rank (replicated parameters)
-    cam = rank_camera(scenes, W, H, rank, world)
+    # this rank's V cameras of the world * V views of a step (view v of rank r = global view r * V + v)
+    all_cams = [rank_camera(scenes, W, H, g, world * V) for g in range(world * V)]
+    cams = all_cams[rank * V:(rank + 1) * V]
+    cam = cams[0]
     grads_cpu = scenes.make_output_grads(cam, seed=1)
 
     params = {k: getattr(sc, k).to(dev).requires_grad_(not a.fwd_only)
               for k in ("means3D", "shs", "opacities", "scales", "rotations")}
     means2D = torch.zeros_like(params["means3D"], requires_grad=not a.fwd_only)
     grads = [g.to(dev) for g in grads_cpu]
-    rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=dev), 1.0,
-                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), D, cam.campos.to(dev),
-                                       False, False)
-    rasterizer = GaussianRasterizer(rs)
+
+    def settings(c):
+        return GaussianRasterizationSettings(H, W, c.tanfovx, c.tanfovy, torch.zeros(3, device=dev), 1.0,
+                                             c.viewmatrix.to(dev), c.projmatrix.to(dev), D, c.campos.to(dev), False, False)
+    rs_list = [settings(c) for c in cams]
+    rs = rs_list[0]
+    rasterizers = [GaussianRasterizer(r) for r in rs_list]
+    factored = world > 1 and a.exchange == "factored" and not a.fwd_only
     bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()), roles=params)
+    fx = None
+    if factored:
+        fx = parallel.FactoredGradExchange(params, views_per_rank=V, sh_degree=D)
+        campos_all = torch.stack([c.campos for c in all_cams]).to(dev)
     state = {}
+    comm_ev = []       # (backward enqueued, exchange finished) events of the timed steps, N > 1 only
+    mode = gaustudio_amd.options(fast_exp=True) if a.fast_exp else gaustudio_amd.options()
 
-    comm_ev = []       # (backward enqueued, reduction finished) events of the timed steps, N > 1 only
+    def render(i, rasterizer):
+        out = rasterizer(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], shs=params["shs"],
+                         scales=params["scales"], rotations=params["rotations"])
+        return out
 
-    def step(timed=False):
+    def step(timed=False, rasts=None):
+        rasts = rasterizers if rasts is None else rasts
         if a.fwd_only:
             with torch.no_grad():
-                out = rasterizer(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
-                                 shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
-            state["out"] = out
+                for r in rasts:
+                    state["out"] = render(0, r)
             return
         for p in params.values():
             p.grad = None
         means2D.grad = None
-        if world > 1:
-            # gradients are born in the flat all-reduce buffer; the SH ranges are reduced while the backward runs
-            bucket.arm(a.overlap_chunks)
-        color, radii, depth, median, opac = rasterizer(
-            means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], shs=params["shs"],
-            scales=params["scales"], rotations=params["rotations"])
-        torch.autograd.backward([color, depth, median, opac], grads)
+        for v, r in enumerate(rasts):
+            last = v == len(rasts) - 1
+            if factored:
+                fx.arm(v)                                   # colour gradients of view v go to their all-gather slot
+            elif world > 1 and len(rasts) == 1:
+                # gradients are born in the flat all-reduce buffer; the SH ranges are reduced while the backward runs
+                bucket.arm(a.overlap_chunks)
+            color, radii, depth, median, opac = render(v, r)
+            torch.autograd.backward([color, depth, median, opac], grads)
+            if last:
+                state["out"] = (color, radii, depth, median, opac)
         if world > 1 and timed:
             e0 = torch.cuda.Event(enable_timing=True); e0.record()
-        parallel.allreduce_gaussian_grads(bucket)          # the tail of the one logical reduction (no-op at N=1)
+        if factored:
+            fx.exchange(campos_all)
+        else:
+            parallel.allreduce_gaussian_grads(bucket)      # the tail of the one logical reduction (no-op at N=1)
         if world > 1 and timed:
             e1 = torch.cuda.Event(enable_timing=True); e1.record()
             comm_ev.append((e0, e1))
-        state["out"] = (color, radii, depth, median, opac)
 
     def barrier():
         torch.cuda.synchronize()
@@ -297,22 +468,83 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    _C.set_profiling(True)                                   # HIP events on the launch stream, no host syncs
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(timed=True)
-    barrier()
-    dt = time.perf_counter() - t0
-    fwd_ms = _C.last_forward_ms()
-    bwd_ms = _C.last_backward_ms()
-    _C.set_profiling(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def timed_run(fn, steps, warmup):
+        for _ in range(warmup):
+            fn(False)
+        barrier()
+        _C.set_profiling(True)                               # HIP events on the launch stream, no host syncs
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(True)
+        barrier()
+        dt = time.perf_counter() - t0
+        f, b = _C.last_forward_ms(), _C.last_backward_ms()
+        _C.set_profiling(False)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), f, b
+
+    rotating_headline = a.rotate_cameras is not None and a.rotate_cameras > 0
+
+    # ---- rotating mode: K cameras cycled, Adam update of every parameter between the steps ----
+    def make_rotating(K):
+        ring = ring_of_cameras(scenes, W, H, K, rank, world)
+        rrs = [GaussianRasterizer(settings(c)) for c in ring]
+        opt = None if a.fwd_only else torch.optim.Adam(list(params.values()), lr=1e-7, foreach=True)
+        opt_ev = []
+        it = {"i": 0}
+
+        def fn(timed):
+            i = it["i"]; it["i"] += 1
+            step(timed, [rrs[(i * V + v) % K] for v in range(V)])
+            if opt is not None:
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                opt.step()                                   # params + 2 moments + gradients: 16 x 59 floats per Gaussian of traffic
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    opt_ev.append((e0, e1))
+        return fn, opt_ev
+
+    with mode:
+        if rotating_headline:
+            rot_fn, opt_ev = make_rotating(a.rotate_cameras)
+            dt, fwd_ms, bwd_ms = timed_run(rot_fn, a.steps, a.warmup)
+            torch.cuda.synchronize()
+            opt_ms = sum(x.elapsed_time(y) for x, y in opt_ev) / max(1, len(opt_ev)) if opt_ev else 0.0
+            dt -= opt_ms * 1e-3 * a.steps                    # the optimizer is not part of the metric; its traffic is the point
+        else:
+            dt, fwd_ms, bwd_ms = timed_run(lambda timed: step(timed), a.steps, a.warmup)
+            opt_ms = None
+
+    extras = {}
+    if world == 1 and not a.no_extras and not rotating_headline and a.workload in ("C3", "C3D0") and not a.fast_exp:
+        # beside the static-camera headline: (1) the rotating / optimizer-contended step, (2) the opt-in fast_exp mode
+        K = 8
+        rot_fn, opt_ev = make_rotating(K)
+        rdt, rf, rb = timed_run(rot_fn, 24, 8)
+        torch.cuda.synchronize()
+        ro = sum(x.elapsed_time(y) for x, y in opt_ev) / max(1, len(opt_ev)) if opt_ev else 0.0
+        rstep = rdt / 24 * 1e3 - ro
+        extras["rotating"] = {"cameras": K, "steps": 24, "ms_per_step": round(rstep, 4), "optimizer_ms_excluded": round(ro, 4),
+                              "value": round(V * H * W / (rstep * 1e-3) / 1e6, 3), "unit": "Mpixels/s",
+                              "stage_ms": {"forward": rf, "backward": rb},
+                              "note": "a different camera every step (ring of 8, 3 degrees apart) and an Adam update of all "
+                                      "59 floats per Gaussian between the steps (timed with events and subtracted): nothing of "
+                                      "the previous step survives in the Infinity Cache, the binning capacity is speculated "
+                                      "from another view's count"}
+        if not a.fwd_only:
+            for p in params.values():
+                p.grad = None
+        with gaustudio_amd.options(fast_exp=True):
+            fdt, ff, fb = timed_run(lambda timed: step(timed), 24, 8)
+        extras["variants"] = {"fast_exp": {"steps": 24, "ms_per_step": round(fdt / 24 * 1e3, 4),
+                                           "value": round(V * H * W / (fdt / 24) / 1e6, 3), "unit": "Mpixels/s",
+                                           "stage_ms": {"forward": ff, "backward": fb},
+                                           "note": "opt-in (gaustudio_amd.options(fast_exp=True) / gsr_options.fast_exp): v_exp_f32 in both "
+                                                   "compositing kernels; not bit-reproducible against the CPU oracle, parity evidence in "
+                                                   "tests/test_gpu_fastexp.py + profiles/r03_fastexp_parity.json"}}
 
     # instance counts of this rank's view (they drive every composite-stage byte count): the reference-defined
     # num_rendered and the instances actually binned; per-tile list lengths
@@ -325,13 +557,13 @@ def main():
         R = counts["num_binned"]
         _, ranges = _C.inspect_binning(out[7], out[8], R, W, H)
         lists = list_histogram(ranges)
-        vis = int((state["out"][1] > 0).sum().item())
+        vis = int((out[5] > 0).sum().item())
         del out
 
     if rank == 0:
         T = ((W + 15) // 16) * ((H + 15) // 16)
         ms_per_step = dt / a.steps * 1e3
-        value = world * H * W / (dt / a.steps) / 1e6
+        value = world * V * H * W / (dt / a.steps) / 1e6
         comp_ms = fwd_ms["composite"] if fwd_ms else None
         alg_bytes = R * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8)
         counters = committed_counters(a.workload)
@@ -345,14 +577,23 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                     "traffic_upper": (counters or {}).get("composite_fwd", {}).get("traffic_upper_bytes"),
                     "traffic_counters_match_kernel_sources": (counters or {}).get("_matches_kernel_sources"),
+                    "traffic_by_mode": (counters or {}).get("by_mode"),
                     "algorithmic_bytes": alg_bytes, "avg_ms": round(comp_ms, 4),
                     "algorithmic_bytes_with_reference_R": R_ref * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8),
                     "valu": valu_issue(counters, "composite_fwd", comp_ms),
                     "note": "algorithmic bytes use the instances actually staged (tight binning); `traffic` = FETCH_SIZE + "
-                            "WRITE_SIZE of the committed PMC passes with the access-pattern calibration of "
-                            "profiles/r02_fetch_write_calibration.txt (`traffic_upper` = 2*FETCH + WRITE); the kernel is "
-                            "VALU-issue bound (256 pixel evaluations per staged 48-B record): `valu.issue_frac` is the "
-                            "fraction of the SIMDs' issue cycles its VALU instructions fill, see DESIGN.md s4"}
+                            "WRITE_SIZE of the committed PMC passes (a PMC pass cannot run inside this process) with the "
+                            "access-pattern calibration of profiles/r02_fetch_write_calibration.txt (`traffic_upper` = 2*FETCH + "
+                            "WRITE); the kernel is VALU-issue bound (256 pixel evaluations per staged 48-B record): `valu.issue_frac` "
+                            "is the fraction of the SIMDs' issue cycles its VALU instructions fill, see DESIGN.md s4"}
+        if world > 1:
+            par = (f"{V} camera(s) per GPU x{world}, one logical gradient exchange per step: " +
+                   (f"all-gather of {fx.color_bytes_per_rank} B/rank of colour gradients + all-reduce of {fx.geometry_bytes} B of "
+                    f"geometry gradients (SH gradient rebuilt locally)" if factored else
+                    f"1 RCCL all-reduce of {bucket.nbytes} B/rank ({a.overlap_chunks if a.overlap_chunks > 1 and V == 1 else 1} chunk(s) "
+                    f"overlapped with the backward)"))
+        else:
+            par = "single GPU"
         line = {
             "metric": "Mpixels/s fwd+bwd @1M Gaussians 1920x1080" if a.workload == "C3" and not a.fwd_only
                       else f"Mpixels/s {'fwd' if a.fwd_only else 'fwd+bwd'} @{a.workload}",
@@ -361,28 +602,36 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "gaussians": P, "visible": vis, "width": W, "height": H, "sh_degree": D,
                        "num_rendered": R_ref, "instances_binned": R, "tiles": T, "tile_list_length": lists,
-                       "views_per_step": world,
-                       "parallelism": f"one camera per GPU x{world}, 1 logical RCCL all-reduce of "
-                                      f"{0 if bucket is None else bucket.nbytes} B/rank "
-                                      f"({a.overlap_chunks if a.overlap_chunks > 1 else 1} chunk(s) overlapped with the backward)"
-                                      if world > 1 else "single GPU"},
+                       "views_per_step": world * V, "views_per_rank": V,
+                       "camera": (f"ring of {a.rotate_cameras}, a different one every step, Adam update between the steps "
+                                  f"({round(opt_ms, 4)} ms, excluded)") if rotating_headline else "static (the same view every step)",
+                       "mode": "fast_exp" if a.fast_exp else "bit-exact (default)",
+                       "parallelism": par},
             "stage_ms": {"forward": fwd_ms, "backward": bwd_ms},
             "stage_roofline": stage_roofline(P, vis, R, T, H, W, D, fwd_ms, bwd_ms, a.fwd_only),
             "roofline": roof,
         }
+        line.update(extras)
         if bwd_ms:
             line["valu_composite_bwd"] = valu_issue(counters, "composite_bwd", bwd_ms.get("composite_bwd"))
         if world > 1 and comm_ev:
             torch.cuda.synchronize()
             exposed = sum(e0.elapsed_time(e1) for e0, e1 in comm_ev) / len(comm_ev)
             comp_total = sum(v for k, v in (fwd_ms or {}).items() if k != "calls") + sum(v for k, v in (bwd_ms or {}).items() if k != "calls")
-            line["comm"] = {"payload_bytes_per_rank": bucket.nbytes, "chunks_per_step": bucket.stats["chunks"] / max(1, a.steps + a.warmup),
-                            "chunk_bytes_per_step": bucket.stats["chunk_bytes"] / max(1, a.steps + a.warmup),
-                            "tail_bytes_per_step": bucket.stats["tail_bytes"] / max(1, a.steps + a.warmup),
-                            "compute_ms": round(comp_total, 4), "comm_exposed_ms": round(exposed, 4),
-                            "note": "compute_ms = sum of the operator's kernel stages (HIP events); comm_exposed_ms = time from the "
-                                    "end of the backward's enqueue to the end of the reduction on rank 0's stream (what the "
-                                    "collective adds to the step after overlap)"}
+            n_it = max(1, a.steps + a.warmup)
+            comm = {"exchange": "factored" if factored else "dense",
+                    "compute_ms": round(comp_total * V, 4), "comm_exposed_ms": round(exposed, 4),
+                    "note": "compute_ms = sum of the operator's kernel stages (HIP events) x views per rank; comm_exposed_ms = time "
+                            "from the end of the last backward's enqueue to the end of the exchange on rank 0's stream (what the "
+                            "collectives add to the step after overlap)"}
+            if factored:
+                comm.update(fx.payload())
+            else:
+                comm.update({"payload_bytes_per_rank": bucket.nbytes, "dense_payload_bytes_per_rank": bucket.nbytes,
+                             "chunks_per_step": bucket.stats["chunks"] / n_it,
+                             "chunk_bytes_per_step": bucket.stats["chunk_bytes"] / n_it,
+                             "tail_bytes_per_step": bucket.stats["tail_bytes"] / n_it})
+            line["comm"] = comm
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sc, cam, D, grads_cpu)
         else:

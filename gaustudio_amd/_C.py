@@ -36,7 +36,7 @@ def lib():
         L.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
         L.gsr_backward_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.gsr_abi_version.restype = ctypes.c_int
-        if L.gsr_abi_version() != 5:
+        if L.gsr_abi_version() != 6:
             raise ImportError("libgsrast.so ABI version mismatch")
         _lib = L
     return _lib
@@ -79,26 +79,37 @@ def native():
     return _native
 
 
+def _opts(options):
+    """Per-call options (gaustudio_amd/options.py): an explicit tuple, or what the calling thread's `with options(...)`
+    blocks say."""
+    if options is None:
+        from .options import current
+        options = current()
+    return [int(v) for v in options]
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                        campos, prefiltered, debug):
-    """RasterizeGaussiansCUDA, rasterize_points.cu:35-121 -> csrc/torch_binding.cpp RasterizeGaussians."""
+                        campos, prefiltered, debug, options=None):
+    """RasterizeGaussiansCUDA, rasterize_points.cu:35-121 -> csrc/torch_binding.cpp RasterizeGaussians.
+    `options` (trailing, optional, not in the reference): the per-call options tuple of gaustudio_amd/options.py."""
     return native().rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier),
                                         cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
                                         int(image_height), int(image_width), sh, int(degree), campos,
-                                        bool(prefiltered), bool(debug))
+                                        bool(prefiltered), bool(debug), _opts(options))
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
-                                 binningBuffer, imageBuffer, debug):
+                                 binningBuffer, imageBuffer, debug, options=None):
     """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:123-210 -> torch_binding.cpp RasterizeGaussiansBackward."""
     return native().rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations,
                                                  float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix,
                                                  float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth,
                                                  dL_dout_median_depth, dL_dout_final_opacity, sh, int(degree), campos,
-                                                 geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug))
+                                                 geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug),
+                                                 _opts(options))
 
 
 def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None):

@@ -6,5 +6,6 @@ from .rasterizer import (  # noqa: F401
     _RasterizeGaussians,
     rasterize_gaussians,
 )
+from .options import options  # noqa: F401,E402  (per-call options: tile band, fast_exp, kernel A/B switches)
 
 __version__ = "0.1.0"

@@ -136,6 +136,32 @@ std::atomic<int> g_opt_fwd_variant{env_int("GSR_FWD_VARIANT", 0)}; // 0: per-qua
 std::atomic<int> g_opt_bwd_variant{env_int("GSR_BWD_VARIANT", -1)};   // -1: from gsr_selftest; bit 0: select on T
 std::atomic<int> g_opt_speculative{env_int("GSR_SPECULATIVE", 1)}; // launch binning + compositing before R is known
 std::atomic<int> g_opt_band_lo{0}, g_opt_band_hi{0};               // tile rows [lo, hi) this process renders (hi <= 0: all)
+std::atomic<int> g_opt_fast_exp{env_int("GSR_FAST_EXP", 0)};       // exp on the transcendental unit in both compositing kernels
+
+// options of ONE call: the caller's gsr_options where given (>= 0), the process defaults elsewhere
+struct Resolved {
+	int tight, cull, fwd_variant, bwd_variant, speculative, band_lo, band_hi, fast_exp;
+};
+Resolved resolve_options(const gsr_options* o)
+{
+	gsr_options v;
+	gsr_options_init(&v);
+	if (o) {
+		const size_t n = o->struct_bytes > 0 ? (size_t)o->struct_bytes : 0;
+		memcpy(&v, o, n < sizeof(v) ? n : sizeof(v));
+	}
+	Resolved r;
+	r.tight = v.tight_binning >= 0 ? v.tight_binning : g_opt_tight.load();
+	r.cull = v.cull >= 0 ? v.cull : g_opt_cull.load();
+	r.fwd_variant = v.fwd_variant >= 0 ? v.fwd_variant : g_opt_fwd_variant.load();
+	r.bwd_variant = v.bwd_variant >= 0 ? v.bwd_variant : g_opt_bwd_variant.load();
+	r.speculative = v.speculative >= 0 ? v.speculative : g_opt_speculative.load();
+	if (v.tile_row_lo >= 0) { r.band_lo = v.tile_row_lo; r.band_hi = v.tile_row_hi; }
+	else { r.band_lo = g_opt_band_lo.load(); r.band_hi = g_opt_band_hi.load(); }
+	r.fast_exp = v.fast_exp >= 0 ? v.fast_exp : g_opt_fast_exp.load();
+	return r;
+}
+
 // per device: capacity (instances) the binning buffer is allocated with while R is still in flight, and whether
 // the last frame had a tile list long enough for the radix path (which needs the second key buffer)
 struct DevState {
@@ -158,16 +184,22 @@ struct StageArgs {
 	const float* dptr[4];   // device source or nullptr
 	float host[4][16];      // host values when dptr[i] == nullptr
 	int n[4];
+	uint32_t* word_dst;     // optional: one 32-bit word stored by the same launch (the forward's options word)
+	uint32_t word;
 };
 __global__ void stage_cam_kernel(StageArgs a, float* dst0, float* dst1, float* dst2, float* dst3)
 {
 	float* dst[4] = {dst0, dst1, dst2, dst3};
 	const int which = threadIdx.x >> 4, i = threadIdx.x & 15;
 	if (dst[which] != nullptr && i < a.n[which]) dst[which][i] = a.dptr[which] ? a.dptr[which][i] : a.host[which][i];
+	if (threadIdx.x == 0 && a.word_dst != nullptr) *a.word_dst = a.word;
 }
-hipError_t stage_small(const float* const src[4], float* const dst[4], const int n[4], hipStream_t s)
+hipError_t stage_small(const float* const src[4], float* const dst[4], const int n[4], hipStream_t s,
+                       uint32_t* word_dst = nullptr, uint32_t word = 0)
 {
 	StageArgs a;
+	a.word_dst = word_dst;
+	a.word = word;
 	for (int k = 0; k < 4; k++) {
 		a.n[k] = (dst[k] != nullptr) ? n[k] : 0;
 		a.dptr[k] = nullptr;
@@ -266,7 +298,16 @@ __global__ __launch_bounds__(256) void inspect_image_kernel(int gx, int W, int H
 
 extern "C" {
 
-int gsr_abi_version(void) { return 5; }
+int gsr_abi_version(void) { return 6; }
+
+void gsr_options_init(gsr_options* opt)
+{
+	if (!opt) return;
+	opt->struct_bytes = (int32_t)sizeof(gsr_options);
+	opt->tight_binning = opt->cull = opt->fwd_variant = opt->bwd_variant = opt->speculative = -1;
+	opt->tile_row_lo = opt->tile_row_hi = -1;
+	opt->fast_exp = -1;
+}
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
@@ -311,7 +352,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 	return GSR_OK;
 }
 
-static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
+static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
                         gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
                         int width, int height, const float* means3D, const float* shs, const float* shs_rest,
                         const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
@@ -344,6 +385,9 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	if (!geometry_alloc || !binning_alloc || !image_alloc)
 		return fail(GSR_ERR_ARG, "gsr_forward: NULL allocator", __FILE__, __LINE__);
 
+	const Resolved ro = resolve_options(opt);
+	if (ro.fast_exp && ro.fwd_variant == 1)
+		return fail(GSR_ERR_ARG, "gsr_forward: fast_exp needs the per-quarter compositing kernels (fwd_variant 0)", __FILE__, __LINE__);
 	const GeomLayout gl((size_t)P);
 	const ImgLayout il(width, height);
 	if (il.gx > 65535 || il.gy > 65535) return fail(GSR_ERR_ARG, "gsr_forward: image too large", __FILE__, __LINE__);
@@ -364,14 +408,18 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	uint32_t* med_pos = reinterpret_cast<uint32_t*>(img + il.med_pos);
 
 	Timer tm(prof_next(g_fwd_log), s);
-	// camera block + control words + tile counters
+	// control words + tile counters, then the camera block and the options this call runs with (one tiny launch)
+	HIP_TRY(hipMemsetAsync(img + il.ctl, 0, il.final_T - il.ctl, s));   // ctl + ranges + tile_count
 	{
 		const float* const src[4] = {viewmatrix, projmatrix, cam_pos, background};
 		float* const dst[4] = {cam->view, cam->proj, cam->campos, cam->bg};
 		const int n[4] = {16, 16, 3, 3};
-		HIP_TRY(stage_small(src, dst, n, s));
+		const bool banded = ro.band_hi > 0 || ro.band_lo > 0;
+		const uint32_t word = (ro.fast_exp ? GSR_CTL_OPT_FAST_EXP : 0u) | (ro.tight ? GSR_CTL_OPT_TIGHT : 0u) |
+		                      (ro.cull ? GSR_CTL_OPT_CULL : 0u) | (ro.fwd_variant == 1 ? GSR_CTL_OPT_WAVE_LISTS : 0u) |
+		                      (banded ? GSR_CTL_OPT_BAND : 0u);
+		HIP_TRY(stage_small(src, dst, n, s, &ctl->opts, word));
 	}
-	HIP_TRY(hipMemsetAsync(img + il.ctl, 0, il.final_T - il.ctl, s));   // ctl + ranges + tile_count
 
 	FwdArgs a;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
@@ -379,9 +427,9 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
 	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.prefiltered = prefiltered;
 	a.shs_rest = shs_rest; a.act = activation_flags;
-	a.tight = g_opt_tight.load() != 0;
-	a.band_lo = g_opt_band_lo.load();
-	a.band_hi = g_opt_band_hi.load();
+	a.tight = ro.tight != 0;
+	a.band_lo = ro.band_lo > 0 ? ro.band_lo : 0;
+	a.band_hi = ro.band_hi;
 
 	tm.mark();
 	uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + gl.tiles_touched);
@@ -413,8 +461,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 	tm.mark();
 
 	DevState& ds = dev_state();
-	const bool nocull = g_opt_cull.load() == 0;
-	const bool wave_lists = g_opt_fwd_variant.load() == 1;
+	const bool nocull = ro.cull == 0;
+	const bool wave_lists = ro.fwd_variant == 1;
 	auto launch_rest = [&](uint32_t cap, bool with_long) -> int {
 		const BinLayout bl((size_t)cap, with_long);
 		char* bin = binning_alloc(binning_ctx, bl.total);
@@ -436,7 +484,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 		}
 		tm.mark();
 		launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
-		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap, with_long ? 0xffffffffu : GSR_SORT_LDS_MAX, nocull, wave_lists, s);
+		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap, with_long ? 0xffffffffu : GSR_SORT_LDS_MAX, nocull, wave_lists, ro.fast_exp != 0, s);
 		STAGE_CHECK("composite_fwd", debug, s);
 		tm.mark();
 		return 0;
@@ -444,7 +492,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_all
 
 	const uint32_t cap0 = ds.cap.load();
 	const bool long0 = ds.long_lists.load() != 0;
-	const bool speculate = !debug && g_opt_speculative.load() != 0 && cap0 > 0;
+	const bool speculate = !debug && ro.speculative != 0 && cap0 > 0;
 	if (speculate) {
 		const int rc = launch_rest(cap0, long0);
 		if (rc < 0) return rc;
@@ -479,7 +527,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
                 float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth,
                 float* out_median_depth, float* out_opacity, int* radii, int debug, void* stream)
 {
-	return forward_impl(geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
+	return forward_impl(nullptr, geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
 	                    background, width, height, means3D, shs, nullptr, colors_precomp, opacities, scales,
 	                    scale_modifier, rotations, cov3D_precomp, 0, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
 	                    prefiltered, out_color, out_depth, out_median_depth, out_opacity, radii, debug, stream);
@@ -495,11 +543,26 @@ int gsr_forward_raw(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_f
 {
 	if (P > 0 && (!f_dc || (M > 1 && !f_rest) || !raw_scales || !raw_rotations))
 		return fail(GSR_ERR_ARG, "gsr_forward_raw: f_dc, f_rest, raw_scales and raw_rotations are required", __FILE__, __LINE__);
-	return forward_impl(geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
+	return forward_impl(nullptr, geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
 	                    background, width, height, means3D, f_dc, M > 1 ? f_rest : nullptr, nullptr, raw_opacities,
 	                    raw_scales, scale_modifier, raw_rotations, nullptr, activation_flags, viewmatrix, projmatrix, cam_pos,
 	                    tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_median_depth, out_opacity, radii, debug,
 	                    stream);
+}
+
+int gsr_forward_ex(const gsr_options* opt, gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc,
+                   void* binning_ctx, gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                   const float* background, int width, int height, const float* means3D, const float* shs,
+                   const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
+                   float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
+                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                   int prefiltered, float* out_color, float* out_depth, float* out_median_depth, float* out_opacity,
+                   int* radii, int debug, void* stream)
+{
+	return forward_impl(opt, geometry_alloc, geometry_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M,
+	                    background, width, height, means3D, shs, shs_rest, colors_precomp, opacities, scales, scale_modifier,
+	                    rotations, cov3D_precomp, activation_flags, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+	                    prefiltered, out_color, out_depth, out_median_depth, out_opacity, radii, debug, stream);
 }
 
 size_t gsr_geometry_bytes(int P) { return GeomLayout((size_t)(P > 0 ? P : 0)).total; }
@@ -511,9 +574,8 @@ size_t gsr_backward_scratch_bytes(int P, int R)
 }
 
 // composite_bwd variant: bit 0 = keep a select on T (devices where v_rcp_f32(1.0) != 1.0)
-static int bwd_variant(hipStream_t s)
+static int bwd_variant(int opt, hipStream_t s)
 {
-	const int opt = g_opt_bwd_variant.load();
 	if (opt >= 0) return opt;
 	DevState& ds = dev_state();
 	int st = ds.selftest.load();
@@ -525,7 +587,7 @@ static int bwd_variant(hipStream_t s)
 	return (st & 3) == 3 ? 0 : 1;
 }
 
-static int backward_impl(int parts, int sh_g0, int sh_g1, int P, int D, int M, int R, const float* background, int width, int height,
+static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1, int P, int D, int M, int R, const float* background, int width, int height,
                          const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
                          const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                          int activation_flags, float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
@@ -600,9 +662,23 @@ static int backward_impl(int parts, int sh_g0, int sh_g1, int P, int D, int M, i
 
 	tm.mark();
 	if (R > 0) {
+		const Resolved ro = resolve_options(opt);
+		if (debug) {
+			// the forward recorded what it ran with: a backward in another exp mode would take other alpha >= 1/255 decisions
+			GsCtl c;
+			HIP_TRY(hipMemcpyAsync(&c, image_buffer + il.ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if (((c.opts & GSR_CTL_OPT_FAST_EXP) != 0u) != (ro.fast_exp != 0))
+				return fail(GSR_ERR_ARG, "gsr_backward: fast_exp differs from the forward that produced these buffers", __FILE__, __LINE__);
+		}
+		int variant = bwd_variant(ro.bwd_variant, s);
+		if (ro.fast_exp) {
+			if (variant & 2) return fail(GSR_ERR_ARG, "gsr_backward: fast_exp needs the per-quarter kernel (bwd_variant bit 1 clear)", __FILE__, __LINE__);
+			variant |= 8;   // bit 3: the forward used the hardware exp -- the backward takes the same decisions with it
+		}
 		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix,
 		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags,
-		                     reinterpret_cast<const GsCtl*>(image_buffer + il.ctl), bwd_variant(s), s);
+		                     reinterpret_cast<const GsCtl*>(image_buffer + il.ctl), variant, s);
 		STAGE_CHECK("composite_bwd", debug, s);
 	}
 	tm.mark();
@@ -625,7 +701,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                  char* scratch, int debug, void* stream)
 {
 	(void)viewmatrix; (void)projmatrix; (void)campos;   // the device copies made by gsr_forward are used
-	return backward_impl(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P, P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp, scales,
+	return backward_impl(nullptr, GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P, P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp, scales,
 	                     scale_modifier, rotations, cov3D_precomp, 0, tan_fovx, tan_fovy, radii, geom_buffer,
 	                     binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
 	                     dL_dpix_final_opacity, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
@@ -645,11 +721,32 @@ int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int
 		return fail(GSR_ERR_ARG, "gsr_backward_parts: nothing to do", __FILE__, __LINE__);
 	if ((parts & GSR_BWD_PART_SH) && sh_g0 % 256 != 0)
 		return fail(GSR_ERR_ARG, "gsr_backward_parts: sh_g0 must be a multiple of 256", __FILE__, __LINE__);
-	return backward_impl(parts, sh_g0, sh_g1, P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp,
+	return backward_impl(nullptr, parts, sh_g0, sh_g1, P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp,
 	                     scales, scale_modifier, rotations, cov3D_precomp, 0, tan_fovx, tan_fovy, radii, geom_buffer,
 	                     binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
 	                     dL_dpix_final_opacity, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
 	                     nullptr, dL_dscale, dL_drot, scratch, debug, stream);
+}
+
+int gsr_backward_ex(const gsr_options* opt, int parts, int sh_g0, int sh_g1, int P, int D, int M, int R,
+                    const float* background, int width, int height, const float* means3D, const float* shs,
+                    const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
+                    const float* rotations, const float* cov3D_precomp, int activation_flags, float tan_fovx,
+                    float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
+                    const char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth,
+                    const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D,
+                    float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                    float* dL_dsh_rest, float* dL_dscale, float* dL_drot, char* scratch, int debug, void* stream)
+{
+	if (!(parts & (GSR_BWD_PART_MAIN | GSR_BWD_PART_SH)))
+		return fail(GSR_ERR_ARG, "gsr_backward_ex: nothing to do", __FILE__, __LINE__);
+	if ((parts & GSR_BWD_PART_SH) && sh_g0 % 256 != 0)
+		return fail(GSR_ERR_ARG, "gsr_backward_ex: sh_g0 must be a multiple of 256", __FILE__, __LINE__);
+	return backward_impl(opt, parts, sh_g0, sh_g1, P, D, M, R, background, width, height, means3D, shs, shs_rest,
+	                     colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, activation_flags, tan_fovx, tan_fovy,
+	                     radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
+	                     dL_dpix_final_opacity, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest,
+	                     dL_dscale, dL_drot, scratch, debug, stream);
 }
 
 int gsr_set_option(const char* name, int value)
@@ -662,6 +759,7 @@ int gsr_set_option(const char* name, int value)
 	else if (n == "fwd_variant") g_opt_fwd_variant.store(value);
 	else if (n == "bwd_variant") g_opt_bwd_variant.store(value);
 	else if (n == "speculative") g_opt_speculative.store(value);
+	else if (n == "fast_exp") g_opt_fast_exp.store(value != 0);
 	else if (n == "tile_row_lo") g_opt_band_lo.store(value > 0 ? value : 0);
 	else if (n == "tile_row_hi") g_opt_band_hi.store(value);
 	else if (n == "bin_capacity") {   // capacity assumed for the NEXT forward on the current device (tests: force the re-launch path)
@@ -681,6 +779,7 @@ int gsr_get_option(const char* name)
 	if (n == "fwd_variant") return g_opt_fwd_variant.load();
 	if (n == "bwd_variant") return g_opt_bwd_variant.load();
 	if (n == "speculative") return g_opt_speculative.load();
+	if (n == "fast_exp") return g_opt_fast_exp.load();
 	if (n == "tile_row_lo") return g_opt_band_lo.load();
 	if (n == "tile_row_hi") return g_opt_band_hi.load();
 	if (n == "bin_capacity") return (int)dev_state().cap.load();
@@ -731,7 +830,7 @@ int gsr_backward_raw(int P, int D, int M, int R, const float* background, int wi
 {
 	if (P > 0 && (!f_dc || (M > 1 && (!f_rest || !dL_df_rest)) || !dL_df_dc))
 		return fail(GSR_ERR_ARG, "gsr_backward_raw: f_dc / f_rest and their gradient outputs are required", __FILE__, __LINE__);
-	return backward_impl(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P, P, D, M, R, background, width, height, means3D, f_dc, M > 1 ? f_rest : nullptr, nullptr, raw_scales,
+	return backward_impl(nullptr, GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P, P, D, M, R, background, width, height, means3D, f_dc, M > 1 ? f_rest : nullptr, nullptr, raw_scales,
 	                     scale_modifier, raw_rotations, nullptr, activation_flags, tan_fovx, tan_fovy, radii, geom_buffer,
 	                     binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
 	                     dL_dpix_final_opacity, dL_dmean2D, dL_draw_opacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_df_dc,

@@ -48,8 +48,15 @@ struct GsCtl {
 	uint32_t err_overflow;   // the reference-defined count does not fit the reference's int num_rendered
 	uint32_t ref_rendered;   // the reference's num_rendered: sum of getRect areas (rasterizer_impl.cu:280-284)
 	uint32_t has_qmask;      // composite_fwd left one 16-bit block mask per list entry behind the list (see gs_qmask_ptr)
-	uint32_t pad[2];
+	uint32_t opts;           // options the forward ran with (GSR_CTL_OPT_*): the backward of this image buffer must agree
+	uint32_t pad[1];
 };
+
+#define GSR_CTL_OPT_FAST_EXP 1u     // compositing used gs_exp_hw: the backward must take its decisions with it as well
+#define GSR_CTL_OPT_TIGHT 2u
+#define GSR_CTL_OPT_CULL 4u
+#define GSR_CTL_OPT_WAVE_LISTS 8u
+#define GSR_CTL_OPT_BAND 16u
 
 // Per-instance block masks of the forward (bit 4*row + col: which 4x4 pixel blocks of the tile the instance can touch,
 // gs_quarter_mask<4>), kept for the backward: u16 per list entry, in the binning buffer right behind the list's
@@ -78,6 +85,12 @@ __device__ __forceinline__ float gs_exp(float p)
 	y = FMA(y, f, 0x1.000002p+0f);
 	return __int_as_float(__float_as_int(y) + (__float_as_int(tm) << 23));
 }
+
+// exp(p) on the transcendental unit: v_mul_f32 + v_exp_f32 (2 VALU instead of 9).  1 ulp of 2^x plus the rounding of
+// p * log2(e): within 1e-6 relative of gs_exp for p in [-6, 0], the range in which the alpha >= 1/255 decision is taken.
+// NOT reproducible on a CPU: used only in the opt-in `fast_exp` mode of both compositing kernels and,
+// with an exact-decision fallback (FX = 2 in composite_bwd), in the backward of a bit-exact forward.
+__device__ __forceinline__ float gs_exp_hw(float p) { return __builtin_amdgcn_exp2f(p * 0x1.715476p+0f); }
 
 // Reproducible natural logarithm (positive normal x): x = m * 2^e, m in [1, 2), ln x = e ln2 + 2 atanh((m-1)/(m+1))
 // with the series cut after s^9 (|error| < 1.5e-6 + rounding).  Only IEEE +,*,/,fma: the CPU oracle evaluates the

@@ -117,8 +117,7 @@ void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* range
                       uint32_t* point_list, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl,
-                          uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, hipStream_t s);
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp, hipStream_t s);
 
 // --- launchers (gsr_kernels_bwd.hip) ---
 struct BwdArgs {

@@ -458,7 +458,12 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 #define GSR_BWQ_SENT GSR_BWQ_BATCH         // batch index of the sentinel record (opacity 0)
 #define GSR_BWQ_QSTRIDE 66   // float2 per quarter in the slab: 4 steps x 16 pixels + 2 pad (16-B aligned, banks shifted)
 
-template <bool FLAGS, bool TSEL>
+// FX: exp on the transcendental unit (gs_exp_hw), after a forward that ran in fast_exp mode: same instruction, same
+// bits, same alpha >= 1/255 decisions as that forward.  (Measured at C3: 0.5108 -> 0.5084 ms -- nine VALU instructions
+// fewer per step buy nothing here, the kernel is bound by latency, not by issue; a third mode -- hardware exp after a
+// BIT-EXACT forward, with a re-evaluation by gs_exp wherever opacity * G came within 4e-6 of 1/255 so that the decisions
+// stayed the forward's -- was built, passed the summation-bound tests and measured 0.5346 ms: removed.)
+template <bool FLAGS, bool TSEL, bool FX>
 __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_quarter_kernel(
     int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
@@ -679,9 +684,19 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			const int pos = top - 1 - (int)j;   // == `contributor` after decrement (backward.cu:520)
 			const float dx = A.x - pixfx, dy = A.y - pixfy;
 			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
-			const float G = gs_exp(power);
-			const float a0 = B.y * G;
-			const bool live = (pos < lc) & (power <= 0.0f) & (power >= B.w) & (!(a0 < 1.0f / 255.0f));
+			float G, a0;
+			bool live;
+			if (!FX) {
+				G = gs_exp(power);
+				a0 = B.y * G;
+				live = (pos < lc) & (power <= 0.0f) & (power >= B.w) & (!(a0 < 1.0f / 255.0f));
+			} else {
+				// gs_exp_hw is valid for every power <= 0, and power < pcut implies opacity * exp(power) < (1/255) exp(-1e-3):
+				// the forward's pcut pre-test is implied by the alpha test
+				G = gs_exp_hw(power);
+				a0 = B.y * G;
+				live = (pos < lc) & (power <= 0.0f) & (!(a0 < 1.0f / 255.0f));
+			}
 			// a dead pixel (and the sentinel of an exhausted quarter) is carried through with G masked to 0: alpha = 0,
 			// 1/(1-alpha) = 1 (gsr_selftest), w = 0, q = 0, S <- fma(0, ., S)
 			const float Gm = live ? G : 0.f;
@@ -833,18 +848,22 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
 {
 	const int chunk = (il.T + 7) / 8;
 	const bool tsel = (variant & 1) != 0, wave_lists = (variant & 2) != 0;
-#define GSR_LAUNCH_CB(K, FL, TS)                                                                                   \
-	hipLaunchKernelGGL((K<FL, TS>), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H,        \
-	                   bg, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix, dL_dpix_depth, dL_dpix_median,      \
+	const bool fx = (variant & 8) != 0;   // the forward ran in fast_exp mode (per-quarter kernels only)
+	const bool flags = row_flags != nullptr;
+#define GSR_LAUNCH_CB(...)                                                                                         \
+	hipLaunchKernelGGL((__VA_ARGS__), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg,  \
+	                   ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix, dL_dpix_depth, dL_dpix_median, \
 	                   dL_dpix_opacity, rows, row_flags, ctl)
-#define GSR_LAUNCH_CB2(K)                                                                                          \
-	if (row_flags != nullptr) {                                                                                    \
-		if (tsel) GSR_LAUNCH_CB(K, true, true); else GSR_LAUNCH_CB(K, true, false);                                \
-	} else {                                                                                                       \
-		if (tsel) GSR_LAUNCH_CB(K, false, true); else GSR_LAUNCH_CB(K, false, false);                              \
+	if (wave_lists) {
+		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_kernel<true, true>); else GSR_LAUNCH_CB(composite_bwd_kernel<true, false>); }
+		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_kernel<false, true>); else GSR_LAUNCH_CB(composite_bwd_kernel<false, false>); }
+	} else if (fx) {
+		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, true, true>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, true>); }
+		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, true, true>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, true>); }
+	} else {
+		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, true, false>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, false>); }
+		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, true, false>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, false>); }
 	}
-	if (wave_lists) { GSR_LAUNCH_CB2(composite_bwd_kernel) } else { GSR_LAUNCH_CB2(composite_bwd_quarter_kernel) }
-#undef GSR_LAUNCH_CB2
 #undef GSR_LAUNCH_CB
 }
 

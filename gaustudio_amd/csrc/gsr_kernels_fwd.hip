@@ -1011,6 +1011,7 @@ void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* range
 		                   GSR_SORT_LDS_MAX, ctl, cap);
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // composite_fwd: 256 threads = 4 wave64; wave w owns one 8x8 pixel block of the tile (gs_pixel_of_thread).
 // Instances are staged 256 at a time through LDS as three float4 planes.  Each wave then culls the
@@ -1172,7 +1173,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 #define GSR_FWD_LIST 264                       // list entries per quarter (u16 byte offsets): 256 + two groups of sentinels
 #define GSR_FWD_NONE 0xffffu
 
-template <bool NOCULL>
+// FX: exp on the transcendental unit (gs_exp_hw) instead of the reproducible 9-instruction gs_exp -- the opt-in
+// `fast_exp` mode: outputs then agree with the bit-exact mode to ~1e-6 relative except at threshold
+// flips (tests/test_gpu_fastexp.py attributes every one of them), and the backward must run in the same mode.
+template <bool NOCULL, bool FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void composite_fwd_quarter_kernel(
     int T, int chunk, int gx, int W, int H, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
@@ -1188,6 +1192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 	// the block masks computed below stay behind for composite_bwd (gs_qmask_ptr)
 	uint16_t* __restrict__ qmask = gs_qmask_ptr(point_list, num_binned);
 	if (!NOCULL && blockIdx.x == 0 && threadIdx.x == 0) ctl->has_qmask = 1u;
+	if (FX && blockIdx.x == 0 && threadIdx.x == 0) ctl->opts |= GSR_CTL_OPT_FAST_EXP;
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
@@ -1281,7 +1286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 				const float4 Cc = *reinterpret_cast<const float4*>(rec_base + off + 2 * GSR_FWD_PLANE * 16);
 				const float dx = A.x - pixfx, dy = A.y - pixfy;
 				const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
-				const float alpha = fminf(0.99f, B.y * gs_exp(power));
+				const float alpha = fminf(0.99f, B.y * (FX ? gs_exp_hw(power) : gs_exp(power)));
 				const bool valid = (!done) & (power <= 0.0f) & (power >= (NOCULL ? -80.0f : B.w)) & (!(alpha < 1.0f / 255.0f));
 				const float test_T = T_ * (1 - alpha);
 				const bool stop = valid & (test_T < 0.0001f);
@@ -1312,7 +1317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 			const float4 A = rr->q0, B = rr->q1;
 			const float dx = A.x - pixfx, dy = A.y - pixfy;
 			const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
-			const float alpha = fminf(0.99f, B.y * gs_exp(power));
+			const float alpha = fminf(0.99f, B.y * (FX ? gs_exp_hw(power) : gs_exp(power)));
 			if (med_T * (1 - alpha) < 0.5f) {
 				median_D = B.z;
 				median_weight = alpha * med_T;
@@ -1336,8 +1341,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl_,
-                          uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, hipStream_t s)
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos,
+                          GsCtl* ctl_, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
 #define GSR_LAUNCH_FWD(K)                                                                                              \
@@ -1349,8 +1354,13 @@ void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges
 		else GSR_LAUNCH_FWD(composite_fwd_kernel<false>);
 	} else {
 		GsCtl* ctl = ctl_;
-		if (nocull) GSR_LAUNCH_FWD(composite_fwd_quarter_kernel<true>);
-		else GSR_LAUNCH_FWD(composite_fwd_quarter_kernel<false>);
+		if (fast_exp) {
+			if (nocull) GSR_LAUNCH_FWD((composite_fwd_quarter_kernel<true, true>));
+			else GSR_LAUNCH_FWD((composite_fwd_quarter_kernel<false, true>));
+		} else {
+			if (nocull) GSR_LAUNCH_FWD((composite_fwd_quarter_kernel<true, false>));
+			else GSR_LAUNCH_FWD((composite_fwd_quarter_kernel<false, false>));
+		}
 	}
 #undef GSR_LAUNCH_FWD
 }

@@ -51,6 +51,19 @@ void require_device(const torch::Tensor& t, const char* name)
 	throw std::runtime_error(std::string(gsr_last_error()) + " [gsrast rc=" + std::to_string(rc) + "]");
 }
 
+// per-call options (include/gsrast.h gsr_options) as Python hands them over: [tight_binning, cull, fwd_variant,
+// bwd_variant, speculative, tile_row_lo, tile_row_hi, fast_exp], -1 = process default; a shorter (or empty) list
+// leaves the remaining fields at their defaults
+gsr_options make_options(const std::vector<int>& v)
+{
+	gsr_options o;
+	gsr_options_init(&o);
+	int32_t* f[8] = {&o.tight_binning, &o.cull, &o.fwd_variant, &o.bwd_variant, &o.speculative, &o.tile_row_lo, &o.tile_row_hi,
+	                 &o.fast_exp};
+	for (size_t i = 0; i < v.size() && i < 8; i++) *f[i] = v[i];
+	return o;
+}
+
 void* current_stream(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 // One-shot output arena for the NEXT backward of ONE specific graph (gaustudio_amd/parallel.py): five caller-owned
@@ -119,7 +132,7 @@ RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D
                    const float scale_modifier, const torch::Tensor& cov3D_precomp_, const torch::Tensor& viewmatrix_,
                    const torch::Tensor& projmatrix_, const float tan_fovx, const float tan_fovy, const int image_height,
                    const int image_width, const torch::Tensor& sh_, const int degree, const torch::Tensor& campos_,
-                   const bool prefiltered, const bool debug)
+                   const bool prefiltered, const bool debug, const std::vector<int>& options)
 {
 	if (means3D_.ndimension() != 2 || means3D_.size(1) != 3) {
 		AT_ERROR("means3D must have dimensions (num_points, 3)");   // rasterize_points.cu:57-59
@@ -165,10 +178,11 @@ RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D
 	torch::Tensor geom = torch::empty({0}, bo), binning = torch::empty({0}, bo), img = torch::empty({0}, bo);
 	const int M = (sh.numel() != 0 && sh.size(0) != 0) ? (int)sh.size(1) : 0;   // rasterize_points.cu:86-90
 
-	const int rc = gsr_forward(resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, degree, M, fptr(bg, "bg"), W, H,
-	                           fptr(means3D, "means3D"), fptr(sh, "sh"), fptr(colors, "colors_precomp"),
+	const gsr_options opt = make_options(options);
+	const int rc = gsr_forward_ex(&opt, resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, degree, M, fptr(bg, "bg"), W, H,
+	                           fptr(means3D, "means3D"), fptr(sh, "sh"), nullptr, fptr(colors, "colors_precomp"),
 	                           fptr(opacity, "opacities"), fptr(scales, "scales"), scale_modifier,
-	                           fptr(rotations, "rotations"), fptr(cov3D_precomp, "cov3D_precomp"),
+	                           fptr(rotations, "rotations"), fptr(cov3D_precomp, "cov3D_precomp"), 0,
 	                           fptr(viewmatrix, "viewmatrix"), fptr(projmatrix, "projmatrix"), fptr(campos, "campos"),
 	                           tan_fovx, tan_fovy, prefiltered ? 1 : 0, out_color.data_ptr<float>(),
 	                           out_depth.data_ptr<float>(), out_median.data_ptr<float>(), out_opacity.data_ptr<float>(),
@@ -187,10 +201,11 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
                            const torch::Tensor& dL_dout_median_depth, const torch::Tensor& dL_dout_final_opacity,
                            const torch::Tensor& sh_, const int degree, const torch::Tensor& campos_,
                            const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer,
-                           const torch::Tensor& imageBuffer, const bool debug)
+                           const torch::Tensor& imageBuffer, const bool debug, const std::vector<int>& options)
 {
 	require_device(means3D_, "means3D");
 	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
+	const gsr_options opt = make_options(options);
 	const int P = means3D_.size(0);
 	const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);
 	const auto means3D = means3D_.contiguous(), colors = colors_.contiguous(), scales = scales_.contiguous();
@@ -243,15 +258,15 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 		const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
 		torch::Tensor scratch = torch::empty({(long long)gsr_backward_scratch_bytes(P, R)}, bo);
 		auto run = [&](int parts, int g0, int g1) {
-			const int rc = gsr_backward_parts(
-			    parts, g0, g1, P, degree, M, R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(sh, "sh"),
+			const int rc = gsr_backward_ex(
+			    &opt, parts, g0, g1, P, degree, M, R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(sh, "sh"), nullptr,
 			    fptr(colors, "colors_precomp"), fptr(scales, "scales"), scale_modifier, fptr(rotations, "rotations"),
-			    fptr(cov3D_precomp, "cov3D_precomp"), tan_fovx, tan_fovy, radii.data_ptr<int>(),
+			    fptr(cov3D_precomp, "cov3D_precomp"), 0, tan_fovx, tan_fovy, radii.data_ptr<int>(),
 			    reinterpret_cast<const char*>(geomBuffer.data_ptr()), reinterpret_cast<const char*>(binningBuffer.data_ptr()),
 			    reinterpret_cast<const char*>(imageBuffer.data_ptr()), fptr(g_color, "dL_dout_color"),
 			    fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"), fptr(g_op, "dL_dout_final_opacity"),
 			    dL_dmeans2D.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
-			    dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr,
+			    dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr, nullptr,
 			    dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(), reinterpret_cast<char*>(scratch.data_ptr()),
 			    debug ? 1 : 0, current_stream(means3D));
 			if (rc < 0) fail(rc);
@@ -297,7 +312,7 @@ RasterizeGaussiansRaw(const torch::Tensor& background, const torch::Tensor& mean
                       const torch::Tensor& raw_rotations_, const float scale_modifier, const int activation_flags,
                       const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, const float tan_fovx,
                       const float tan_fovy, const int image_height, const int image_width, const int degree,
-                      const torch::Tensor& campos_, const bool prefiltered, const bool debug)
+                      const torch::Tensor& campos_, const bool prefiltered, const bool debug, const std::vector<int>& options)
 {
 	if (means3D_.ndimension() != 2 || means3D_.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
 	require_device(means3D_, "means3D");
@@ -320,10 +335,12 @@ RasterizeGaussiansRaw(const torch::Tensor& background, const torch::Tensor& mean
 	torch::Tensor radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
 	const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
 	torch::Tensor geom = torch::empty({0}, bo), binning = torch::empty({0}, bo), img = torch::empty({0}, bo);
-	const int rc = gsr_forward_raw(resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, degree, M, fptr(bg, "bg"), W, H,
-	                               fptr(means3D, "means3D"), fptr(f_dc, "f_dc"), fptr(f_rest, "f_rest"),
+	TORCH_CHECK(P == 0 || M == 1 || f_rest.numel() != 0, "f_rest is required when M > 1");
+	const gsr_options opt = make_options(options);
+	const int rc = gsr_forward_ex(&opt, resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, degree, M, fptr(bg, "bg"), W, H,
+	                               fptr(means3D, "means3D"), fptr(f_dc, "f_dc"), M > 1 ? fptr(f_rest, "f_rest") : nullptr, nullptr,
 	                               fptr(opacity, "opacity"), fptr(scales, "scales"), scale_modifier,
-	                               fptr(rotations, "rotations"), activation_flags, fptr(viewmatrix, "viewmatrix"),
+	                               fptr(rotations, "rotations"), nullptr, activation_flags, fptr(viewmatrix, "viewmatrix"),
 	                               fptr(projmatrix, "projmatrix"), fptr(campos, "campos"), tan_fovx, tan_fovy,
 	                               prefiltered ? 1 : 0, out_color.data_ptr<float>(), out_depth.data_ptr<float>(),
 	                               out_median.data_ptr<float>(), out_opacity.data_ptr<float>(),
@@ -341,7 +358,7 @@ RasterizeGaussiansRawBackward(const torch::Tensor& background, const torch::Tens
                               const torch::Tensor& dL_dout_depth, const torch::Tensor& dL_dout_median_depth,
                               const torch::Tensor& dL_dout_final_opacity, const int degree,
                               const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer,
-                              const torch::Tensor& imageBuffer, const bool debug)
+                              const torch::Tensor& imageBuffer, const bool debug, const std::vector<int>& options)
 {
 	require_device(means3D_, "means3D");
 	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
@@ -362,9 +379,11 @@ RasterizeGaussiansRawBackward(const torch::Tensor& background, const torch::Tens
 	if (P != 0) {
 		const auto bo = torch::TensorOptions(torch::kByte).device(means3D.device());
 		torch::Tensor scratch = torch::empty({(long long)gsr_backward_scratch_bytes(P, R)}, bo);
-		const int rc = gsr_backward_raw(
-		    P, degree, M, R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(f_dc, "f_dc"), fptr(f_rest, "f_rest"),
-		    fptr(scales, "scales"), scale_modifier, fptr(rotations, "rotations"), activation_flags, tan_fovx, tan_fovy,
+		const gsr_options opt = make_options(options);
+		const int rc = gsr_backward_ex(
+		    &opt, GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P, P, degree, M, R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"),
+		    fptr(f_dc, "f_dc"), M > 1 ? fptr(f_rest, "f_rest") : nullptr, nullptr,
+		    fptr(scales, "scales"), scale_modifier, fptr(rotations, "rotations"), nullptr, activation_flags, tan_fovx, tan_fovy,
 		    radii.data_ptr<int>(), reinterpret_cast<const char*>(geomBuffer.data_ptr()),
 		    reinterpret_cast<const char*>(binningBuffer.data_ptr()), reinterpret_cast<const char*>(imageBuffer.data_ptr()),
 		    fptr(g_color, "dL_dout_color"), fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"),
@@ -380,11 +399,31 @@ RasterizeGaussiansRawBackward(const torch::Tensor& background, const torch::Tens
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
-	m.def("rasterize_gaussians", &RasterizeGaussians);
-	m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward);
+	// the reference's positional signatures, plus one optional trailing argument: the per-call options (gsr_options)
+	const std::vector<int> no_opts;
+	m.def("rasterize_gaussians", &RasterizeGaussians, py::arg("background"), py::arg("means3D"), py::arg("colors"),
+	      py::arg("opacity"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"),
+	      py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"), py::arg("image_height"),
+	      py::arg("image_width"), py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("prefiltered"), py::arg("debug"),
+	      py::arg("options") = no_opts);
+	m.def("rasterize_gaussians_backward", &RasterizeGaussiansBackward, py::arg("background"), py::arg("means3D"),
+	      py::arg("radii"), py::arg("colors"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"),
+	      py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"),
+	      py::arg("dL_dout_color"), py::arg("dL_dout_depth"), py::arg("dL_dout_median_depth"), py::arg("dL_dout_final_opacity"),
+	      py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"), py::arg("R"), py::arg("binningBuffer"),
+	      py::arg("imageBuffer"), py::arg("debug"), py::arg("options") = no_opts);
 	m.def("mark_visible", &markVisible);
 	m.def("set_grad_arena", &set_grad_arena, py::arg("outs"), py::arg("keys") = std::vector<int64_t>(), py::arg("sh_chunks") = 1,
 	      py::arg("hook") = py::none());
-	m.def("rasterize_gaussians_raw", &RasterizeGaussiansRaw);
-	m.def("rasterize_gaussians_raw_backward", &RasterizeGaussiansRawBackward);
+	m.def("rasterize_gaussians_raw", &RasterizeGaussiansRaw, py::arg("background"), py::arg("means3D"), py::arg("f_dc"),
+	      py::arg("f_rest"), py::arg("raw_opacity"), py::arg("raw_scales"), py::arg("raw_rotations"), py::arg("scale_modifier"),
+	      py::arg("activation_flags"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"),
+	      py::arg("image_height"), py::arg("image_width"), py::arg("degree"), py::arg("campos"), py::arg("prefiltered"),
+	      py::arg("debug"), py::arg("options") = no_opts);
+	m.def("rasterize_gaussians_raw_backward", &RasterizeGaussiansRawBackward, py::arg("background"), py::arg("means3D"),
+	      py::arg("radii"), py::arg("f_dc"), py::arg("f_rest"), py::arg("raw_scales"), py::arg("raw_rotations"),
+	      py::arg("scale_modifier"), py::arg("activation_flags"), py::arg("tan_fovx"), py::arg("tan_fovy"),
+	      py::arg("dL_dout_color"), py::arg("dL_dout_depth"), py::arg("dL_dout_median_depth"), py::arg("dL_dout_final_opacity"),
+	      py::arg("degree"), py::arg("geomBuffer"), py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"),
+	      py::arg("debug"), py::arg("options") = no_opts);
 }

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from .options import current as _current_options
 from .rasterizer import _run_guarded
 
 ACT_OPACITY_SIGMOID = 1
@@ -32,13 +33,14 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     def forward(ctx, means3D, means2D, f_dc, f_rest, raw_opacities, raw_scales, raw_rotations, raster_settings, act):
         rs = raster_settings
         n = _C.native()
+        opts = [int(v) for v in _current_options()]       # per-call options, kept with the graph (options.py)
         call = (rs.bg, means3D, f_dc, f_rest, raw_opacities, raw_scales, raw_rotations, float(rs.scale_modifier), int(act),
                 rs.viewmatrix, rs.projmatrix, float(rs.tanfovx), float(rs.tanfovy), int(rs.image_height),
-                int(rs.image_width), int(rs.sh_degree), rs.campos, bool(rs.prefiltered), bool(rs.debug))
+                int(rs.image_width), int(rs.sh_degree), rs.campos, bool(rs.prefiltered), bool(rs.debug), opts)
         (num_rendered, color, depth, median, opacity, radii, geom, binning, img) = _run_guarded(
             n.rasterize_gaussians_raw, call, rs.debug, "snapshot_fw.dump",
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
-        ctx.raster_settings, ctx.num_rendered, ctx.act = rs, num_rendered, int(act)
+        ctx.raster_settings, ctx.num_rendered, ctx.act, ctx.gsr_options = rs, num_rendered, int(act), opts
         ctx.save_for_backward(means3D, f_dc, f_rest, raw_scales, raw_rotations, radii, geom, binning, img)
         return color, radii, depth, median, opacity
 
@@ -49,7 +51,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         n = _C.native()
         call = (rs.bg, means3D, radii, f_dc, f_rest, raw_scales, raw_rotations, float(rs.scale_modifier), ctx.act,
                 float(rs.tanfovx), float(rs.tanfovy), g_color, g_depth, g_median, g_opacity, int(rs.sh_degree), geom,
-                int(ctx.num_rendered), binning, img, bool(rs.debug))
+                int(ctx.num_rendered), binning, img, bool(rs.debug), ctx.gsr_options)
         (g_means2D, g_op, g_means3D, g_fdc, g_frest, g_scales, g_rot) = _run_guarded(
             n.rasterize_gaussians_raw_backward, call, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")

@@ -242,28 +242,25 @@ def tile_row_band(height: int, rank: Optional[int] = None, world_size: Optional[
 
 
 class tile_band:
-    """Context manager: inside it the rasterizer of THIS process bins, composites and differentiates only the tile rows
-    [lo, hi) of every view (libgsrast option "tile_row_lo" / "tile_row_hi").  Preprocessing stays replicated (every
-    rank projects every Gaussian: 0.06 ms per million), there is no exchange in the forward; pixels outside the band
-    come back as an empty scene's, and the per-Gaussian gradients are the band's partial sums -- the same flat
-    all-reduce as for view sharding (allreduce_gaussian_grads) completes them.  A loss must only use the band's rows
-    (band_rows())."""
+    """Context manager: inside it the rasterizer calls of THIS THREAD bin, composite and differentiate only the tile rows
+    [lo, hi) of every view (per-call option `tile_row_lo` / `tile_row_hi`, gaustudio_amd/options.py -- nothing
+    process-wide is changed, so two bands can be rendered concurrently from two threads of one process, and the backward
+    of a call keeps the band of its forward).  Preprocessing stays replicated (every rank projects every Gaussian: 0.06 ms
+    per million), there is no exchange in the forward; pixels outside the band come back as an empty scene's, and the
+    per-Gaussian gradients are the band's partial sums -- the same flat all-reduce as for view sharding
+    (allreduce_gaussian_grads) completes them.  A loss must only use the band's rows (band_rows())."""
 
     def __init__(self, lo: int, hi: int):
         self.lo, self.hi = int(lo), int(hi)
+        from .options import options
+        self._ctx = options(tile_band=(self.lo, self.hi))
 
     def band_rows(self, height: int):
         return slice(min(height, 16 * self.lo), min(height, 16 * self.hi))
 
     def __enter__(self):
-        from . import _C
-        self._old = (_C.get_option("tile_row_lo"), _C.get_option("tile_row_hi"))
-        _C.set_option("tile_row_lo", self.lo)
-        _C.set_option("tile_row_hi", self.hi if self.hi > 0 else -1)
+        self._ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
-        from . import _C
-        _C.set_option("tile_row_lo", self._old[0])
-        _C.set_option("tile_row_hi", self._old[1])
-        return False
+        return self._ctx.__exit__(*exc)

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from .options import current as _current_options
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -52,15 +53,19 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
         rs = raster_settings
-        # argument order of _C.rasterize_gaussians (rasterize_points.h:18-38)
+        # per-call options of the calling thread (gaustudio_amd/options.py; all -1 = process defaults unless a
+        # `with options(...)` block is active): they stay with the graph, the backward below runs with the same ones
+        opts = _current_options()
+        # argument order of _C.rasterize_gaussians (rasterize_points.h:18-38), then the options
         call = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, opts)
         (num_rendered, color, depth, median_depth, final_opacity, radii, geom_buf, binning_buf,
          img_buf) = _run_guarded(
             _C.rasterize_gaussians, call, rs.debug, "snapshot_fw.dump",
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
+        ctx.gsr_options = opts
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf,
                               binning_buf, img_buf)
@@ -75,7 +80,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         call = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth,
                 grad_median_depth, grad_final_opacity, sh, rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered,
-                binning_buf, img_buf, rs.debug)
+                binning_buf, img_buf, rs.debug, ctx.gsr_options)
         (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations) = _run_guarded(
             _C.rasterize_gaussians_backward, call, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")

@@ -173,6 +173,7 @@ int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int
  *   "speculative"   1|0  enqueue binning + compositing before the host has read the instance count (default 1);
  *   "bwd_variant"   -1 = auto (gsr_selftest), bit 0 = keep the select on T in composite_bwd, bit 1 = the per-wave
  *                        (8x8) kernel instead of the per-quarter one;
+ *   "fast_exp"      0|1  process default of gsr_options.fast_exp (below);
  *   "bin_capacity"  n    binning capacity (instances) assumed by the next gsr_forward on the current device
  *                        (0 = forget; tests use a small n to force the re-allocate-and-relaunch path);
  *   "tile_row_lo", "tile_row_hi"  tile-grid sharding of ONE view across processes: only the 16-pixel
@@ -181,6 +182,49 @@ int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int
  *                        radii and num_rendered keep describing the whole view.  hi <= 0: the whole image. */
 int gsr_set_option(const char* name, int value);
 int gsr_get_option(const char* name);
+
+/* ---- per-call options (ABI v6).  The process-wide switches above change the behaviour of every caller in the
+ * process; two configurations in one process (two tile bands from two threads, a bit-exact evaluation pass next to a
+ * fast_exp training loop) need them per call.  Every field: -1 = take the process default (gsr_set_option /
+ * environment).  gsr_forward_ex / gsr_backward_ex are the supersets of the plain and the raw entry points (an absent
+ * input is NULL: `shs_rest` NULL = `shs` holds all M coefficients; activation_flags 0 = activated inputs) with the
+ * options in front; opt == NULL = all defaults, and gsr_forward(...) == gsr_forward_ex(NULL, ...).
+ * The backward of a forward must be given the same `fast_exp` (the adapters keep the options of the forward with the
+ * graph; the forward also records what it ran with in the image buffer, and a debug-mode backward checks it).
+ *   fast_exp  0|1   exp on the transcendental unit (v_exp_f32) in both compositing kernels instead of the reproducible
+ *                   9-instruction polynomial: not bit-reproducible against the CPU oracle any more (values within
+ *                   ~1e-6 relative, threshold flips attributed by tests/test_gpu_fastexp.py); default 0. */
+typedef struct gsr_options {
+	int32_t struct_bytes;   /* sizeof(gsr_options) of the caller: fields beyond it are taken as -1 */
+	int32_t tight_binning;
+	int32_t cull;
+	int32_t fwd_variant;
+	int32_t bwd_variant;
+	int32_t speculative;
+	int32_t tile_row_lo;    /* tile band of THIS call: [lo, hi), hi <= 0 with lo >= 0 = the whole image */
+	int32_t tile_row_hi;
+	int32_t fast_exp;
+} gsr_options;
+void gsr_options_init(gsr_options* opt);   /* struct_bytes = sizeof, every field -1 */
+
+int gsr_forward_ex(const gsr_options* opt, gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc,
+                   void* binning_ctx, gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M,
+                   const float* background, int width, int height, const float* means3D, const float* shs,
+                   const float* shs_rest, const float* colors_precomp, const float* opacities, const float* scales,
+                   float scale_modifier, const float* rotations, const float* cov3D_precomp, int activation_flags,
+                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                   int prefiltered, float* out_color, float* out_depth, float* out_median_depth, float* out_opacity,
+                   int* radii, int debug, void* stream);
+/* parts / sh_g0 / sh_g1 as in gsr_backward_parts; dL_dsh_rest NULL unless shs_rest is given. */
+int gsr_backward_ex(const gsr_options* opt, int parts, int sh_g0, int sh_g1, int P, int D, int M, int R,
+                    const float* background, int width, int height, const float* means3D, const float* shs,
+                    const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
+                    const float* rotations, const float* cov3D_precomp, int activation_flags, float tan_fovx,
+                    float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
+                    const char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth,
+                    const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D,
+                    float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                    float* dL_dsh_rest, float* dL_dscale, float* dL_drot, char* scratch, int debug, void* stream);
 
 /* Device self-test of the arithmetic identities composite_bwd relies on: bit 0: v_rcp_f32(1.0) == 1.0,
  * bit 1: t * v_rcp_f32(1.0) == t.  Synchronises the stream.  Negative = GSR_ERR_*. */

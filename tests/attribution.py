@@ -1,0 +1,312 @@
+"""TEST INFRASTRUCTURE: threshold-event attribution for pixels that differ between two forward implementations.
+
+The compositing loop (forward.cu:330-380) takes three data-dependent decisions per (pixel, Gaussian):
+
+    power > 0            -> skip                       (forward.cu:341-342)
+    alpha < 1/255        -> skip                       (forward.cu:349-350)
+    T (1 - alpha) < 1e-4 -> the pixel is done          (forward.cu:351-356)
+
+Two implementations that evaluate exp() / the FMA contraction differently agree to ~1e-6 on every smooth quantity,
+but where one of these quantities lies within rounding distance of its threshold they can take opposite branches, and
+the pixel then changes by up to alpha*T*c (~4e-3).  Counting such pixels is not a proof that they ARE flips.  This module
+proves it constructively: for a pixel whose two values differ by more than the tolerance, the
+tile's list is replayed in float64 from the (bit-identical) per-Gaussian records; every decision whose operand lies
+inside a stated relative window of its threshold is a branch point, and the replay explores both branches.  The pixel
+is ATTRIBUTED iff
+  * one leaf of that decision tree reproduces implementation A's value (all five channels) and
+  * a DIFFERENT leaf reproduces implementation B's value to the same tolerance,
+i.e. the whole difference is explained by decisions taken inside the windows.  A fourth kind of event covers the
+<= 1e-5 of the Gaussians whose integer `radii` differ between the implementations (a ceil() taken on the other side:
+the Gaussian is binned into a different set of tiles): membership of such a Gaussian in the pixel's list is a branch
+point as well.  Everything else -- a wrong list order, a wrong record, a wrong accumulation -- reproduces neither
+value and is reported as unattributed.
+"""
+import numpy as np
+
+ALPHA_MIN = 1.0 / 255.0
+# relative windows around the thresholds inside which the two implementations may legitimately decide differently:
+# exp() differs by <= 4e-7 relative, `power` by <= ~1e-6 * (|a dx^2| + |b dx dy| + |c dy^2|) (FMA contraction), T is a
+# product of up to a few hundred (1 - alpha) factors (<= ~3e-5 relative)
+WIN_ALPHA = 2.0e-5       # |alpha * 255 - 1|            (largest margin of an attributed event on the MI355X, C1-C5: 1.8e-6)
+WIN_T = 5.0e-5           # |T (1 - alpha) / 1e-4 - 1|   (largest observed: 4.5e-6)
+WIN_POWER = 1.0e-5       # |power| / (|a dx^2| + |b dx dy| + |c dy^2|): only a cancelling (indefinite) form gets here
+MAX_LEAVES = 256
+
+
+def tile_list(st, tile):
+    """ids of the tile's depth-sorted list, from the decoded state of a forward (util.hip_forward / the oracle)."""
+    r = np.asarray(st["ranges"][tile].cpu() if hasattr(st["ranges"], "cpu") else st["ranges"][tile]).astype(np.int64)
+    pl = st["point_list"]
+    ids = pl[int(r[0]):int(r[1])]
+    return np.asarray(ids.cpu() if hasattr(ids, "cpu") else ids).astype(np.int64)
+
+
+def _records(st, ids):
+    g = lambda k: np.asarray(st[k][ids].cpu() if hasattr(st[k], "cpu") else st[k][ids]).astype(np.float64)
+    return g("means2D"), g("conic_opacity"), g("rgb"), g("depths")
+
+
+def _explore(n, power, mag, alpha_raw, alpha, rgb, dep, include):
+    leaves = []
+
+    def rec(i, T, c0, c1, c2, d, events):
+        while i < n:
+            if len(leaves) >= MAX_LEAVES:
+                return
+            inc = True if include is None else include[i]
+            if inc is False:
+                i += 1
+                continue
+            if inc is None:                                            # in one implementation's list only
+                rec2 = list(events) + [(i, "radius", 0.0)]
+                # branch A: absent
+                _cont(i + 1, T, c0, c1, c2, d, rec2)
+                # branch B (fall through): present
+            # --- power > 0 ---
+            p_skip = power[i] > 0.0
+            p_margin = abs(power[i]) / mag[i] if mag[i] > 1e-200 else np.inf
+            if p_margin < WIN_POWER:
+                if p_skip:   # alternative: treat as not skipped -> needs the rest of the body; handled by flipping below
+                    _body(i, T, c0, c1, c2, d, list(events) + [(i, "power", p_margin)], force_alpha=None)
+                else:
+                    _cont(i + 1, T, c0, c1, c2, d, list(events) + [(i, "power", p_margin)])
+            if p_skip:
+                i += 1
+                continue
+            # --- alpha < 1/255 ---
+            a_skip = alpha[i] < ALPHA_MIN
+            a_margin = abs(alpha_raw[i] / ALPHA_MIN - 1.0)
+            if a_margin < WIN_ALPHA:
+                if a_skip:
+                    _body(i, T, c0, c1, c2, d, list(events) + [(i, "alpha", a_margin)], force_alpha=True)
+                else:
+                    _cont(i + 1, T, c0, c1, c2, d, list(events) + [(i, "alpha", a_margin)])
+            if a_skip:
+                i += 1
+                continue
+            # --- T (1 - alpha) < 1e-4 ---
+            test_T = T * (1.0 - alpha[i])
+            t_stop = test_T < 1e-4
+            t_margin = abs(test_T / 1e-4 - 1.0)
+            if t_margin < WIN_T:
+                if t_stop:
+                    # alternative: not done -> apply and go on
+                    _apply_and_go(i, T, test_T, c0, c1, c2, d, list(events) + [(i, "T", t_margin)])
+                else:
+                    leaves.append((np.array([c0, c1, c2, d, 1.0 - T]), tuple(events) + ((i, "T", t_margin),)))
+            if t_stop:
+                leaves.append((np.array([c0, c1, c2, d, 1.0 - T]), tuple(events)))
+                return
+            w = alpha[i] * T
+            c0 += rgb[i, 0] * w
+            c1 += rgb[i, 1] * w
+            c2 += rgb[i, 2] * w
+            d += dep[i] * w
+            T = test_T
+            i += 1
+        leaves.append((np.array([c0, c1, c2, d, 1.0 - T]), tuple(events)))
+
+    def _cont(i, T, c0, c1, c2, d, events):
+        rec(i, T, c0, c1, c2, d, events)
+
+    def _apply_and_go(i, T, test_T, c0, c1, c2, d, events):
+        w = alpha[i] * T
+        rec(i + 1, test_T, c0 + rgb[i, 0] * w, c1 + rgb[i, 1] * w, c2 + rgb[i, 2] * w, d + dep[i] * w, events)
+
+    def _body(i, T, c0, c1, c2, d, events, force_alpha):
+        # the instance is evaluated although the default decision skipped it: alpha test (unless forced), T test, apply
+        if force_alpha is None and alpha[i] < ALPHA_MIN:
+            rec(i + 1, T, c0, c1, c2, d, events)
+            return
+        test_T = T * (1.0 - alpha[i])
+        if test_T < 1e-4:
+            leaves.append((np.array([c0, c1, c2, d, 1.0 - T]), tuple(events)))
+            return
+        _apply_and_go(i, T, test_T, c0, c1, c2, d, events)
+
+    rec(0, 1.0, 0.0, 0.0, 0.0, 0.0, [])
+    return leaves
+
+
+def attribute_pixel(st, tile, px, py, val_a, val_b, tol_a, tol_b, maybe_ids=(), extra_ids=()):
+    """val_* = (r, g, b, depth, opacity) of the two implementations at pixel (px, py) of `tile`; tol_* = per-channel
+    absolute tolerances for matching a replay leaf to them (the replay is float64, the implementations accumulate in
+    fp32).  maybe_ids: Gaussians of the list whose membership is undecided (their radii differ between the
+    implementations); extra_ids: Gaussians NOT in this list that the other implementation may have binned here.
+    Returns dict(attributed, events, kinds, leaves)."""
+    ids = tile_list(st, tile)
+    include = None
+    if len(extra_ids):
+        # insert by depth (stable: equal depths by id), membership undecided
+        depths_all = st["depths"]
+        dep_of = lambda i: float(depths_all[int(i)])
+        cur = [(dep_of(i), int(i), True) for i in ids] + [(dep_of(i), int(i), None) for i in extra_ids]
+        cur.sort(key=lambda t: (t[0], t[1]))
+        ids = np.array([c[1] for c in cur], dtype=np.int64)
+        include = [c[2] for c in cur]
+    if len(maybe_ids):
+        include = [True] * len(ids) if include is None else include
+        ms = set(int(i) for i in maybe_ids)
+        include = [None if (int(g) in ms) else inc for g, inc in zip(ids, include)]
+    xy, co, rgb, dep = _records(st, ids)
+    leaves = _explore(len(ids), *_terms(xy, co, float(px), float(py)), rgb, dep, include)
+    va, vb = np.asarray(val_a, np.float64), np.asarray(val_b, np.float64)
+    hit_a = [k for k, (v, _) in enumerate(leaves) if np.all(np.abs(v - va) <= tol_a)]
+    hit_b = [k for k, (v, _) in enumerate(leaves) if np.all(np.abs(v - vb) <= tol_b)]
+    best = None
+    for ka in hit_a:
+        for kb in hit_b:
+            ea, eb = set(leaves[ka][1]), set(leaves[kb][1])
+            diff = ea ^ eb                                   # the decisions the two implementations took differently
+            if not diff:
+                continue
+            cand = sorted(diff)
+            if best is None or len(cand) < len(best):
+                best = cand
+    return {"attributed": best is not None, "events": best or [], "leaves": len(leaves),
+            "matches_a": len(hit_a), "matches_b": len(hit_b),
+            "kinds": sorted(set(e[1] for e in (best or [])))}
+
+
+def _terms(xy, co, px, py):
+    dx = xy[:, 0] - px
+    dy = xy[:, 1] - py
+    ta, tb, tc = co[:, 0] * dx * dx, co[:, 1] * dx * dy, co[:, 2] * dy * dy
+    power = -0.5 * (ta + tc) - tb
+    mag = np.abs(ta) + np.abs(tb) + np.abs(tc) + 1e-300      # all terms 0 (pixel on the centre): power is exactly 0 everywhere
+    alpha_raw = co[:, 3] * np.exp(np.minimum(power, 0.0))
+    alpha = np.minimum(0.99, alpha_raw)
+    return power, mag, alpha_raw, alpha
+
+
+def attribute_images(st, W, H, imgs_a, imgs_b, tol=1e-5, depth_scale=1.0, radii_b=None, max_pixels=4000):
+    """imgs_* = dict(color[3,H,W], depth[1,H,W], opacity[1,H,W]) as numpy arrays of implementations A (the one `st`
+    was decoded from) and B.  Every pixel with a channel differing by more than `tol` is attributed.
+    Returns dict(flagged, attributed, unattributed=[...], by_kind, max_margin, events=[...])."""
+    a = np.concatenate([imgs_a["color"], imgs_a["depth"], imgs_a["opacity"]], 0).astype(np.float64)   # [5,H,W]
+    b = np.concatenate([imgs_b["color"], imgs_b["depth"], imgs_b["opacity"]], 0).astype(np.float64)
+    bad = (np.abs(a - b) > tol).any(0)
+    ys, xs = np.nonzero(bad)
+    gx = (W + 15) // 16
+    out = {"flagged": int(len(ys)), "attributed": 0, "unattributed": [], "by_kind": {}, "max_margin": {}, "events": []}
+    if len(ys) > max_pixels:
+        out["unattributed"] = [f"{len(ys)} pixels differ: more than max_pixels={max_pixels}, not a handful of flips"]
+        return out
+    # Gaussians whose radii differ between the implementations (a ceil() on the other side)
+    maybe = np.zeros(0, np.int64)
+    rect_b = None
+    if radii_b is not None:
+        ra = np.asarray(st["radii"].cpu()).astype(np.int64)
+        rb = np.asarray(radii_b).astype(np.int64)
+        maybe = np.nonzero(ra != rb)[0]
+        if len(maybe):
+            m2 = np.asarray(st["means2D"][maybe].cpu()).astype(np.float64)
+            rmax = np.maximum(ra[maybe], rb[maybe]).astype(np.float64)
+            gy = (H + 15) // 16
+            rect_b = (np.clip(((m2[:, 0] - rmax) // 16).astype(np.int64), 0, gx), np.clip(((m2[:, 1] - rmax) // 16).astype(np.int64), 0, gy),
+                      np.clip(((m2[:, 0] + rmax + 15) // 16).astype(np.int64), 0, gx), np.clip(((m2[:, 1] + rmax + 15) // 16).astype(np.int64), 0, gy))
+    # fp32 accumulation noise of the implementations against the float64 replay: colour/opacity values are O(1), depth
+    # is in scene units
+    tol_leaf = np.array([4e-6, 4e-6, 4e-6, 4e-6 * max(depth_scale, 1.0), 4e-6])
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        tile = (y // 16) * gx + (x // 16)
+        ids = tile_list(st, tile)
+        mb, extra = [], []
+        if rect_b is not None:
+            tx, ty = x // 16, y // 16
+            cover = (rect_b[0] <= tx) & (tx < rect_b[2]) & (rect_b[1] <= ty) & (ty < rect_b[3])
+            cand = maybe[cover]
+            inl = set(ids.tolist())
+            mb = [int(g) for g in cand if int(g) in inl]
+            extra = [int(g) for g in cand if int(g) not in inl]
+        res = attribute_pixel(st, tile, x, y, a[:, y, x], b[:, y, x], tol_leaf, np.maximum(tol_leaf, tol), mb, extra)
+        if res["attributed"]:
+            out["attributed"] += 1
+            for (_pos, kind, margin) in res["events"]:
+                out["by_kind"][kind] = out["by_kind"].get(kind, 0) + 1
+                out["max_margin"][kind] = max(out["max_margin"].get(kind, 0.0), float(margin))
+            out["events"].append({"pixel": [x, y], "events": [[int(p), k, float(m)] for p, k, m in res["events"]]})
+        else:
+            out["unattributed"].append({"pixel": [x, y], "a": a[:, y, x].tolist(), "b": b[:, y, x].tolist(),
+                                        "leaves": res["leaves"], "matches_a": res["matches_a"], "matches_b": res["matches_b"]})
+    return out
+
+
+def median_margin(st, tile, px, py):
+    """Smallest relative distance to 0.5 of a transmittance the median test (forward.cu:366-374: T > 0.5 and
+    T (1 - alpha) < 0.5) looks at, along the default walk of the pixel: a median id that differs between two
+    implementations although the pixel's values agree must have such a transmittance within rounding distance of 0.5."""
+    ids = tile_list(st, tile)
+    xy, co, _rgb, _dep = _records(st, ids)
+    power, _mag, _araw, alpha = _terms(xy, co, float(px), float(py))
+    T, best = 1.0, np.inf
+    for i in range(len(ids)):
+        if power[i] > 0.0 or alpha[i] < ALPHA_MIN:
+            continue
+        test_T = T * (1.0 - alpha[i])
+        if test_T < 1e-4:
+            break
+        best = min(best, abs(T / 0.5 - 1.0), abs(test_T / 0.5 - 1.0))
+        T = test_T
+    return best
+
+
+def median_gradient_census(st, W, H, chunk_tiles=128):
+    """REPORT (not a pass/fail criterion): how often does the reference's backward route dL/dmedian_depth differently
+    from the forward's own median decision?  backward.cu:566-569 re-derives the crossing from a transmittance
+    reconstructed by repeated DIVISION (T <- T / (1 - alpha), back to front from final_T) and fires where
+    `test_T > 0.5 && T < 0.5`; this library sends the gradient to the Gaussian the FORWARD recorded (median image,
+    channel 2).  Evaluated here in fp32 torch on the device for every pixel: counts of pixels where the reconstructed
+    test fires exactly once at the forward's Gaussian / at another one / never although the forward has a median /
+    more than once."""
+    import torch
+    dev = st["means2D"].device
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T_tiles = gx * gy
+    ranges = st["ranges"].long()
+    lens = (ranges[:, 1] - ranges[:, 0])
+    pl = st["point_list"].long()
+    xy, co = st["means2D"], st["conic_opacity"]
+    fT, nc = st["final_T"], st["n_contrib"].long()
+    med_id = st["median"][2].long()
+    med_has = st["median"][1] > 0                                  # median weight > 0: the forward found a crossing
+    ys, xs = torch.meshgrid(torch.arange(16, device=dev), torch.arange(16, device=dev), indexing="ij")
+    out = {"pixels": 0, "same": 0, "other": 0, "never": 0, "multiple": 0, "no_median": 0}
+    for t0 in range(0, T_tiles, chunk_tiles):
+        tiles = torch.arange(t0, min(T_tiles, t0 + chunk_tiles), device=dev)
+        L = int(lens[tiles].max())
+        if L == 0:
+            continue
+        pos = torch.arange(L, device=dev)[None, :]
+        valid = pos < lens[tiles][:, None]
+        idx = (ranges[tiles, 0][:, None] + pos).clamp_(max=pl.numel() - 1)
+        ids = pl[idx]                                              # [t, L]
+        px = ((tiles % gx) * 16)[:, None, None] + xs[None]         # [t,16,16]
+        py = ((tiles // gx) * 16)[:, None, None] + ys[None]
+        inside = (px < W) & (py < H)
+        pxc, pyc = px.clamp(max=W - 1), py.clamp(max=H - 1)
+        dx = xy[ids, 0][:, None, None, :] - pxc[..., None].float()
+        dy = xy[ids, 1][:, None, None, :] - pyc[..., None].float()
+        c = co[ids]
+        power = -0.5 * (c[..., 0][:, None, None] * dx * dx + c[..., 2][:, None, None] * dy * dy) - c[..., 1][:, None, None] * dx * dy
+        alpha = torch.clamp_max(c[..., 3][:, None, None] * torch.exp(power), 0.99)
+        live = (power <= 0) & (alpha >= 1.0 / 255.0) & valid[:, None, None, :] & (pos[None, None] < nc[pyc, pxc][..., None])
+        T = fT[pyc, pxc].clone()
+        fires = torch.zeros_like(T, dtype=torch.long)
+        fired_id = torch.full_like(fires, -1)
+        for k in range(L - 1, -1, -1):
+            lv = live[..., k]
+            test_T = T / (1.0 - alpha[..., k])
+            ev = lv & (test_T > 0.5) & (T < 0.5)
+            fires += ev.long()
+            fired_id = torch.where(ev, ids[:, k][:, None, None].expand_as(fired_id), fired_id)
+            T = torch.where(lv, test_T, T)
+        mh = med_has[pyc, pxc] & inside
+        mid = med_id[pyc, pxc]
+        out["pixels"] += int(inside.sum())
+        out["no_median"] += int((inside & ~mh & (fires == 0)).sum())
+        out["same"] += int((mh & (fires == 1) & (fired_id == mid)).sum())
+        out["other"] += int((inside & (fires == 1) & ((fired_id != mid) | ~mh)).sum())
+        out["never"] += int((mh & (fires == 0)).sum())
+        out["multiple"] += int((inside & (fires > 1)).sum())
+    return out

@@ -34,10 +34,16 @@ def test_operator_signatures_match_reference():
     assert fwd == ["self", "means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"]
     assert list(inspect.signature(g.rasterize_gaussians).parameters) == [
         "means3D", "means2D", "sh", "colors_precomp", "opacities", "scales", "rotations", "cov3Ds_precomp", "raster_settings"]
-    assert list(inspect.signature(g._C.rasterize_gaussians).parameters) == [
+    # the reference's positional parameters (rasterize_points.h:18-65), then ONE optional trailing `options` (the
+    # per-call options of include/gsrast.h gsr_options; a reference-style positional call never reaches it)
+    def positional(fn):
+        ps = inspect.signature(fn).parameters
+        assert list(ps)[-1] == "options" and ps["options"].default is None
+        return list(ps)[:-1]
+    assert positional(g._C.rasterize_gaussians) == [
         "background", "means3D", "colors", "opacity", "scales", "rotations", "scale_modifier", "cov3D_precomp", "viewmatrix",
         "projmatrix", "tan_fovx", "tan_fovy", "image_height", "image_width", "sh", "degree", "campos", "prefiltered", "debug"]
-    assert list(inspect.signature(g._C.rasterize_gaussians_backward).parameters) == [
+    assert positional(g._C.rasterize_gaussians_backward) == [
         "background", "means3D", "radii", "colors", "scales", "rotations", "scale_modifier", "cov3D_precomp", "viewmatrix",
         "projmatrix", "tan_fovx", "tan_fovy", "dL_dout_color", "dL_dout_depth", "dL_dout_median_depth",
         "dL_dout_final_opacity", "sh", "degree", "campos", "geomBuffer", "R", "binningBuffer", "imageBuffer", "debug"]
@@ -103,7 +109,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     L = _C.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/gsrast.h but not exported by libgsrast.so"
-    assert L.gsr_abi_version() == 5
+    assert L.gsr_abi_version() == 6
     L.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
     assert L.gsr_backward_scratch_bytes(ctypes.c_int(1000), ctypes.c_int(5000)) >= 5000 * 49
 

@@ -1,0 +1,155 @@
+"""-m gpu: the opt-in `fast_exp` mode (include/gsrast.h gsr_options.fast_exp, gaustudio_amd.options(fast_exp=True)): exp on
+the transcendental unit in both compositing kernels.  The mode is NOT bit-reproducible against the CPU oracle, so its
+parity evidence is (a) every rendered value within 1e-5 of the bit-exact mode's, except pixels that differ by more
+than that, EACH of which must be attributed to a threshold event by tests/attribution.py (the machinery that also
+pins the comparison with the reference's kernels); (b) gradients within the tolerance the reference comparison uses;
+(c) the backward provably runs in the mode of its forward; (d) per-call options are per thread and travel with the graph.
+"""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import gaustudio_amd
+from gaustudio_amd import _C, scenes
+
+import attribution
+from util import hip_backward_raw, hip_forward, scene_kwargs, to_np
+
+pytestmark = pytest.mark.gpu
+
+GRAD_KEYS = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+
+
+def _dump(config, stats):
+    if os.environ.get("GSR_DUMP_PARITY") != "1":
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out", "r03_fastexp_parity.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    data = json.load(open(out)) if os.path.exists(out) else {
+        "what": "fast_exp mode vs the bit-exact mode of the same library on an MI355X: values differing by more than 1e-5 abs, "
+                "each attributed to a threshold event (tests/attribution.py)", "configs": {}}
+    data["configs"][config] = stats
+    json.dump(data, open(out, "w"), indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("P,W,H,D", [(10000, 400, 400, 0), (300000, 800, 800, 3), (1000000, 1920, 1080, 3)], ids=["C1", "C2", "C3"])
+def test_fast_exp_vs_bit_exact_mode(request, P, W, H, D):
+    cam = scenes.make_camera(W, H)
+    sc = scenes.make_scene(P, cam, seed=0)
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam)
+    exact = hip_forward(sc, cam, D, kw)
+    with gaustudio_amd.options(fast_exp=True):
+        fast = hip_forward(sc, cam, D, kw)
+    # everything in front of the compositing kernel is untouched by the mode
+    assert torch.equal(exact["radii"], fast["radii"]) and torch.equal(exact["point_list"], fast["point_list"])
+    assert exact["num_rendered"] == fast["num_rendered"] and torch.equal(exact["ranges"], fast["ranges"])
+    a = {k: to_np(exact[k]) for k in ("color", "depth", "opacity")}
+    b = {k: to_np(fast[k]) for k in ("color", "depth", "opacity")}
+    stats = {}
+    flagged = np.zeros((H, W), bool)
+    for k in a:
+        d = np.abs(a[k].astype(np.float64) - b[k].astype(np.float64))
+        flagged |= (d > 1e-5).any(0)
+        stats[k] = {"over_1e-5": int((d > 1e-5).sum()), "values": int(d.size), "max_abs": float(d.max())}
+    for k in a:       # report: away from the flagged pixels (flips below 1e-5 included) the two modes agree to a few 1e-6
+        stats[k]["max_abs_unflagged"] = float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64))[:, ~flagged].max())
+        stats[k]["over_2e-6"] = int((np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)) > 2e-6 * (20.0 if k == "depth" else 1.0)).sum())
+    rep = attribution.attribute_images(exact, W, H, a, b, tol=1e-5, depth_scale=20.0)
+    stats["attribution"] = {k: rep[k] for k in ("flagged", "attributed", "by_kind", "max_margin")}
+    stats["attribution"]["unattributed"] = len(rep["unattributed"])
+    assert not rep["unattributed"], rep["unattributed"][:3]
+    # backward, each in the mode of its forward (gsr_backward takes the process default: set it for the raw call)
+    gb_exact = hip_backward_raw(exact, sc, cam, D, kw, grads)
+    _C.set_option("fast_exp", 1)
+    try:
+        gb_fast = hip_backward_raw(fast, sc, cam, D, kw, grads, debug=True)      # debug: checks the mode against the forward's record
+    finally:
+        _C.set_option("fast_exp", 0)
+    stats["grads"] = {}
+    for k in GRAD_KEYS:
+        x, y = to_np(gb_fast[k]), to_np(gb_exact[k])
+        scale = max(float(np.abs(y).max()), 1e-30)
+        stats["grads"][k] = {"max_rel": float(np.abs(x - y).max() / scale), "mean_rel": float(np.abs(x - y).mean() / scale)}
+        assert np.abs(x - y).max() <= 5e-4 * scale and np.abs(x - y).mean() <= 1e-6 * scale, (k, stats["grads"][k])
+    _dump(request.node.callspec.id, stats)
+
+
+def test_backward_must_run_in_the_mode_of_its_forward():
+    cam = scenes.make_camera(160, 96)
+    sc = scenes.make_scene(3000, cam, seed=2)
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam)
+    with gaustudio_amd.options(fast_exp=True):
+        fast = hip_forward(sc, cam, 3, kw)
+    with pytest.raises(RuntimeError, match="fast_exp differs from the forward"):
+        hip_backward_raw(fast, sc, cam, 3, kw, grads, debug=True)             # process default: bit-exact mode
+    exact = hip_forward(sc, cam, 3, kw)
+    _C.set_option("fast_exp", 1)
+    try:
+        with pytest.raises(RuntimeError, match="fast_exp differs from the forward"):
+            hip_backward_raw(exact, sc, cam, 3, kw, grads, debug=True)
+    finally:
+        _C.set_option("fast_exp", 0)
+    with pytest.raises(RuntimeError, match="fwd_variant 0"):
+        with gaustudio_amd.options(fast_exp=True, fwd_variant=1):
+            hip_forward(sc, cam, 3, kw)
+
+
+def test_options_travel_with_the_graph_and_are_per_thread():
+    """The backward of a call runs with the options of ITS forward although it is executed outside the `with` block (and
+    on autograd's thread); two threads of one process render two tile bands of one view concurrently -- the case the
+    process-wide tile_row_lo / tile_row_hi switches could not serve."""
+    from gaustudio_amd import parallel
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam = scenes.make_camera(640, 360)
+    sc = scenes.make_scene(40000, cam, seed=14)
+    dev = "cuda"
+    g = [x.to(dev) for x in scenes.make_output_grads(cam, seed=3)]
+    rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, True)   # debug: mode check on
+
+    def run(band, fast, sync=None):
+        leaves = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+        m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        with parallel.tile_band(*band), gaustudio_amd.options(fast_exp=fast):
+            out = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], shs=leaves["shs"],
+                                         scales=leaves["scales"], rotations=leaves["rotations"])
+            if sync is not None:
+                sync.wait()               # both threads are inside their `with` blocks, both forwards have been issued
+        if sync is not None:
+            sync.wait()                   # ... and both have left them before either backward starts
+        torch.autograd.backward([out[0], out[2], out[3], out[4]], g)
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in out], {k: v.grad.clone() for k, v in leaves.items()}
+
+    bands = [parallel.tile_row_band(cam.height, r, 2) for r in range(2)]
+    want = [run(bands[0], False), run(bands[1], True)]                         # one after the other
+    got = [None, None]
+    sync = threading.Barrier(2)
+    errs = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            got[i] = run(bands[i], bool(i), sync)
+        except Exception as e:       # noqa: BLE001
+            errs.append(e)
+            sync.abort()
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(2):
+        for a, b in zip(want[i][0], got[i][0]):
+            assert torch.equal(a, b)
+        for k in want[i][1]:
+            assert torch.equal(want[i][1][k], got[i][1][k]), (i, k)
+    # the two bands really are different renders (band 0 leaves the lower half empty, band 1 the upper)
+    assert float(got[0][0][0][:, 200:].abs().sum()) == 0.0 and float(got[1][0][0][:, :180].abs().sum()) == 0.0
+    assert _C.get_option("tile_row_lo") == 0 and _C.get_option("tile_row_hi") <= 0 and _C.get_option("fast_exp") == 0   # nothing process-wide was touched
