@@ -246,13 +246,13 @@ def run_extract(a, dev, scenes, _C):
     # scene's would -- voxels of 4 cm (scene depth 2 .. 20) and 2^22 hash slots (16 GiB of the 288) hold it
     vol = TSDFVolume(voxel_size=0.04, sdf_trunc=0.16, space_carving=False, device=dev, capacity_blocks=1 << 22)
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    stage_names = ("render", "mask", "points", "normals", "compact", "integrate")
+    stage_names = ("render", "mask", "points", "normals", "integrate")
     acc = {k: 0.0 for k in stage_names}
     marks = []
 
     def step(i, timed=False):
         rs, Kc, E, c = rss[i % K], Ks[i % K], Es[i % K], cams[i % K]
-        e = [ev() for _ in range(7)] if timed else None
+        e = [ev() for _ in range(6)] if timed else None
         if timed: e[0].record()
         with torch.no_grad():
             _, _, _, median, opacity = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=m2, opacities=params["opacities"],
@@ -265,24 +265,25 @@ def run_extract(a, dev, scenes, _C):
         if timed: e[3].record()
         nrm = pp.depth_to_normals(depth, Kc, E, coordinate="world")             # Camera.depth2normal (gs-extract-pcd / normal maps)
         if timed: e[4].record()
-        valid_pts = pts[~invalid]                                               # :110
-        if timed: e[5].record()
-        vol.integrate(valid_pts, c.campos)                                      # :115 vdb_volume.integrate
+        # :110 compacts `pts[~invalid]` for the CPU library; here a masked pixel's point IS the sensor origin (depth 0) and
+        # the integrate kernel skips zero-length rays, so the whole [H*W,3] map goes in: no nonzero / gather pass, no host
+        # synchronisation for the count (tests/test_tsdf.py: identical volume)
+        vol.integrate(pts.view(-1, 3), c.campos)                                # :115 vdb_volume.integrate
         if timed:
-            e[6].record()
+            e[5].record()
             marks.append(e)
-        return nrm, valid_pts.shape[0]
+        return nrm, invalid
 
     for i in range(max(a.warmup, K)):                                           # at least one full ring: allocates the blocks
         step(i)
     torch.cuda.synchronize()
     _C.set_profiling(True)
     t0 = time.perf_counter()
-    n_valid = 0
+    inv = None
     for i in range(a.steps):
-        _, nv = step(i, timed=True)
-        n_valid += nv
+        _, inv = step(i, timed=True)
     torch.cuda.synchronize()
+    n_valid = int((~inv).sum().item()) * a.steps
     dt = time.perf_counter() - t0
     fwd_ms = _C.last_forward_ms()
     _C.set_profiling(False)

@@ -112,12 +112,21 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                                  _opts(options))
 
 
-def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None):
+def sh_grad_from_colors(means3D, campos, colors, degree, out):
+    """out[P,M,3] = sum over the N views (ascending) of basis(dir_r) (x) colors[r]: the SH gradient of a multi-view step from the
+    per-view colour gradients (include/gsrast.h gsr_sh_grad_from_colors; gaustudio_amd/parallel.py FactoredGradExchange)."""
+    native().sh_grad_from_colors(means3D, campos, colors, int(degree), out)
+    return out
+
+
+def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None, colors_out=None):
     """One-shot destination tensors [dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations] for the next
     rasterize_gaussians_backward whose inputs [means3D, sh, scales, rotations] have the data pointers `keys`
     (0 / empty = any); see gaustudio_amd/parallel.py.  With sh_chunks > 1 and a hook, the SH stage of that backward
-    runs in Gaussian ranges and hook(c, g0, g1) is called after range c has been enqueued.  [] disarms."""
-    native().set_grad_arena(list(outs), [int(k) for k in keys], int(sh_chunks), hook)
+    runs in Gaussian ranges and hook(c, g0, g1) is called after range c has been enqueued.  colors_out [P,3]: that
+    backward runs its SH stage in the factored form -- the clamp-masked colour gradient goes there and the returned
+    dL_dsh is None (outs may then be [] or five tensors whose second is ignored).  [] without colors_out disarms."""
+    native().set_grad_arena(list(outs), [int(k) for k in keys], int(sh_chunks), hook, colors_out)
 
 
 def set_option(name, value):

@@ -604,9 +604,12 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL buffer", __FILE__, __LINE__);
 	if (!dL_dpix || !dL_dpix_depth || !dL_dpix_median_depth || !dL_dpix_final_opacity)
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL upstream gradient", __FILE__, __LINE__);
+	const bool sh_colors = (parts & GSR_BWD_PART_SH_COLORS) != 0;
 	if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
-	    (M > 0 && !dL_dsh))
+	    (M > 0 && !dL_dsh && !sh_colors))
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL output", __FILE__, __LINE__);
+	if (sh_colors && (!shs || shs_rest || colors_precomp))
+		return fail(GSR_ERR_ARG, "gsr_backward: GSR_BWD_PART_SH_COLORS needs SH colours in one [P,M,3] tensor", __FILE__, __LINE__);
 	if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
 		return fail(GSR_ERR_ARG, "gsr_backward: SH degree does not fit the stored coefficients", __FILE__, __LINE__);
 
@@ -636,7 +639,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	if (!(parts & GSR_BWD_PART_MAIN)) {
 		// SH stage alone over a Gaussian range (the caller interleaves a collective per chunk, gaustudio_amd/parallel.py)
 		launch_preprocess_bwd(a, cam, recs, goff, rows, nullptr, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
-		                      dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_SH, sh_g0, sh_g1, s);
+		                      dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_SH | (sh_colors ? GSR_PART_SH_COLORS : 0), sh_g0, sh_g1, s);
 		STAGE_CHECK("preprocess_bwd_sh", debug, s);
 		return GSR_OK;
 	}
@@ -683,7 +686,8 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	}
 	tm.mark();
 	launch_preprocess_bwd(a, cam, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-	                      dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_GEOM | ((parts & GSR_BWD_PART_SH) ? GSR_PART_SH : 0),
+	                      dL_dsh_rest, dL_dscale, dL_drot,
+	                      GSR_PART_GEOM | ((parts & GSR_BWD_PART_SH) ? GSR_PART_SH : 0) | (sh_colors ? GSR_PART_SH_COLORS : 0),
 	                      sh_g0, sh_g1, s);
 	STAGE_CHECK("preprocess_bwd", debug, s);
 	tm.mark();
@@ -747,6 +751,21 @@ int gsr_backward_ex(const gsr_options* opt, int parts, int sh_g0, int sh_g1, int
 	                     radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
 	                     dL_dpix_final_opacity, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest,
 	                     dL_dscale, dL_drot, scratch, debug, stream);
+}
+
+int gsr_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, const float* campos, const float* colors,
+                            float* dL_dsh, void* stream)
+{
+	g_err.clear();
+	if (P <= 0 || M <= 0) return GSR_OK;
+	if (N < 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+		return fail(GSR_ERR_ARG, "gsr_sh_grad_from_colors: bad N / SH degree", __FILE__, __LINE__);
+	if (!means3D || !dL_dsh || (N > 0 && (!campos || !colors)))
+		return fail(GSR_ERR_ARG, "gsr_sh_grad_from_colors: NULL argument", __FILE__, __LINE__);
+	if (!is_device_ptr(campos)) return fail(GSR_ERR_ARG, "gsr_sh_grad_from_colors: campos must be device memory", __FILE__, __LINE__);
+	launch_sh_grad_from_colors(P, D, M, N, means3D, campos, colors, dL_dsh, (hipStream_t)stream);
+	STAGE_CHECK("sh_grad_from_colors", 0, (hipStream_t)stream);
+	return GSR_OK;
 }
 
 int gsr_set_option(const char* name, int value)

@@ -165,11 +165,15 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, co
 // the Gaussians [sh_g0, sh_g1) (a multiple-of-256 start; lets a caller interleave a collective per chunk)
 #define GSR_PART_GEOM 1
 #define GSR_PART_SH 2
+#define GSR_PART_SH_COLORS 4   // with GSR_PART_SH: the factored form (dRGB into dL_dcolor in place, dL_dsh untouched)
 void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
                            const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
                            float* dL_drot, int parts, int sh_g0, int sh_g1, hipStream_t s);
 void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s);
+// dL_dsh[P,M,3] = sum over N views of basis(dir) (x) colors[r][g] (gaustudio_amd/parallel.py FactoredGradExchange)
+void launch_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, const float* campos, const float* colors,
+                                float* dL_dsh, hipStream_t s);
 void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint32_t* goff, const float* rows,
                          const uint8_t* row_flags,
                          float* sums10, hipStream_t s);

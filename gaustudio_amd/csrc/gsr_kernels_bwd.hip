@@ -1089,6 +1089,34 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 // gs_sh_backward: from the SH coefficients `sh` (active degree D) returns dc[k] = d(rgb)/d(sh_k) (so that
 // dL_dsh[k][ch] = dc[k] * dRGB[ch]), dRGB = dL_dcolor with the clamped channels zeroed (Q12), and dmean_sh, the
 // gradient reaching the mean through the view direction (backward.cu:126-138).
+// dc[k] = d(rgb) / d(sh_k) for the unit view direction (x, y, z): the SH basis of the active degree (forward.cu:20-71,
+// backward.cu:60-123 dRGBdsh*).  Shared by the per-view SH backward below and by sh_grad_from_colors_kernel, which
+// rebuilds the SH gradients of OTHER ranks' views from their colour gradients with the very same arithmetic.
+template <int D>
+__device__ __forceinline__ void gs_sh_basis(const float x, const float y, const float z, float* dc)
+{
+	dc[0] = bSH_C0;
+	if (D > 0) {
+		dc[1] = -bSH_C1 * y; dc[2] = bSH_C1 * z; dc[3] = -bSH_C1 * x;
+		if (D > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z;
+			const float xy = x * y, yz = y * z, xz = x * z;
+			dc[4] = bSH_C2[0] * xy; dc[5] = bSH_C2[1] * yz;
+			dc[6] = bSH_C2[2] * (FMA(2.f, zz, -xx) - yy);
+			dc[7] = bSH_C2[3] * xz; dc[8] = bSH_C2[4] * (xx - yy);
+			if (D > 2) {
+				dc[9] = bSH_C3[0] * y * FMA(3.f, xx, -yy);
+				dc[10] = bSH_C3[1] * xy * z;
+				dc[11] = bSH_C3[2] * y * (FMA(4.f, zz, -xx) - yy);
+				dc[12] = bSH_C3[3] * z * FMA(-3.f, yy, FMA(-3.f, xx, 2.f * zz));
+				dc[13] = bSH_C3[4] * x * (FMA(4.f, zz, -xx) - yy);
+				dc[14] = bSH_C3[5] * z * (xx - yy);
+				dc[15] = bSH_C3[6] * x * FMA(-3.f, yy, xx);
+			}
+		}
+	}
+}
+
 template <int D>
 __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __restrict__ cam, uint32_t clamped,
                                                const float* __restrict__ dLc, const float* sh, float* dc, float* dRGB,
@@ -1101,11 +1129,8 @@ __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __re
 		for (int ch = 0; ch < 3; ch++) dRGB[ch] = dLc[ch] * (((clamped >> ch) & 1u) ? 0.f : 1.f);
 		float dRGBdx[3] = {0.f, 0.f, 0.f}, dRGBdy[3] = {0.f, 0.f, 0.f}, dRGBdz[3] = {0.f, 0.f, 0.f};
 #define SH(k) sh[(k) * 3 + ch]
-#define DSH(k, coef) dc[k] = (coef)
-		DSH(0, bSH_C0);
+		gs_sh_basis<D>(x, y, z, dc);
 		if (D > 0) {
-			const float d1_ = -bSH_C1 * y, d2_ = bSH_C1 * z, d3_ = -bSH_C1 * x;
-			DSH(1, d1_); DSH(2, d2_); DSH(3, d3_);
 #pragma unroll
 			for (int ch = 0; ch < 3; ch++) {
 				dRGBdx[ch] = -bSH_C1 * SH(3);
@@ -1115,10 +1140,6 @@ __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __re
 			if (D > 1) {
 				const float xx = x * x, yy = y * y, zz = z * z;
 				const float xy = x * y, yz = y * z, xz = x * z;
-				const float d4_ = bSH_C2[0] * xy, d5_ = bSH_C2[1] * yz;
-				const float d6_ = bSH_C2[2] * (FMA(2.f, zz, -xx) - yy);
-				const float d7_ = bSH_C2[3] * xz, d8_ = bSH_C2[4] * (xx - yy);
-				DSH(4, d4_); DSH(5, d5_); DSH(6, d6_); DSH(7, d7_); DSH(8, d8_);
 #pragma unroll
 				for (int ch = 0; ch < 3; ch++) {
 					dRGBdx[ch] += FMA(bSH_C2[4] * 2.f * x, SH(8), FMA(bSH_C2[3] * z, SH(7), FMA(bSH_C2[2] * 2.f * -x, SH(6), bSH_C2[0] * y * SH(4))));
@@ -1126,14 +1147,6 @@ __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __re
 					dRGBdz[ch] += FMA(bSH_C2[3] * x, SH(7), FMA(bSH_C2[2] * 2.f * 2.f * z, SH(6), bSH_C2[1] * y * SH(5)));
 				}
 				if (D > 2) {
-					const float d9_ = bSH_C3[0] * y * FMA(3.f, xx, -yy);
-					const float d10_ = bSH_C3[1] * xy * z;
-					const float d11_ = bSH_C3[2] * y * (FMA(4.f, zz, -xx) - yy);
-					const float d12_ = bSH_C3[3] * z * FMA(-3.f, yy, FMA(-3.f, xx, 2.f * zz));
-					const float d13_ = bSH_C3[4] * x * (FMA(4.f, zz, -xx) - yy);
-					const float d14_ = bSH_C3[5] * z * (xx - yy);
-					const float d15_ = bSH_C3[6] * x * FMA(-3.f, yy, xx);
-					DSH(9, d9_); DSH(10, d10_); DSH(11, d11_); DSH(12, d12_); DSH(13, d13_); DSH(14, d14_); DSH(15, d15_);
 #pragma unroll
 					for (int ch = 0; ch < 3; ch++) {
 						dRGBdx[ch] += FMA(bSH_C3[6] * SH(15) * 3.f, xx - yy,
@@ -1157,7 +1170,6 @@ __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __re
 			}
 		}
 #undef SH
-#undef DSH
 		const float ddx = FMA(dRGBdx[2], dRGB[2], FMA(dRGBdx[1], dRGB[1], dRGBdx[0] * dRGB[0]));
 		const float ddy = FMA(dRGBdy[2], dRGB[2], FMA(dRGBdy[1], dRGB[1], dRGBdy[0] * dRGB[0]));
 		const float ddz = FMA(dRGBdz[2], dRGB[2], FMA(dRGBdz[1], dRGB[1], dRGBdz[0] * dRGB[0]));
@@ -1181,7 +1193,12 @@ constexpr int gs_sh_row_floats(int deg, bool split)
 	return rf > 0 ? rf : 1;
 }
 
-template <int D, bool SPLIT>
+// COLORS (both SH kernels): the FACTORED form of the stage for the multi-GPU gradient exchange (gaustudio_amd/parallel.py
+// FactoredGradExchange): dL_dsh is not written at all; instead dL_dcolor is overwritten in place with dRGB, the
+// clamp-masked colour gradient the SH basis gets multiplied with (12 B per Gaussian and view travel instead of the
+// (D+1)^2 x 12 B of dL_dsh; sh_grad_from_colors_kernel rebuilds the sum over all views).  dL_dmeans gets its SH term
+// as usual.
+template <int D, bool SPLIT, bool COLORS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
     int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, const GsRec* __restrict__ recs,
@@ -1219,7 +1236,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
 		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
 #define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
-		if (SPLIT) {
+		if (COLORS) {
+			float* dcol = const_cast<float*>(dL_dcolor) + 3 * (size_t)idx;
+			dcol[0] = dRGB[0]; dcol[1] = dRGB[1]; dcol[2] = dRGB[2];
+		} else if (SPLIT) {
 			float* ddc = dL_dsh + 3 * (size_t)idx;
 			ddc[0] = OSH(0); ddc[1] = OSH(1); ddc[2] = OSH(2);
 #pragma unroll
@@ -1235,7 +1255,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 #undef OSH
 #pragma unroll
 		for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] += dmean_sh[i];
-	} else if (idx < P) {
+	} else if (idx < P && !COLORS) {
 		if (SPLIT) {
 			float* ddc = dL_dsh + 3 * (size_t)idx;
 			ddc[0] = ddc[1] = ddc[2] = 0.f;
@@ -1248,13 +1268,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 			for (int i = 0; i < RF; i++) row[i] = 0.f;
 		}
 	}
-	if (RF > 0) {
+	if (RF > 0 && !COLORS) {
 		__builtin_amdgcn_wave_barrier();
 		gs_wave_lds_to_rows<RFA>((SPLIT ? dL_dsh_rest : dL_dsh) + (size_t)g0 * RF, nrows, slab, lane);
 	}
 }
 
-template <int D, bool SPLIT>
+template <int D, bool SPLIT, bool COLORS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
     int g_base, int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs,
@@ -1266,7 +1286,23 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 	constexpr int NC = (D + 1) * (D + 1);
 	const bool vis = radii[idx] > 0;
 	float sh[NC * 3], dc[NC], dRGB[3], dmean_sh[3];
-	if (SPLIT) {
+	if (COLORS) {
+		if (!vis) return;                       // the row of dL_dcolor of a culled Gaussian is zero already
+		if (SPLIT) {
+			sh[0] = shs[3 * (size_t)idx]; sh[1] = shs[3 * (size_t)idx + 1]; sh[2] = shs[3 * (size_t)idx + 2];
+			const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
+#pragma unroll
+			for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
+		} else {
+			const float* shp = shs + (size_t)idx * M * 3;
+#pragma unroll
+			for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+		}
+		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
+		float* dcol = const_cast<float*>(dL_dcolor) + 3 * (size_t)idx;
+		dcol[0] = dRGB[0]; dcol[1] = dRGB[1]; dcol[2] = dRGB[2];
+	} else if (SPLIT) {
 		// split storage (f1): dL_dsh -> dL_df_dc [P,1,3], dL_dsh_rest -> dL_df_rest [P,M-1,3]
 		float* ddc = dL_dsh + 3 * (size_t)idx;
 		float* drest = dL_dsh_rest + (size_t)idx * (M - 1) * 3;
@@ -1353,7 +1389,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	grid = dim3((sh_g1 - sh_g0 + 255) / 256);
 	if (a.shs != nullptr) {
 #define GSR_LAUNCH_SH(DEG)                                                                                       \
-	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT>), grid, block, 0, s, sh_g0, sh_end, a.M, a.means3D, a.radii, a.shs, \
+	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT, COLORS>), grid, block, 0, s, sh_g0, sh_end, a.M, a.means3D, a.radii, a.shs, \
 	                   a.shs_rest, cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
 #define GSR_LAUNCH_SH_D()                        \
 		switch (a.D) {                            \
@@ -1364,34 +1400,45 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 		}
 		// cooperative (LDS-staged) variant: rows hold exactly the active degree and every streamed base is 16-B aligned
 		const bool split = a.shs_rest != nullptr;
+		const bool colors = (parts & GSR_PART_SH_COLORS) != 0;   // factored form: dRGB into dL_dcolor, no dL_dsh (not with split storage)
 		const int NCd = (a.D + 1) * (a.D + 1);
 		const float* stream_in = split ? a.shs_rest : a.shs;
-		const float* stream_out = split ? dL_dsh_rest : dL_dsh;
+		const float* stream_out = colors ? stream_in : (split ? dL_dsh_rest : dL_dsh);
 		const bool coop = a.M == NCd && (sh_g0 % 256 == 0) && ((uintptr_t)stream_in % 16 == 0) && ((uintptr_t)stream_out % 16 == 0) &&
 		                  (!split || NCd == 1 || (stream_in != nullptr && stream_out != nullptr));
-#define GSR_LAUNCH_SHC(DEG, SPL)                                                                                  \
-	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL>), grid, block,                                       \
+#define GSR_LAUNCH_SHC(DEG, SPL, COL)                                                                             \
+	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL, COL>), grid, block,                                  \
 	                   sizeof(float) * 256 * gs_row_stride<gs_sh_row_floats(DEG, SPL)>(), s, sh_g0, sh_end, \
 	                   a.means3D, a.radii, a.shs, a.shs_rest, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
-		if (coop && split) {
+		if (colors && coop) {
 			switch (a.D) {
-				case 0: GSR_LAUNCH_SHC(0, true); break;
-				case 1: GSR_LAUNCH_SHC(1, true); break;
-				case 2: GSR_LAUNCH_SHC(2, true); break;
-				default: GSR_LAUNCH_SHC(3, true); break;
+				case 0: GSR_LAUNCH_SHC(0, false, true); break;
+				case 1: GSR_LAUNCH_SHC(1, false, true); break;
+				case 2: GSR_LAUNCH_SHC(2, false, true); break;
+				default: GSR_LAUNCH_SHC(3, false, true); break;
+			}
+		} else if (colors) {
+			constexpr bool SPLIT = false, COLORS = true;
+			GSR_LAUNCH_SH_D()
+		} else if (coop && split) {
+			switch (a.D) {
+				case 0: GSR_LAUNCH_SHC(0, true, false); break;
+				case 1: GSR_LAUNCH_SHC(1, true, false); break;
+				case 2: GSR_LAUNCH_SHC(2, true, false); break;
+				default: GSR_LAUNCH_SHC(3, true, false); break;
 			}
 		} else if (coop) {
 			switch (a.D) {
-				case 0: GSR_LAUNCH_SHC(0, false); break;
-				case 1: GSR_LAUNCH_SHC(1, false); break;
-				case 2: GSR_LAUNCH_SHC(2, false); break;
-				default: GSR_LAUNCH_SHC(3, false); break;
+				case 0: GSR_LAUNCH_SHC(0, false, false); break;
+				case 1: GSR_LAUNCH_SHC(1, false, false); break;
+				case 2: GSR_LAUNCH_SHC(2, false, false); break;
+				default: GSR_LAUNCH_SHC(3, false, false); break;
 			}
 		} else if (split) {
-			constexpr bool SPLIT = true;
+			constexpr bool SPLIT = true, COLORS = false;
 			GSR_LAUNCH_SH_D()
 		} else {
-			constexpr bool SPLIT = false;
+			constexpr bool SPLIT = false, COLORS = false;
 			GSR_LAUNCH_SH_D()
 		}
 #undef GSR_LAUNCH_SHC
@@ -1400,6 +1447,93 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	} else if (dL_dsh != nullptr && a.M > 0) {
 		(void)hipMemsetAsync(dL_dsh + (size_t)sh_g0 * 3 * a.M, 0, sizeof(float) * 3 * (size_t)a.M * (size_t)(sh_g1 - sh_g0), s);
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// sh_grad_from_colors: dL_dsh[g] = sum over the N views r = 0 .. N-1 (in this order) of basis(dir_r(g)) (x) dRGB_r[g], the
+// SH gradient of a multi-view step rebuilt from the per-view clamp-masked colour gradients (what the COLORS form of the
+// SH stage leaves in dL_dcolor) and the views' camera centres.  Every term is computed with the arithmetic of the
+// per-view SH backward (gs_sh_basis, the same normalisation of the view direction), and the views are added in
+// ascending order: the result is bit-identical to running the N backwards on one device and letting autograd
+// accumulate them.  One lane per Gaussian; rows leave through LDS in 1 KiB pieces when they hold exactly the active
+// degree (gs_wave_lds_to_rows), else lane by lane.
+template <int D, bool COOP>
+__global__ __launch_bounds__(256) void sh_grad_from_colors_kernel(int P, int M, int N, const float* __restrict__ means3D,
+                                                                  const float* __restrict__ campos,   // [N,3]
+                                                                  const float* __restrict__ colors,   // [N,P,3]
+                                                                  float* __restrict__ dL_dsh)
+{
+	extern __shared__ __attribute__((aligned(16))) float sh_slab[];
+	constexpr int NC = (D + 1) * (D + 1);
+	constexpr int RF = NC * 3;
+	constexpr int RFP = gs_row_stride<RF>();
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int g0 = blockIdx.x * 256 + wv * 64;
+	const int nrows = min(64, P - g0);
+	if (nrows <= 0) return;   // wave-uniform
+	float acc[RF];
+#pragma unroll
+	for (int i = 0; i < RF; i++) acc[i] = 0.f;
+	if (idx < P) {
+		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+		bool first = true;
+		for (int r = 0; r < N; r++) {
+			const float* c = colors + ((size_t)r * P + idx) * 3;
+			const float c0 = c[0], c1 = c[1], c2 = c[2];
+			if (c0 == 0.f && c1 == 0.f && c2 == 0.f) continue;   // culled in view r (or no gradient): contributes +0
+			const float3 d = {m.x - campos[3 * r], m.y - campos[3 * r + 1], m.z - campos[3 * r + 2]};
+			const float len = sqrtf(FMA(d.z, d.z, FMA(d.y, d.y, d.x * d.x)));
+			float dc[NC];
+			gs_sh_basis<D>(d.x / len, d.y / len, d.z / len, dc);
+			const float cc[3] = {c0, c1, c2};
+			if (first) {
+#pragma unroll
+				for (int i = 0; i < RF; i++) acc[i] = dc[i / 3] * cc[i % 3];
+				first = false;
+			} else {
+#pragma unroll
+				for (int i = 0; i < RF; i++) acc[i] += dc[i / 3] * cc[i % 3];
+			}
+		}
+	}
+	if (COOP) {
+		float* slab = sh_slab + wv * 64 * RFP;
+		float* row = slab + lane * RFP;
+		if (RF % 4 == 0) {
+#pragma unroll
+			for (int i = 0; i < RF / 4; i++)
+				reinterpret_cast<float4*>(row)[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+		} else {
+#pragma unroll
+			for (int i = 0; i < RF; i++) row[i] = acc[i];
+		}
+		__builtin_amdgcn_wave_barrier();
+		gs_wave_lds_to_rows<RF>(dL_dsh + (size_t)g0 * RF, nrows, slab, lane);
+	} else if (idx < P) {
+		float* dsh = dL_dsh + (size_t)idx * M * 3;
+#pragma unroll
+		for (int i = 0; i < RF; i++) dsh[i] = acc[i];
+		for (int i = RF; i < M * 3; i++) dsh[i] = 0.f;   // coefficients above the active degree
+	}
+}
+
+void launch_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, const float* campos, const float* colors,
+                                float* dL_dsh, hipStream_t s)
+{
+	const dim3 grid((P + 255) / 256), block(256);
+	const bool coop = M == (D + 1) * (D + 1) && ((uintptr_t)dL_dsh % 16 == 0);
+#define GSR_LAUNCH_SGC(DEG, CO)                                                                                    \
+	hipLaunchKernelGGL((sh_grad_from_colors_kernel<DEG, CO>), grid, block,                                             \
+	                   (CO) ? sizeof(float) * 256 * gs_row_stride<(DEG + 1) * (DEG + 1) * 3>() : 0, s, P, M, N, means3D, campos, \
+	                   colors, dL_dsh)
+	switch (D) {
+		case 0: if (coop) GSR_LAUNCH_SGC(0, true); else GSR_LAUNCH_SGC(0, false); break;
+		case 1: if (coop) GSR_LAUNCH_SGC(1, true); else GSR_LAUNCH_SGC(1, false); break;
+		case 2: if (coop) GSR_LAUNCH_SGC(2, true); else GSR_LAUNCH_SGC(2, false); break;
+		default: if (coop) GSR_LAUNCH_SGC(3, true); else GSR_LAUNCH_SGC(3, false); break;
+	}
+#undef GSR_LAUNCH_SGC
 }
 
 }  // namespace gsr

@@ -131,19 +131,11 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
 	__shared__ uint32_t lkeys[GSR_TSDF_LNS];
 	__shared__ unsigned long long lvals[GSR_TSDF_LNS];
 	__shared__ int s_org[3];
+	__shared__ int s_first;
 	const int tid = threadIdx.x;
 	for (int k = tid; k < GSR_TSDF_LNS; k += 256) { lkeys[k] = 0xffffffffu; lvals[k] = 0ull; }
+	if (tid == 0) { s_first = 256; s_org[0] = s_org[1] = s_org[2] = 0; }
 	const float inv_vs = 1.0f / voxel_size;
-	if (tid == 0) {
-		// centre of the local window: the voxel of the workgroup's first point (anything nearby would do)
-		const size_t i0 = (size_t)blockIdx.x * 256;
-		float fx = 0.f, fy = 0.f, fz = 0.f;
-		if (i0 < (size_t)N) { fx = points[3 * i0] * inv_vs; fy = points[3 * i0 + 1] * inv_vs; fz = points[3 * i0 + 2] * inv_vs; }
-		const bool ok = fabsf(fx) < 1.0e9f && fabsf(fy) < 1.0e9f && fabsf(fz) < 1.0e9f;   // false for NaN / inf as well
-		s_org[0] = ok ? (int)floorf(fx) : 0; s_org[1] = ok ? (int)floorf(fy) : 0; s_org[2] = ok ? (int)floorf(fz) : 0;
-	}
-	__syncthreads();
-	const int orgx = s_org[0] - 512, orgy = s_org[1] - 512, orgz = s_org[2] - 512;
 	int64_t cached_slot = -1;
 	int cbx = 0x7fffffff, cby = 0, cbz = 0;
 	const int i = blockIdx.x * 256 + tid;
@@ -153,8 +145,20 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
 		px = points[3 * (size_t)i]; py = points[3 * (size_t)i + 1]; pz = points[3 * (size_t)i + 2];
 		const float dx = px - ox, dy = py - oy, dz = pz - oz;
 		depth = sqrtf(dx * dx + dy * dy + dz * dz);
-		if (!(depth > 0.f) || !(depth < 3.0e38f)) active = false;   // degenerate / non-finite point
+		// degenerate / non-finite point.  A point AT the sensor origin is what depth2point makes of a masked pixel (depth 0):
+		// a whole depth map can be integrated without compacting the valid pixels first
+		if (!(depth > 0.f) || !(depth < 3.0e38f)) active = false;
 	}
+	__syncthreads();
+	// centre of the local window: the voxel of the workgroup's first ACTIVE point (anything nearby would do)
+	const bool windowable = active && fabsf(px * inv_vs) < 1.0e9f && fabsf(py * inv_vs) < 1.0e9f && fabsf(pz * inv_vs) < 1.0e9f;
+	if (windowable) atomicMin(&s_first, tid);
+	__syncthreads();
+	if (tid == s_first) {
+		s_org[0] = (int)floorf(px * inv_vs); s_org[1] = (int)floorf(py * inv_vs); s_org[2] = (int)floorf(pz * inv_vs);
+	}
+	__syncthreads();
+	const int orgx = s_org[0] - 512, orgy = s_org[1] - 512, orgz = s_org[2] - 512;
 	if (active) {
 		const float dx = px - ox, dy = py - oy, dz = pz - oz;
 		const float dirx = dx / depth, diry = dy / depth, dirz = dz / depth;

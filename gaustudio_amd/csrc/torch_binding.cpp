@@ -80,15 +80,26 @@ struct GradArena {
 	std::vector<int64_t> keys;   // data_ptr of [means3D, sh, scales, rotations]
 	int sh_chunks = 1;
 	py::object hook;             // None or callable
+	// factored gradient exchange (gaustudio_amd/parallel.py FactoredGradExchange): when defined, that backward runs its
+	// SH stage in the GSR_BWD_PART_SH_COLORS form -- the clamp-masked colour gradient [P,3] is written HERE (a slot of
+	// the all-gather buffer) and no dL_dsh is produced (the binding returns None for it)
+	torch::Tensor colors_out;
 };
 GradArena& g_arena = *new GradArena();   // never destroyed: holds a Python object, must not outlive the interpreter's teardown
 std::mutex g_arena_mutex;                // armed on the caller's thread, consumed on an autograd worker thread
 
 bool arena_matches(const GradArena& a, int64_t P, int64_t M, const torch::TensorOptions& fo, const int64_t keys[4])
 {
-	if (a.outs.size() != 5) return false;
+	const bool factored = a.colors_out.defined();
+	if (a.outs.size() != 5 && !(factored && a.outs.empty())) return false;
+	if (factored) {
+		const torch::Tensor& t = a.colors_out;
+		if (t.sizes() != at::IntArrayRef({P, 3}) || t.device() != fo.device() || t.scalar_type() != torch::kFloat32 || !t.is_contiguous())
+			return false;
+	}
 	const std::vector<int64_t> shapes[5] = {{P, 3}, {P, M, 3}, {P, 1}, {P, 3}, {P, 4}};
-	for (int i = 0; i < 5; i++) {
+	for (int i = 0; i < (int)a.outs.size(); i++) {
+		if (factored && i == 1) continue;   // no dL_dsh in the factored form
 		const torch::Tensor& t = a.outs[i];
 		if (!t.defined() || t.sizes() != at::IntArrayRef(shapes[i]) || t.device() != fo.device() ||
 		    t.scalar_type() != torch::kFloat32 || !t.is_contiguous())
@@ -114,7 +125,8 @@ void check_small(const torch::Tensor& t, int64_t n, const char* name)
 
 }  // namespace
 
-void set_grad_arena(std::vector<torch::Tensor> outs, std::vector<int64_t> keys, int sh_chunks, py::object hook)
+void set_grad_arena(std::vector<torch::Tensor> outs, std::vector<int64_t> keys, int sh_chunks, py::object hook,
+                    c10::optional<torch::Tensor> colors_out)
 {
 	TORCH_CHECK(outs.empty() || outs.size() == 5, "set_grad_arena expects [means3D, sh, opacity, scales, rotations] gradients or []");
 	TORCH_CHECK(keys.empty() || keys.size() == 4, "set_grad_arena keys: data_ptr of [means3D, sh, scales, rotations] or []");
@@ -123,6 +135,27 @@ void set_grad_arena(std::vector<torch::Tensor> outs, std::vector<int64_t> keys, 
 	g_arena.keys = std::move(keys);
 	g_arena.sh_chunks = sh_chunks > 1 ? sh_chunks : 1;
 	g_arena.hook = std::move(hook);
+	g_arena.colors_out = colors_out.has_value() ? *colors_out : torch::Tensor();
+}
+
+// the other half of the factored exchange: dL_dsh[P,M,3] from every view's colour gradients (include/gsrast.h)
+void sh_grad_from_colors(const torch::Tensor& means3D, const torch::Tensor& campos, const torch::Tensor& colors, int degree,
+                         torch::Tensor& dL_dsh)
+{
+	require_device(means3D, "means3D");
+	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+	const int64_t P = means3D.size(0);
+	TORCH_CHECK(dL_dsh.dim() == 3 && dL_dsh.size(0) == P && dL_dsh.size(2) == 3 && dL_dsh.is_contiguous() && dL_dsh.is_cuda() &&
+	            dL_dsh.scalar_type() == torch::kFloat32, "dL_dsh must be a contiguous float32 [P,M,3] device tensor");
+	TORCH_CHECK(colors.dim() == 3 && colors.size(1) == P && colors.size(2) == 3 && colors.is_contiguous() && colors.is_cuda() &&
+	            colors.scalar_type() == torch::kFloat32, "colors must be a contiguous float32 [N,P,3] device tensor");
+	const int64_t N = colors.size(0);
+	TORCH_CHECK(campos.numel() == N * 3 && campos.is_cuda() && campos.is_contiguous() && campos.scalar_type() == torch::kFloat32,
+	            "campos must be a contiguous float32 [N,3] device tensor");
+	const auto m = means3D.contiguous();
+	const int rc = gsr_sh_grad_from_colors((int)P, degree, (int)dL_dsh.size(1), (int)N, fptr(m, "means3D"), fptr(campos, "campos"),
+	                                       fptr(colors, "colors"), dL_dsh.data_ptr<float>(), current_stream(means3D));
+	if (rc < 0) fail(rc);
 }
 
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -248,9 +281,10 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 		}
 	}
 	const bool in_arena = arena.outs.size() == 5;
+	const bool factored = arena.colors_out.defined() && M > 0 && sh.numel() != 0;
 	torch::Tensor dL_dmeans3D = in_arena ? arena.outs[0] : torch::empty({P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
-	torch::Tensor dL_dcolors = torch::empty({P, 3}, fo), dL_dcov3D = torch::empty({P, 6}, fo);
-	torch::Tensor dL_dsh = in_arena ? arena.outs[1] : torch::empty({P, M, 3}, fo);
+	torch::Tensor dL_dcolors = factored ? arena.colors_out : torch::empty({P, 3}, fo), dL_dcov3D = torch::empty({P, 6}, fo);
+	torch::Tensor dL_dsh = factored ? torch::Tensor() : (in_arena ? arena.outs[1] : torch::empty({P, M, 3}, fo));
 	torch::Tensor dL_dopacity = in_arena ? arena.outs[2] : torch::empty({P, 1}, fo);
 	torch::Tensor dL_dscales = in_arena ? arena.outs[3] : torch::empty({P, 3}, fo);
 	torch::Tensor dL_drotations = in_arena ? arena.outs[4] : torch::empty({P, 4}, fo);
@@ -266,13 +300,15 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 			    reinterpret_cast<const char*>(imageBuffer.data_ptr()), fptr(g_color, "dL_dout_color"),
 			    fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"), fptr(g_op, "dL_dout_final_opacity"),
 			    dL_dmeans2D.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
-			    dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr, nullptr,
+			    dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), (M && !factored) ? dL_dsh.data_ptr<float>() : nullptr, nullptr,
 			    dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(), reinterpret_cast<char*>(scratch.data_ptr()),
 			    debug ? 1 : 0, current_stream(means3D));
 			if (rc < 0) fail(rc);
 		};
-		const bool chunked = in_arena && arena.sh_chunks > 1 && !arena.hook.is_none() && M > 0 && sh.numel() != 0;
-		if (!chunked) {
+		const bool chunked = in_arena && !factored && arena.sh_chunks > 1 && !arena.hook.is_none() && M > 0 && sh.numel() != 0;
+		if (factored) {
+			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH | GSR_BWD_PART_SH_COLORS, 0, P);
+		} else if (!chunked) {
 			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P);
 		} else {
 			// SH stage in Gaussian ranges (multiples of 256): the hook sees each range as soon as it is enqueued
@@ -414,7 +450,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 	      py::arg("imageBuffer"), py::arg("debug"), py::arg("options") = no_opts);
 	m.def("mark_visible", &markVisible);
 	m.def("set_grad_arena", &set_grad_arena, py::arg("outs"), py::arg("keys") = std::vector<int64_t>(), py::arg("sh_chunks") = 1,
-	      py::arg("hook") = py::none());
+	      py::arg("hook") = py::none(), py::arg("colors_out") = py::none());
+	m.def("sh_grad_from_colors", &sh_grad_from_colors, py::arg("means3D"), py::arg("campos"), py::arg("colors"), py::arg("degree"),
+	      py::arg("dL_dsh"));
 	m.def("rasterize_gaussians_raw", &RasterizeGaussiansRaw, py::arg("background"), py::arg("means3D"), py::arg("f_dc"),
 	      py::arg("f_rest"), py::arg("raw_opacity"), py::arg("raw_scales"), py::arg("raw_rotations"), py::arg("scale_modifier"),
 	      py::arg("activation_flags"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"),

@@ -1,5 +1,7 @@
 """Multi-GPU data parallelism for the rasterizer: one camera per GPU, replicated Gaussians, ONE logical
-all-reduce of the per-Gaussian gradients after backward (BASELINE.json north_star).
+exchange of the per-Gaussian gradients after backward (BASELINE.json north_star): either the dense
+all-reduce of the flat 236 B/Gaussian buffer (FlatGradBucket / allreduce_gaussian_grads) or its factored form
+(FactoredGradExchange: 44 B/Gaussian all-reduced + 12 B/Gaussian/view all-gathered, same sums).
 
 The reference has no distributed code at all ("Collective / NCCL call sites: none");
 this is new design for an 8 x MI355X node: one process per GPU, torch.distributed backend "nccl"
@@ -193,6 +195,162 @@ def allreduce_gaussian_grads(bucket: FlatGradBucket, group: Optional[dist.Proces
     if work is None or not async_op:
         bucket.unpack()
     return work
+
+
+# ---- the factored exchange: 12 B per Gaussian and view + 44 B per Gaussian instead of 236 B per Gaussian -----------------
+GEOMETRY_ROLES = ("means3D", "opacities", "scales", "rotations")     # 3 + 1 + 3 + 4 = 11 floats per Gaussian
+
+
+class FactoredGradExchange:
+    """The gradient exchange of a multi-GPU step in FACTORED form (new design).
+
+    81 % of the dense payload is dL_dsh, and dL_dsh of ONE view is an outer product: basis(view direction) (x) dRGB, where
+    dRGB is the Gaussian's clamp-masked colour gradient (3 floats) and the direction follows from the Gaussian's mean and
+    the view's camera centre -- both known on every rank.  So instead of all-reducing (D+1)^2 x 12 B per Gaussian, every
+    view's dRGB[P,3] is ALL-GATHERED (12 B per Gaussian and view) and each rank rebuilds
+    sum_views basis (x) dRGB itself (`gsr_sh_grad_from_colors`, same arithmetic as the per-view SH backward, views added
+    in ascending order: bit-identical to accumulating the views on one device); only the geometry block
+    [means3D 3 | opacity 1 | scales 3 | rotations 4] = 44 B per Gaussian is all-reduced.  At 8 ranks x 1 view a rank
+    moves 2 x 7/8 x 44 + 7 x 12 = 161 B per Gaussian instead of 2 x 7/8 x 236 = 413 B, independent of the SH degree.
+
+        fx = FactoredGradExchange(params_by_role, views_per_rank=V, sh_degree=D)
+        for v, cam in enumerate(my_views):
+            fx.arm(v); out = rasterizer_of(cam)(...); loss(out).backward()     # gradients accumulate as usual, no dL_dsh
+        fx.exchange(campos_of_all_views)      # [world * V, 3], global view order: rank-major
+        # now p.grad of all five parameters holds the sum over all world * V views
+
+    `compact=True` additionally exchanges only the Gaussians that are visible (radii > 0 <=> a non-zero colour OR
+    geometry gradient row) in at least one view of the step: one bit-mask all-reduce, then compacted buffers; worth it
+    for real scenes where a view touches a fraction of the Gaussians (it costs a host synchronisation for the row count).
+    Runs on CPU tensors with the "gloo" backend when `sh_from_colors` is given (tests; the product kernel is HIP only)."""
+
+    def __init__(self, params_by_role: dict, views_per_rank: int = 1, sh_degree: int = 3, group=None, compact: bool = False,
+                 sh_from_colors=None):
+        if set(params_by_role) != set(ARENA_ROLES):
+            raise ValueError(f"params_by_role must name exactly {ARENA_ROLES}")
+        self.p = dict(params_by_role)
+        self.group = group
+        self.world = dist.get_world_size(group) if _multi(group) else 1
+        self.rank = dist.get_rank(group) if _multi(group) else 0
+        self.V = int(views_per_rank)
+        self.D = int(sh_degree)
+        self.compact = bool(compact)
+        self._sh_from_colors = sh_from_colors
+        means = self.p["means3D"]
+        dev, self.P = means.device, means.shape[0]
+        for t in self.p.values():
+            if t.dtype != torch.float32 or t.device != dev:
+                raise ValueError("all parameters must be float32 on one device")
+        self.M = self.p["shs"].shape[1]
+        self._geo_sizes = [self.p[r].numel() for r in GEOMETRY_ROLES]
+        self.geo = torch.zeros(sum(self._geo_sizes), dtype=torch.float32, device=dev)
+        self.colors = torch.zeros((self.world * self.V, self.P, 3), dtype=torch.float32, device=dev)
+        self.sh_grad = torch.empty((self.P, self.M, 3), dtype=torch.float32, device=dev)
+        self.stats = {"steps": 0, "rows_exchanged": 0}
+
+    def geo_views(self):
+        out, o = {}, 0
+        for r, n in zip(GEOMETRY_ROLES, self._geo_sizes):
+            out[r] = self.geo[o:o + n].view_as(self.p[r])
+            o += n
+        return out
+
+    # wire sizes of one step (per rank): what goes out and what comes in
+    @property
+    def geometry_bytes(self):
+        return self.geo.numel() * 4
+
+    @property
+    def color_bytes_per_rank(self):
+        return self.V * self.P * 12
+
+    def payload(self):
+        n = max(1, self.stats["steps"])
+        rows = self.stats["rows_exchanged"] / n if self.compact else self.P
+        sent = rows * (44 + 12 * self.V)
+        return {"payload_bytes_per_rank": int(sent), "allreduce_bytes": int(rows * 44), "allgather_bytes_sent": int(rows * 12 * self.V),
+                "allgather_bytes_received": int(rows * 12 * self.V * (self.world - 1)),
+                "dense_payload_bytes_per_rank": self.P * (self.M * 3 + 11) * 4, "rows_per_step": rows, "rows_total": self.P,
+                "compacted": self.compact}
+
+    def arm(self, v: int):
+        """Before the forward + backward of this rank's local view v: its colour gradients go to slot rank * V + v of the
+        all-gather buffer.  The first view's geometry gradients are born in the all-reduce buffer when no p.grad exists
+        yet; later views accumulate into them through autograd as usual."""
+        from . import _C
+        slot = self.colors[self.rank * self.V + v]
+        fresh = all(self.p[r].grad is None for r in ARENA_ROLES)
+        outs = []
+        if v == 0 and fresh and self.geo.is_cuda:
+            g = self.geo_views()
+            outs = [g["means3D"], self.sh_grad, g["opacities"], g["scales"], g["rotations"]]     # slot 1 (dL_dsh) is ignored
+        keys = [int(self.p[r].data_ptr()) for r in _KEY_ROLES]
+        _C.set_grad_arena(outs, keys, 1, None, colors_out=slot)
+
+    def exchange(self, campos_all: torch.Tensor):
+        """campos_all [world * V, 3]: the camera centres of ALL views of this step in global order (rank-major) -- every
+        rank knows the step's camera list.  Afterwards p.grad of all five parameters is the sum over all views."""
+        P, V, W = self.P, self.V, self.world
+        views = self.geo_views()
+        for r in GEOMETRY_ROLES:                              # pack what autograd did not put there itself
+            p, v = self.p[r], views[r]
+            if p.grad is None:
+                v.zero_()
+            elif not (p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape and p.grad.is_contiguous()):
+                v.copy_(p.grad)
+        multi = W > 1
+        mine = self.colors[self.rank * V:(self.rank + 1) * V]
+        rows = None
+        if multi and self.compact:
+            # rows with a non-zero gradient in ANY view of ANY rank (a culled Gaussian's rows are exactly zero)
+            live = (mine.abs().amax(dim=(0, 2)) > 0) | (self.geo_views()["means3D"].abs().amax(dim=1) > 0)
+            mask = live.to(torch.int32)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+            rows = torch.nonzero(mask, as_tuple=False).flatten()
+            K = rows.numel()                                  # host synchronisation: the buffers below are sized by it
+            geo_rows = torch.cat([views[r].reshape(P, -1)[rows] for r in GEOMETRY_ROLES], dim=1).contiguous()       # [K,11]
+            col = torch.zeros((W * V, K, 3), dtype=torch.float32, device=self.geo.device)
+            col[self.rank * V:(self.rank + 1) * V] = mine[:, rows]
+            w1 = _all_gather_in_place(col, self.rank, V, self.group)
+            w2 = dist.all_reduce(geo_rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w1.wait()
+            self.colors.zero_()
+            self.colors[:, rows] = col
+            w2.wait()
+            o = 0
+            for r in GEOMETRY_ROLES:
+                n = views[r].reshape(P, -1).shape[1]
+                views[r].reshape(P, -1)[rows] = geo_rows[:, o:o + n]
+                o += n
+            self.stats["rows_exchanged"] += K
+        elif multi:
+            w1 = _all_gather_in_place(self.colors, self.rank, V, self.group)
+            w2 = dist.all_reduce(self.geo, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w1.wait()
+        # the SH gradient of the whole step from every view's colour gradient (runs while the geometry all-reduce is in flight)
+        fn = self._sh_from_colors
+        if fn is None:
+            from . import _C
+            fn = _C.sh_grad_from_colors
+        fn(self.p["means3D"].detach(), campos_all.to(self.geo.device, torch.float32).contiguous(), self.colors, self.D, self.sh_grad)
+        if multi and not self.compact:
+            w2.wait()
+        for r in GEOMETRY_ROLES:
+            self.p[r].grad = views[r]
+        self.p["shs"].grad = self.sh_grad
+        self.stats["steps"] += 1
+
+
+def _all_gather_in_place(buf: torch.Tensor, rank: int, V: int, group):
+    """All-gathers buf[world * V, ...] whose rows [rank * V, (rank + 1) * V) hold this rank's contribution; returns a work
+    handle.  RCCL gathers in place (the input is the rank's slice of the output)."""
+    flat = buf.view(-1)
+    n = flat.numel() // (dist.get_world_size(group))
+    try:
+        return dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n], group=group, async_op=True)
+    except (RuntimeError, NotImplementedError):              # a backend without the tensor form
+        chunks = [flat[i * n:(i + 1) * n] for i in range(dist.get_world_size(group))]
+        return dist.all_gather(chunks, flat[rank * n:(rank + 1) * n].clone(), group=group, async_op=True)
 
 
 def shard_views(views: Sequence, rank: Optional[int] = None, world_size: Optional[int] = None):

@@ -155,6 +155,11 @@ int gsr_backward(int P, int D, int M, int R,
  * term to dL_dmean3D; needs MAIN to have run on the same buffers).  gsr_backward == both parts over [0, P). */
 #define GSR_BWD_PART_MAIN 1
 #define GSR_BWD_PART_SH 2
+/* with GSR_BWD_PART_SH (gsr_backward_ex only): the SH stage in its FACTORED form for the multi-GPU gradient exchange
+ * (gaustudio_amd/parallel.py FactoredGradExchange) -- dL_dsh is not written (may be NULL); dL_dcolor[P,3] is overwritten
+ * in place with dRGB, the clamp-masked colour gradient the SH basis is multiplied with (backward.cu:35-40); dL_dmean3D
+ * gets its SH term as usual.  SH colours in one [P,M,3] tensor only. */
+#define GSR_BWD_PART_SH_COLORS 4
 int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int R, const float* background, int width,
                        int height, const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                        float scale_modifier, const float* rotations, const float* cov3D_precomp, float tan_fovx,
@@ -163,6 +168,15 @@ int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int
                        const float* dL_dpix_median_depth, const float* dL_dpix_final_opacity, float* dL_dmean2D,
                        float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                        float* dL_dscale, float* dL_drot, char* scratch, int debug, void* stream);
+
+/* The other half of the factored exchange: dL_dsh[P,M,3] = sum over the N views r = 0 .. N-1, in this order, of
+ * basis_D(normalize(means3D[g] - campos[r])) (x) colors[r][g], i.e. the SH gradient of a multi-view step rebuilt from
+ * the per-view dRGB (what GSR_BWD_PART_SH_COLORS leaves in dL_dcolor; rows of Gaussians culled in a view are zero there)
+ * and the views' camera centres campos[N,3] (device memory).  Same arithmetic as the per-view SH backward and a fixed
+ * order of views: bit-identical to accumulating the N per-view gradients one after the other.  colors[N,P,3].
+ * (new; the reference has no multi-GPU path at all) */
+int gsr_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, const float* campos, const float* colors,
+                            float* dL_dsh, void* stream);
 
 /* Process-wide tunables (also read from the environment at load: GSR_TIGHT_BINNING, GSR_CULL, GSR_FWD_VARIANT,
  * GSR_BWD_VARIANT, GSR_SPECULATIVE).  The first five never change a bit of the forward (the backward variants add the

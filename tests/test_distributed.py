@@ -123,6 +123,100 @@ def test_chunked_overlapped_reduction_equals_one_allreduce(tmp_path):
         assert torch.equal(outs[0][k], want) and torch.equal(outs[1][k], want), k
 
 
+# ------------------------------------------------------------------------------------------------ factored exchange
+def _sh_basis_torch(d, D):
+    """SH basis of unit directions d[...,3] up to degree D (forward.cu:20-71 constants), float32 torch: the test-side
+    stand-in for gsr_sh_grad_from_colors on CPU tensors."""
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    C0, C1 = 0.28209479177387814, 0.4886025119029199
+    C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+    C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435)
+    b = [torch.full_like(x, C0)]
+    if D > 0:
+        b += [-C1 * y, C1 * z, -C1 * x]
+    if D > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        b += [C2[0] * xy, C2[1] * yz, C2[2] * (2 * zz - xx - yy), C2[3] * xz, C2[4] * (xx - yy)]
+    if D > 2:
+        b += [C3[0] * y * (3 * xx - yy), C3[1] * xy * z, C3[2] * y * (4 * zz - xx - yy), C3[3] * z * (2 * zz - 3 * xx - 3 * yy),
+              C3[4] * x * (4 * zz - xx - yy), C3[5] * z * (xx - yy), C3[6] * x * (xx - 3 * yy)]
+    return torch.stack(b, dim=-1)
+
+
+def _sh_from_colors_torch(means3D, campos, colors, D, out):
+    """out[P,M,3] = sum over views (ascending) of basis(dir) (x) colors[r] -- what gsr_sh_grad_from_colors computes."""
+    out.zero_()
+    nc = (D + 1) ** 2
+    for r in range(colors.shape[0]):
+        d = means3D - campos[r]
+        d = d / d.norm(dim=1, keepdim=True)
+        out[:, :nc] += _sh_basis_torch(d, D)[:, :, None] * colors[r][:, None, :]
+    return out
+
+
+def _factored_inputs(world, V, P=700, M=16):
+    """Per-view colour gradients and geometry gradients (about a third of the Gaussians culled per view: zero rows)."""
+    views = []
+    for gview in range(world * V):
+        g = torch.Generator().manual_seed(900 + gview)
+        vis = (torch.rand(P, generator=g) > 0.35).float()[:, None]
+        views.append(dict(colors=torch.randn(P, 3, generator=g) * vis, means3D=torch.randn(P, 3, generator=g) * vis,
+                          opacities=torch.randn(P, 1, generator=g) * vis, scales=torch.randn(P, 3, generator=g) * vis,
+                          rotations=torch.randn(P, 4, generator=g) * vis))
+    g = torch.Generator().manual_seed(7)
+    means = torch.randn(P, 3, generator=g)
+    campos = torch.randn(world * V, 3, generator=g) * 5 + 20.0
+    return views, means, campos, (P, M)
+
+
+def _worker_factored(rank, world, port, out_dir, V, compact):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        views, means, campos, (P, M) = _factored_inputs(world, V)
+        shapes = dict(means3D=(P, 3), shs=(P, M, 3), opacities=(P, 1), scales=(P, 3), rotations=(P, 4))
+        params = {k: (means.clone() if k == "means3D" else torch.zeros(shp)).requires_grad_(True) for k, shp in shapes.items()}
+        fx = parallel.FactoredGradExchange(params, views_per_rank=V, sh_degree=3, compact=compact, sh_from_colors=_sh_from_colors_torch)
+        assert fx.world == world and fx.colors.shape == (world * V, P, 3)
+        # what the armed backwards of this rank's V views leave behind: colour gradients in their slots, geometry
+        # gradients accumulated in p.grad
+        for v in range(V):
+            gv = views[rank * V + v]
+            fx.colors[rank * V + v].copy_(gv["colors"])
+            for k in parallel.GEOMETRY_ROLES:
+                params[k].grad = gv[k].clone() if params[k].grad is None else params[k].grad + gv[k]
+        fx.exchange(campos)
+        pay = fx.payload()
+        assert pay["dense_payload_bytes_per_rank"] == P * 59 * 4
+        if not compact:
+            assert pay["payload_bytes_per_rank"] == P * (44 + 12 * V)
+        else:
+            assert pay["rows_per_step"] < P                     # some Gaussians are culled in every view
+        torch.save({k: p.grad.clone() for k, p in params.items()}, os.path.join(out_dir, f"fx_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("V,compact", [(1, False), (2, False), (1, True)])
+def test_factored_exchange_equals_dense_accumulation(tmp_path, V, compact):
+    """FactoredGradExchange (all-gather of per-view colour gradients + all-reduce of the geometry block + local rebuild of the
+    SH gradient) == the sum over all world * V views of the dense per-view gradients, on every rank; with and without
+    visible-row compaction."""
+    world = 2
+    mp.spawn(_worker_factored, args=(world, _free_port(), str(tmp_path), V, compact), nprocs=world, join=True)
+    views, means, campos, (P, M) = _factored_inputs(world, V)
+    want = {k: sum(v[k] for v in views) for k in parallel.GEOMETRY_ROLES}
+    want["shs"] = _sh_from_colors_torch(means, campos, torch.stack([v["colors"] for v in views]), 3, torch.zeros(P, M, 3))
+    got = [torch.load(os.path.join(tmp_path, f"fx_rank{r}.pt")) for r in range(world)]
+    for k in want:
+        assert torch.equal(got[0][k], got[1][k]), k                           # replicated result
+        tol = 0.0 if k == "shs" else 1e-6 * float(want[k].abs().max())         # geometry: (a + b) + c vs the ring's order
+        assert float((got[0][k] - want[k]).abs().max()) <= tol, k
+    assert float(want["shs"].abs().max()) > 0
+
+
 def test_bucket_roundtrip_and_view_sharding_without_process_group():
     ps = [torch.randn(5, 3, requires_grad=True), torch.randn(5, 16, 3, requires_grad=True), torch.randn(5, 1, requires_grad=True)]
     b = parallel.FlatGradBucket(ps)
@@ -199,3 +293,86 @@ def test_two_ranks_real_kernels_gradients_born_in_the_bucket(tmp_path):
         torch.autograd.backward([out[0], out[2], out[3], out[4]], g)
     for k, a in zip(KEYS, got[0]):
         assert torch.equal(a, params[k].grad.cpu()), k
+
+
+# ------------------------------------------------------------------------------------------------ GPU: factored exchange with the real kernels
+def _accumulate_views_dense(sc, cams, dev, D=3):
+    """Both views one after the other in one process, autograd accumulating: the north star's reference for the exchange."""
+    from gaustudio_amd import GaussianRasterizationSettings, GaussianRasterizer
+    params = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in KEYS}
+    for cam in cams:
+        rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                           cam.viewmatrix.to(dev), cam.projmatrix.to(dev), D, cam.campos.to(dev), False, False)
+        out = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"]),
+                                     opacities=params["opacities"], shs=params["shs"], scales=params["scales"],
+                                     rotations=params["rotations"])
+        g = [t.to(dev) for t in scenes.make_output_grads(cam, seed=5)]
+        torch.autograd.backward([out[0], out[2], out[3], out[4]], g)
+    return {k: p.grad.cpu() for k, p in params.items()}
+
+
+def _factored_step(sc, my_cams, all_cams, dev, V, D=3, compact=False):
+    from gaustudio_amd import GaussianRasterizationSettings, GaussianRasterizer
+    params = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in KEYS}
+    fx = parallel.FactoredGradExchange(params, views_per_rank=V, sh_degree=D, compact=compact)
+    m2 = torch.zeros_like(params["means3D"])
+    for v, cam in enumerate(my_cams):
+        rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                           cam.viewmatrix.to(dev), cam.projmatrix.to(dev), D, cam.campos.to(dev), False, False)
+        fx.arm(v)
+        out = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=m2, opacities=params["opacities"], shs=params["shs"],
+                                     scales=params["scales"], rotations=params["rotations"])
+        g = [t.to(dev) for t in scenes.make_output_grads(cam, seed=5)]
+        torch.autograd.backward([out[0], out[2], out[3], out[4]], g)
+        assert params["shs"].grad is None                      # the factored backward produces no dL_dsh
+    if V >= 1 and fx.geo.is_cuda:
+        gv = fx.geo_views()
+        assert all(params[r].grad.data_ptr() == gv[r].data_ptr() for r in parallel.GEOMETRY_ROLES)   # born in the all-reduce buffer
+    fx.exchange(torch.stack([c.campos for c in all_cams]).to(dev))
+    return {k: p.grad.cpu() for k, p in params.items()}, fx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [0, 3])
+def test_factored_exchange_single_process_bit_equal(D):
+    """world_size 1, two local views: the factored path (colour gradients -> gsr_sh_grad_from_colors, geometry gradients
+    accumulated in the exchange buffer) gives bit for bit what plain autograd accumulation of the dense backward gives."""
+    dev = torch.device("cuda", 0)
+    sc, cams = _scene_and_cams(2)
+    want = _accumulate_views_dense(sc, cams, dev, D)
+    got, fx = _factored_step(sc, cams, cams, dev, V=2, D=D)
+    for k in KEYS:
+        assert torch.equal(got[k], want[k]), k
+    assert float(want["shs"].abs().max()) > 0
+    assert fx.payload()["payload_bytes_per_rank"] == 1500 * (44 + 24) and fx.payload()["dense_payload_bytes_per_rank"] == 1500 * 236
+
+
+def _gpu_worker_factored(rank, world, port, out_dir, compact):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # RCCL refuses two ranks on one device
+    try:
+        dev = torch.device("cuda", 0)
+        sc, cams = _scene_and_cams(world)
+        got, fx = _factored_step(sc, parallel.shard_views(cams), cams, dev, V=1, compact=compact)
+        if compact:
+            assert fx.payload()["rows_per_step"] <= 1500
+        torch.save(got, os.path.join(out_dir, f"fxgpu_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compact", [False, True])
+def test_two_ranks_factored_exchange_real_kernels(tmp_path, compact):
+    """Two ranks (gloo, one GPU), one camera each, the HIP kernels: after FactoredGradExchange every rank holds the gradients
+    of both views -- dL_dsh bit-identical to single-process accumulation (same arithmetic, same view order), the geometry
+    gradients equal (a sum of two terms commutes)."""
+    world = 2
+    mp.spawn(_gpu_worker_factored, args=(world, _free_port(), str(tmp_path), compact), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"fxgpu_rank{r}.pt")) for r in range(world)]
+    sc, cams = _scene_and_cams(world)
+    want = _accumulate_views_dense(sc, cams, torch.device("cuda", 0))
+    for k in KEYS:
+        assert torch.equal(got[0][k], got[1][k]), k
+        assert torch.equal(got[0][k], want[k]), k

@@ -141,6 +141,31 @@ def test_integrate_matches_oracle_exactly(carve):
 
 
 @pytest.mark.gpu
+def test_masked_pixels_at_the_sensor_origin_need_no_compaction():
+    """gs-extract-mesh compacts `points[~invalid_mask]` before vdbfusion (extract_mesh.py:110).  depth2point maps a masked
+    pixel (depth 0) onto the sensor origin, and the integrate kernel skips zero-length rays: a whole point map with the
+    invalid pixels left in gives the very same volume as the compacted one -- also when a workgroup's FIRST point is such a
+    pixel (the local aggregation window is centred on the first active point)."""
+    scans = _sphere_scan(n=30000, seed=5)
+    compacted = _gpu_volume(0.05, 0.2, scans, capacity=1 << 14)
+    rng = np.random.default_rng(2)
+    padded = []
+    for pts, o in scans:
+        keep = rng.random(len(pts) * 2) < 0.5                      # half of the "pixels" are masked
+        keep[::256] = False                                          # in particular every workgroup's first one
+        full = np.tile(np.asarray(o, np.float32), (len(keep), 1))
+        idx = np.nonzero(keep)[0][:len(pts)]
+        full[idx] = pts[:len(idx)]
+        padded.append((full, o))
+        # compare against integrating exactly the kept points
+    ref = _gpu_volume(0.05, 0.2, [(f[np.any(f != np.asarray(o, np.float32), axis=1)], o) for f, o in padded], capacity=1 << 14)
+    got = _gpu_volume(0.05, 0.2, padded, capacity=1 << 14)
+    for x, y in zip(ref.export_voxels(), got.export_voxels()):
+        assert torch.equal(x, y)
+    assert compacted.export_voxels()[0].shape[0] > 0
+
+
+@pytest.mark.gpu
 def test_integrate_is_order_independent_and_deterministic():
     scans = _sphere_scan(n=20000, seed=3)
     a = _gpu_volume(0.02, 0.08, scans, capacity=1 << 14)

@@ -2,15 +2,16 @@
 # One gpurun call: rocprofv3 kernel-trace stats + PMC passes (SQ / FETCH / WRITE, each in its own run, never combined
 # with tracing domains other than --kernel-trace) of bench.py on a workload; summaries land in gpurun_out/<name>/.
 # usage: bash tools/profile_session.sh <name> [workload=C3] [passes="stats sq fetch write"]
-name="${1:-prof}"; wl="${2:-C3}"; passes="${3:-stats sq fetch write}"
+name="${1:-prof}"; wl="${2:-C3}"; passes="${3:-stats sq fetch write}"; extra="${4:-}"   # extra: e.g. "--rotate-cameras 8"
 out="gpurun_out/$name"; mkdir -p "$out"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 root="$(pwd)"
-bench="python $root/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-ref-ab"
+bench="python $root/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-ref-ab --no-extras $extra"
 cd /tmp
 for p in $passes; do
   case $p in
     stats) timeout 600 rocprofv3 --kernel-trace --stats -d "$root/$out/stats" -o k -- $bench > "$root/$out/stats.log" 2>&1
+           grep '^{"metric"' "$root/$out/stats.log" | tail -1 > "$root/$out/${wl}_bench_line.json"
            db=$(ls "$root/$out"/stats/*/k_results.db "$root/$out"/stats/k_results.db 2>/dev/null | head -1)
            python "$root/tools/rocpd_summary.py" "$db" > "$root/$out/${wl}_kernel_stats.txt" 2>&1 ;;
     sq)    timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d "$root/$out/sq" -o k -- $bench > "$root/$out/sq.log" 2>&1
