@@ -107,20 +107,23 @@ bool query_device_ptr(const void* p)
 }
 
 // hipPointerGetAttributes is a driver query of several microseconds and sits on the hot path (camera matrices and
-// background of every call): the classification of the last few pointers is remembered per thread.  A training
-// loop passes the same few tensors every iteration; torch's caching allocator never hands a device address back
-// to the host heap, so a cached answer cannot go stale in a way that matters (a wrong "host" answer would read
-// the pointer on the host and fault loudly, never silently).
+// background of every call): the classification of the last few DEVICE pointers is remembered per thread (a training
+// loop passes the same few tensors every iteration).  Host pointers (gaustudio's CPU `bg`) are queried every time.
 bool is_device_ptr(const void* p)
 {
-	struct Entry { const void* p; bool dev; };
-	thread_local Entry cache[8] = {};
+	// only DEVICE answers are remembered: a device address handed out by hipMalloc / torch's caching allocator never
+	// becomes a host heap address (separate address ranges), whereas a freed host address may well be returned by a
+	// later malloc -- caching "host" would rest on allocator behaviour this library does not control
+	thread_local const void* cache[8] = {};
 	thread_local int next = 0;
-	for (const Entry& e : cache)
-		if (e.p == p && p != nullptr) return e.dev;
+	if (p == nullptr) return false;
+	for (const void* e : cache)
+		if (e == p) return true;
 	const bool dev = query_device_ptr(p);
-	cache[next] = Entry{p, dev};
-	next = (next + 1) & 7;
+	if (dev) {
+		cache[next] = p;
+		next = (next + 1) & 7;
+	}
 	return dev;
 }
 
@@ -511,10 +514,15 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		const int rc = launch_rest(Rb, need_long);
 		if (rc < 0) return rc;
 	}
-	// grow-only capacity with 25 % headroom for the next frame
+	// capacity for the next frame: this frame's count + 25 % headroom; a larger remembered capacity (one 4K close-up in
+	// between training views) decays by 1/8 per frame towards it instead of pinning 12-20 B x cap per live forward for
+	// the rest of the process
 	const uint32_t want = Rb + Rb / 4 + 4096u;
 	uint32_t cur = ds.cap.load();
-	while (cur < want && !ds.cap.compare_exchange_weak(cur, want)) {}
+	for (;;) {
+		const uint32_t next = cur < want ? want : (cur - (cur - want) / 8 > want + 4096u ? cur - (cur - want) / 8 : want);
+		if (next == cur || ds.cap.compare_exchange_weak(cur, next)) break;
+	}
 	ds.long_lists.store(need_long ? 1 : 0);
 	return (int)host->ref_rendered;
 }

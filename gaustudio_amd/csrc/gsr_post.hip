@@ -243,8 +243,9 @@ int gsr_masked_bilateral(const float* depth, const unsigned char* mask, int widt
 	int radius = d <= 0 ? (int)lrintf(sigma_space * 1.5f) : d / 2;
 	if (radius < 1) radius = 1;
 	const int dw = d <= 0 ? 2 * radius + 1 : d;   // the dilation window of the reference is d x d
-	const uint32_t init[2] = {0xffffffffu, 0u};
-	if (hipMemcpyAsync(scratch2, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) return GSR_ERR_HIP;
+	// min / max words: two 32-bit fills (a memcpy from a stack array would be a pageable, i.e. host-synchronous, H2D copy)
+	if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch2), (int)0xffffffffu, 1, s) != hipSuccess) return GSR_ERR_HIP;
+	if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch2 + 1), 0, 1, s) != hipSuccess) return GSR_ERR_HIP;
 	const dim3 grid((width + 63) / 64, (height + 3) / 4);
 	hipLaunchKernelGGL(bilateral_mask_minmax_kernel, grid, dim3(256), 0, s, depth, mask, width, height, dw, new_mask, scratch2);
 	hipLaunchKernelGGL(bilateral_filter_kernel, grid, dim3(256), 0, s, depth, new_mask, width, height, radius,

@@ -101,14 +101,25 @@ __device__ __forceinline__ bool tsdf_commit(unsigned long long* __restrict__ key
 	}
 	if (cached_slot < 0) { atomicOr(&status[0], 1u); return false; }   // table full
 	const int local = ((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7);
-	const unsigned long long prev = atomicAdd(&vox[(size_t)cached_slot * BLOCK_VOX + local], add);
-	if ((prev & 0xffffffull) + (add & 0xffffffull) > 0xffffffull) {
-		// the 24-bit observation count would overflow: undo the add (the carry would corrupt the sum field) and
-		// report it -- status bit 1; the voxel keeps what it had (at most 2^24 - 1 observations)
-		atomicAdd(&vox[(size_t)cached_slot * BLOCK_VOX + local], (unsigned long long)(-(long long)add));
-		atomicOr(&status[0], 2u);
+	unsigned long long* cell = &vox[(size_t)cached_slot * BLOCK_VOX + local];
+	// far from the limit of the 24-bit observation count (the common case: a plain read, stale by a few updates at worst,
+	// stays 2^20 observations away from it) one fire-and-forget add; near it the update is committed by compare-and-swap,
+	// so that an add which would carry into the sum field never becomes visible -- not even transiently to a concurrent
+	// update (an add-then-undo pair could be interleaved with another thread's check)
+	unsigned long long cur = *reinterpret_cast<volatile unsigned long long*>(cell);
+	if ((cur & 0xffffffull) + (add & 0xffffffull) < 0xf00000ull) {
+		atomicAdd(cell, add);
+		return true;
 	}
-	return true;
+	for (;;) {
+		if ((cur & 0xffffffull) + (add & 0xffffffull) > 0xffffffull) {
+			atomicOr(&status[0], 2u);   // the count is full: the observation is dropped, the voxel keeps what it had
+			return true;
+		}
+		const unsigned long long seen = atomicCAS(cell, cur, cur + add);
+		if (seen == cur) return true;
+		cur = seen;
+	}
 }
 
 // VDBFusion Alg. 1, one thread per point.  Plain float arithmetic, one rounding per operation (compiled with

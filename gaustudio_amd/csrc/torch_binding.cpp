@@ -24,7 +24,10 @@ char* resize_cb(void* ctx, size_t n)
 {
 	auto* t = static_cast<torch::Tensor*>(ctx);
 	try {
-		t->resize_({(long long)n});
+		// a grow replaces the storage instead of resize_()-ing it: resize_ would copy the old (dead) contents device to
+		// device -- the binning buffer is asked for twice when the speculated capacity turned out too small
+		if ((size_t)t->numel() < n) *t = torch::empty({(long long)n}, t->options());
+		else t->resize_({(long long)n});
 	} catch (...) {
 		return nullptr;
 	}
@@ -87,6 +90,13 @@ struct GradArena {
 };
 GradArena& g_arena = *new GradArena();   // never destroyed: holds a Python object, must not outlive the interpreter's teardown
 std::mutex g_arena_mutex;                // armed on the caller's thread, consumed on an autograd worker thread
+// A backward whose SH chunks were reduced from inside it (sh_chunks > 1) leaves gradients that are PARTLY summed over the
+// ranks already: a second local backward of the same parameters before the tail reduction would make autograd add a
+// local view into reduced data -- silently wrong sums.  The keys of such a backward stay "pending" until the caller
+// finishes the reduction (any set_grad_arena call, which parallel.allreduce_gaussian_grads issues); a backward of the
+// same parameters in between is refused.
+int64_t g_pending_keys[4] = {0, 0, 0, 0};
+bool g_pending = false;
 
 bool arena_matches(const GradArena& a, int64_t P, int64_t M, const torch::TensorOptions& fo, const int64_t keys[4])
 {
@@ -136,6 +146,7 @@ void set_grad_arena(std::vector<torch::Tensor> outs, std::vector<int64_t> keys, 
 	g_arena.sh_chunks = sh_chunks > 1 ? sh_chunks : 1;
 	g_arena.hook = std::move(hook);
 	g_arena.colors_out = colors_out.has_value() ? *colors_out : torch::Tensor();
+	g_pending = false;
 }
 
 // the other half of the factored exchange: dL_dsh[P,M,3] from every view's colour gradients (include/gsrast.h)
@@ -275,9 +286,17 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 		const int64_t keys[4] = {(int64_t)(uintptr_t)means3D_.data_ptr(), (int64_t)(uintptr_t)sh_.data_ptr(),
 		                         (int64_t)(uintptr_t)scales_.data_ptr(), (int64_t)(uintptr_t)rotations_.data_ptr()};
 		std::lock_guard<std::mutex> lock(g_arena_mutex);
+		TORCH_CHECK(!(g_pending && std::equal(keys, keys + 4, g_pending_keys)),
+		            "rasterize_gaussians_backward: the previous backward of these parameters reduced its SH gradients chunk by chunk "
+		            "(FlatGradBucket.arm(overlap_chunks > 1)) and the tail reduction has not run yet: another local backward now would "
+		            "be accumulated into partly reduced gradients.  Use overlap_chunks only for the LAST local view of a step.");
 		if (arena_matches(g_arena, P, M, fo, keys)) {   // one-shot, and only for the graph it was armed for
 			arena = std::move(g_arena);
 			g_arena = GradArena();
+			if (arena.sh_chunks > 1 && !arena.hook.is_none()) {
+				std::copy(keys, keys + 4, g_pending_keys);
+				g_pending = true;
+			}
 		}
 	}
 	const bool in_arena = arena.outs.size() == 5;

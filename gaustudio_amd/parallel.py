@@ -192,6 +192,8 @@ def allreduce_gaussian_grads(bucket: FlatGradBucket, group: Optional[dist.Proces
             work = None
     bucket._works = []
     bucket._reduced_upto = 0
+    if done > 0:
+        bucket.disarm()          # the chunk-reduced backward is complete now: its parameters may be differentiated again
     if work is None or not async_op:
         bucket.unpack()
     return work
@@ -375,8 +377,16 @@ def render_views_and_reduce(render_fn, views: Iterable, bucket: FlatGradBucket,
     multi = _multi(group)
     if multi:
         # the first view's gradients are born in the flat buffer; with a single local view its backward is also the
-        # last one, so its SH chunks may be reduced while it is still running
-        bucket.arm(overlap_chunks if len(views) == 1 else 0, group)
+        # last one, so its SH chunks may be reduced while it is still running.  Every rank must then issue the same chunk
+        # collectives: the ranks agree (one 4-byte MIN all-reduce) that all of them could arm, else nobody chunks.
+        chunks = overlap_chunks if len(views) == 1 else 0
+        armed = bucket.arm(chunks, group)
+        if chunks > 1:
+            ok = torch.tensor([1 if armed else 0], dtype=torch.int32, device=bucket.flat.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                bucket.disarm()
+                bucket.arm(0, group)
     try:
         outs = [render_fn(v) for v in views]
     finally:
