@@ -3,6 +3,8 @@
 #include "../../include/gsrast.h"
 #include "gsr_internal.h"
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -236,15 +238,57 @@ GsCtl* pinned_ctl()
 	return p;
 }
 
+// ---- optional roctx ranges around the stages: gsr_set_option("roctx", 1) / GSR_ROCTX=1 makes every
+// stage of gsr_forward / gsr_backward a named range in rocprofv3 --marker-trace / rocprof-sys timelines.  The marker
+// library is looked up at run time (libroctx64.so, then librocprofiler-sdk-roctx.so): no link-time dependency, and a
+// machine without it simply gets no ranges. ----
+std::atomic<int> g_opt_roctx{env_int("GSR_ROCTX", 0)};
+struct Roctx {
+	int (*push)(const char*) = nullptr;
+	int (*pop)() = nullptr;
+	Roctx()
+	{
+		for (const char* lib : {"libroctx64.so", "librocprofiler-sdk-roctx.so", "libroctx64.so.4"}) {
+			void* h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
+			if (!h) continue;
+			push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+			pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+			if (push && pop) return;
+			push = nullptr; pop = nullptr;
+		}
+	}
+};
+Roctx& roctx()
+{
+	static Roctx r;
+	return r;
+}
+
+// stage boundaries of one call: HIP events for the per-stage times (gsr_set_profiling) and, when asked for, roctx ranges
 struct Timer {
 	ProfSet* set;
 	hipStream_t s;
-	Timer(ProfSet* p, hipStream_t st) : set(p), s(st) {}
+	const char* const* names;
+	int k = 0;
+	bool open = false, ranges;
+	Timer(ProfSet* p, hipStream_t st, const char* const* stage_names = nullptr)
+	    : set(p), s(st), names(stage_names), ranges(stage_names != nullptr && g_opt_roctx.load() != 0 && roctx().push != nullptr) {}
+	~Timer()
+	{
+		if (open) roctx().pop();
+	}
 	void mark()
 	{
 		if (set && set->n < 6) (void)hipEventRecord(set->ev[set->n++], s);
+		if (ranges) {
+			if (open) roctx().pop();
+			open = names[k] != nullptr;
+			if (open) roctx().push(names[k++]);
+		}
 	}
 };
+const char* const kFwdStages[] = {"gsr.preprocess_fwd", "gsr.scan", "gsr.scatter", "gsr.sort", "gsr.composite_fwd", nullptr, nullptr, nullptr};
+const char* const kBwdStages[] = {"gsr.composite_bwd", "gsr.preprocess_bwd", nullptr, nullptr};
 
 __global__ __launch_bounds__(256) void fill_empty_outputs_kernel(size_t HW, float* out_color, float* out_depth,
                                                                  float* out_median, float* out_opacity)
@@ -410,7 +454,7 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + il.n_contrib);
 	uint32_t* med_pos = reinterpret_cast<uint32_t*>(img + il.med_pos);
 
-	Timer tm(prof_next(g_fwd_log), s);
+	Timer tm(prof_next(g_fwd_log), s, kFwdStages);
 	// control words + tile counters, then the camera block and the options this call runs with (one tiny launch)
 	HIP_TRY(hipMemsetAsync(img + il.ctl, 0, il.final_T - il.ctl, s));   // ctl + ranges + tile_count
 	{
@@ -654,7 +698,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 
 	// The background is re-staged here because the reference reads the backward's own `background`
 	// argument (backward.cu:584-587), which the forward never dereferences.
-	Timer tm(prof_next(g_bwd_log), s);
+	Timer tm(prof_next(g_bwd_log), s, kBwdStages);
 	{
 		const float* const src[4] = {background, nullptr, nullptr, nullptr};
 		float* const dst[4] = {bg_dev, nullptr, nullptr, nullptr};
@@ -787,6 +831,7 @@ int gsr_set_option(const char* name, int value)
 	else if (n == "bwd_variant") g_opt_bwd_variant.store(value);
 	else if (n == "speculative") g_opt_speculative.store(value);
 	else if (n == "fast_exp") g_opt_fast_exp.store(value != 0);
+	else if (n == "roctx") g_opt_roctx.store(value != 0);
 	else if (n == "tile_row_lo") g_opt_band_lo.store(value > 0 ? value : 0);
 	else if (n == "tile_row_hi") g_opt_band_hi.store(value);
 	else if (n == "bin_capacity") {   // capacity assumed for the NEXT forward on the current device (tests: force the re-launch path)
@@ -807,6 +852,7 @@ int gsr_get_option(const char* name)
 	if (n == "bwd_variant") return g_opt_bwd_variant.load();
 	if (n == "speculative") return g_opt_speculative.load();
 	if (n == "fast_exp") return g_opt_fast_exp.load();
+	if (n == "roctx") return g_opt_roctx.load() != 0 && roctx().push != nullptr;
 	if (n == "tile_row_lo") return g_opt_band_lo.load();
 	if (n == "tile_row_hi") return g_opt_band_hi.load();
 	if (n == "bin_capacity") return (int)dev_state().cap.load();

@@ -188,6 +188,9 @@ int gsr_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, co
  *   "bwd_variant"   -1 = auto (gsr_selftest), bit 0 = keep the select on T in composite_bwd, bit 1 = the per-wave
  *                        (8x8) kernel instead of the per-quarter one;
  *   "fast_exp"      0|1  process default of gsr_options.fast_exp (below);
+ *   "roctx"         0|1  (GSR_ROCTX) wrap every stage of gsr_forward / gsr_backward in a roctx range ("gsr.preprocess_fwd",
+ *                        "gsr.scan", ... ) for rocprofv3 --marker-trace timelines; the marker library is dlopen()ed, get
+ *                        returns 1 only if it was found;
  *   "bin_capacity"  n    binning capacity (instances) assumed by the next gsr_forward on the current device
  *                        (0 = forget; tests use a small n to force the re-allocate-and-relaunch path);
  *   "tile_row_lo", "tile_row_hi"  tile-grid sharding of ONE view across processes: only the 16-pixel

@@ -47,12 +47,14 @@ for cand in (f"{sess}/bench_line.json", f"{sess}/{wl}_bench_line.json"):
             pass
 
 
-def coalesced_read_bytes(name):
+def coalesced_read_bytes(name, fetch_kb=0.0):
     R = R_binned or 0
     if name.startswith("composite_bwd"):
         return _H * _W * 36 + R * 6
     if name.startswith("composite_fwd"):
         return R * 4
+    if name.startswith("preprocess_"):
+        return int(2 * fetch_kb * 1024)     # pure streaming kernels: EVERY read is a coalesced stream -> 2 x FETCH_SIZE
     return 0
 doc = {"_comment": "per-launch counters of the benchmark-sized dispatches (largest grid of each kernel) from rocprofv3 PMC passes "
                    f"of `bench.py --workload {wl}` ({sess}); FETCH_SIZE / WRITE_SIZE are KiB; traffic_bytes = FETCH + WRITE with the "
@@ -71,7 +73,7 @@ for name in ("composite_fwd_quarter_kernel", "composite_bwd_quarter_kernel", "co
     key = name.replace("_quarter_kernel", "").replace("_kernel", "")
     if key in doc:
         continue
-    co = coalesced_read_bytes(name)
+    co = coalesced_read_bytes(name, f.get("FETCH_SIZE", 0))
     doc[key] = {"grid": g, "fetch_size_kb": f.get("FETCH_SIZE"), "write_size_kb": w.get("WRITE_SIZE"),
                 "coalesced_read_bytes_counted_at_half": co,
                 "traffic_bytes": int((f.get("FETCH_SIZE", 0) + w.get("WRITE_SIZE", 0)) * 1024 + co // 2),
@@ -89,7 +91,7 @@ if sess_rot:
         if not grids or key not in doc:
             continue
         g = max(grids)
-        co = coalesced_read_bytes(name)
+        co = coalesced_read_bytes(name, fe2[(name, g)].get("FETCH_SIZE", 0))
         rot = int((fe2[(name, g)].get("FETCH_SIZE", 0) + wr2.get((name, g), {}).get("WRITE_SIZE", 0)) * 1024 + co // 2)
         by_mode[key] = {"static_bytes": doc[key]["traffic_bytes"], "rotating_bytes": rot}
     doc["by_mode"] = by_mode
