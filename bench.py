@@ -283,8 +283,8 @@ def run_extract(a, dev, scenes, _C):
     for i in range(a.steps):
         _, inv = step(i, timed=True)
     torch.cuda.synchronize()
-    n_valid = int((~inv).sum().item()) * a.steps
     dt = time.perf_counter() - t0
+    n_valid = int((~inv).sum().item()) * a.steps             # (after the clock: the first reduction loads a torch code object)
     fwd_ms = _C.last_forward_ms()
     _C.set_profiling(False)
     for e in marks:

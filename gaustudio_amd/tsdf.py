@@ -70,7 +70,7 @@ class TSDFVolume:
             raise RuntimeError(f"TSDFVolume: the block hash ({self.capacity} slots) overflowed; "
                                "create the volume with a larger capacity_blocks")
         if st & 2:
-            raise RuntimeError("TSDFVolume: a voxel received more than 2^24 - 1 observations (the count field of the packed "
+            raise RuntimeError("TSDFVolume: a voxel received more than 2^24 - 2^20 observations (the count field of the packed "
                                "voxel word is full); later observations of it were dropped")
 
     # ------------------------------------------------------------------ inspection

@@ -337,11 +337,13 @@ int gsr_masked_bilateral(const float* depth, const unsigned char* mask, int widt
  *       2^-15 fixed point (a block's voxels live at its hash slot; the fields hold up to 2^24 - 1 observations
  *       of a voxel);
  *   status[1] u32, zero-initialised: bit 0 set when the hash table overflowed (the ray that hit it is dropped from there
- *       on), bit 1 when a voxel was offered more than 2^24 - 1 observations (the surplus is dropped).
+ *       on), bit 1 when a voxel was offered more than 2^24 - 2^20 = 15 728 640 observations (the surplus is dropped; the
+ *       count is declared full 2^20 below the field's capacity so that the overflow guard needs no second atomic).
  * Algorithm and parity status: gaustudio_amd/csrc/gsr_tsdf.hip, DESIGN.md s8. ---- */
 
 /* VDBVolume::Integrate(points, origin) with the default weighting (weight 1): points[num_points,3] device,
- * origin[3] host. */
+ * origin[3] host.  Points within 1e-3 voxels of the origin (and non-finite ones) are skipped: that is what depth2point
+ * makes of a masked pixel (depth 0), so a whole point map can be passed without compacting the valid pixels. */
 int gsr_tsdf_integrate(const float* points, int num_points, const float origin[3], float voxel_size, float sdf_trunc,
                        int space_carving, uint64_t* block_keys, uint64_t capacity, uint64_t* voxels, uint32_t* status,
                        void* stream);

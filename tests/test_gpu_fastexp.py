@@ -101,6 +101,41 @@ def test_backward_must_run_in_the_mode_of_its_forward():
             hip_forward(sc, cam, 3, kw)
 
 
+def test_c_abi_options_struct_and_roctx_switch():
+    """gsr_options through the C ABI itself (ctypes): gsr_options_init, a per-call fast_exp on gsr_backward_ex, a SHORTER
+    struct from an older caller (fields beyond struct_bytes count as -1), NULL-equivalent defaults == gsr_backward; and the
+    roctx switch (stage ranges for rocprofv3 --marker-trace) does not disturb a call."""
+    from util import make_options
+    L = _C.lib()
+    cam = scenes.make_camera(160, 96)
+    sc = scenes.make_scene(3000, cam, seed=2)
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam)
+    exact = hip_forward(sc, cam, 3, kw)
+    with gaustudio_amd.options(fast_exp=True):
+        fast = hip_forward(sc, cam, 3, kw)
+    want_exact = hip_backward_raw(exact, sc, cam, 3, kw, grads)
+    got = hip_backward_raw(exact, sc, cam, 3, kw, grads, debug=True, options={})                      # every field -1
+    assert all(torch.equal(got[k], want_exact[k]) for k in GRAD_KEYS)
+    # per-call fast_exp: the backward of the fast forward, debug check passes; the process default stays 0
+    gfast = hip_backward_raw(fast, sc, cam, 3, kw, grads, debug=True, options=dict(fast_exp=1))
+    assert _C.get_option("fast_exp") == 0
+    assert float((gfast["dL_dsh"] - want_exact["dL_dsh"]).abs().max()) <= 1e-4 * float(want_exact["dL_dsh"].abs().max())
+    # a struct that ends before `fast_exp` (32 of 36 bytes): the field is ignored although the memory says 1
+    short = make_options(L, struct_bytes=32, fast_exp=1)
+    got = hip_backward_raw(exact, sc, cam, 3, kw, grads, debug=True, options=short)
+    assert all(torch.equal(got[k], want_exact[k]) for k in GRAD_KEYS)
+    with pytest.raises(RuntimeError, match="fast_exp differs from the forward"):
+        hip_backward_raw(exact, sc, cam, 3, kw, grads, debug=True, options=dict(fast_exp=1))
+    _C.set_option("roctx", 1)
+    try:
+        again = hip_forward(sc, cam, 3, kw)
+        assert torch.equal(again["color"], exact["color"])
+        assert _C.get_option("roctx") in (0, 1)               # 1 iff a marker library could be dlopen()ed
+    finally:
+        _C.set_option("roctx", 0)
+
+
 def test_options_travel_with_the_graph_and_are_per_thread():
     """The backward of a call runs with the options of ITS forward although it is executed outside the `with` block (and
     on autograd's thread); two threads of one process render two tile bands of one view concurrently -- the case the

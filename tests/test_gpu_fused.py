@@ -19,6 +19,47 @@ def _raw_params(sc, dev):
     return {k: v.to(dev).requires_grad_(True) for k, v in raw.items()}
 
 
+def _assert_images_equal_up_to_attributed_events(sc, cam, D, a, out_a, out_b):
+    """The in-kernel activations (expf / sqrtf of the device library) differ from torch's in the last bit, so the two
+    paths see parameters a few 1e-8 apart: images agree to 1e-5 except where that moves an alpha / transmittance across a
+    threshold or a radius across a ceil() -- and every such pixel must be ATTRIBUTED by the replay of tests/attribution.py
+    (decoded state of the unfused forward), exactly as against the reference kernels.  No blanket flip budget."""
+    import attribution
+    from util import hip_forward
+    sc_act = scenes.Scene(a["xyz"].detach().cpu(), torch.exp(a["scale"]).detach().cpu(), F.normalize(a["rot"]).detach().cpu(),
+                          torch.sigmoid(a["opacity"]).detach().cpu(),
+                          torch.cat((a["f_dc"].reshape(-1, 1, 3), a["f_rest"].reshape(-1, 15, 3)), dim=1).detach().cpu())
+    st = hip_forward(sc_act, cam, D, dict(shs=sc_act.shs, scales=sc_act.scales, rotations=sc_act.rotations))
+    assert torch.equal(st["color"], out_a[0]) and torch.equal(st["radii"], out_a[1])      # the same forward, decoded
+    assert float((out_a[1] != out_b[1]).float().mean()) < 1e-4                            # radii: a ceil() on the other side at most
+    ia = {k: out_a[i].detach().cpu().numpy() for i, k in ((0, "color"), (2, "depth"), (4, "opacity"))}
+    ib = {k: out_b[i].detach().cpu().numpy() for i, k in ((0, "color"), (2, "depth"), (4, "opacity"))}
+    rep = attribution.attribute_images(st, cam.width, cam.height, ia, ib, tol=1e-5, depth_scale=20.0,
+                                       radii_b=out_b[1].detach().cpu().numpy())
+    assert not rep["unattributed"], (rep["flagged"], rep["unattributed"][:3])
+    return rep
+
+
+def test_fused_matches_unfused_at_c3_size():
+    """The headline size (1 M Gaussians, 1920x1080, SH 3), forward: fused vs unfused, every differing pixel attributed."""
+    from gaustudio_amd.fused import FusedGaussianRasterizer
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = "cuda"
+    cam = scenes.make_camera(1920, 1080)
+    sc = scenes.make_scene(1_000_000, cam, seed=0)
+    rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+    a = _raw_params(sc, dev)
+    with torch.no_grad():
+        shs = torch.cat((a["f_dc"].reshape(-1, 1, 3), a["f_rest"].reshape(-1, 15, 3)), dim=1)
+        out_a = GaussianRasterizer(rs)(means3D=a["xyz"], means2D=None, opacities=torch.sigmoid(a["opacity"]), shs=shs,
+                                       scales=torch.exp(a["scale"]), rotations=F.normalize(a["rot"]))
+        out_b = FusedGaussianRasterizer(rs)(means3D=a["xyz"], means2D=None, raw_opacities=a["opacity"], f_dc=a["f_dc"],
+                                            f_rest=a["f_rest"], raw_scales=a["scale"], raw_rotations=a["rot"])
+    rep = _assert_images_equal_up_to_attributed_events(sc, cam, 3, a, out_a, out_b)
+    assert rep["flagged"] < 2000            # a handful of events per 2 M pixels, not a systematic difference
+
+
 @pytest.mark.parametrize("D", [0, 3])
 def test_fused_matches_unfused(D):
     from gaustudio_amd.fused import FusedGaussianRasterizer
@@ -43,10 +84,7 @@ def test_fused_matches_unfused(D):
                                         raw_scales=b["scale"], raw_rotations=b["rot"])
     torch.autograd.backward([out_b[0], out_b[2], out_b[3], out_b[4]], grads)
 
-    assert torch.equal(out_a[1], out_b[1]) or (out_a[1] != out_b[1]).float().mean() < 1e-4      # radii
-    for i, name in ((0, "color"), (2, "depth"), (4, "opacity")):
-        d = (out_a[i] - out_b[i]).detach().abs()
-        assert float((d > 1e-5).float().mean()) < 1e-4 and float(d.max()) < 6e-3, name            # flip budget as in test_gpu_ref
+    _assert_images_equal_up_to_attributed_events(sc, cam, D, a, out_a, out_b)
     for k in a:
         ga, gb = a[k].grad, b[k].grad
         assert gb is not None and gb.shape == ga.shape, k

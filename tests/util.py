@@ -106,9 +106,28 @@ def _nonempty(os_):
     return r[:, 1] > r[:, 0]
 
 
-def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False):
-    """gsr_backward called straight through ctypes with a test-owned scratch buffer, so that the
-    composite-stage accumulator rows (scratch[P,12]) can be inspected next to the 8 outputs."""
+class GsrOptions(__import__("ctypes").Structure):
+    """include/gsrast.h gsr_options (ABI v6)."""
+    _fields_ = [(n, __import__("ctypes").c_int32) for n in ("struct_bytes", "tight_binning", "cull", "fwd_variant", "bwd_variant",
+                                                           "speculative", "tile_row_lo", "tile_row_hi", "fast_exp")]
+
+
+def make_options(L, struct_bytes=None, **fields):
+    import ctypes
+    o = GsrOptions()
+    L.gsr_options_init(ctypes.byref(o))
+    assert o.struct_bytes == ctypes.sizeof(GsrOptions) and all(getattr(o, n) == -1 for n, _ in GsrOptions._fields_[1:])
+    for k, v in fields.items():
+        setattr(o, k, int(v))
+    if struct_bytes is not None:
+        o.struct_bytes = int(struct_bytes)      # an older caller's (shorter) struct: the fields beyond it count as -1
+    return o
+
+
+def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False, options=None):
+    """gsr_backward (or, with `options` = a GsrOptions / None-able dict, gsr_backward_ex) called straight through ctypes
+    with a test-owned scratch buffer, so that the composite-stage accumulator rows (scratch[P,12]) can be inspected next
+    to the 8 outputs."""
     import ctypes
     from gaustudio_amd import _C
     L = _C.lib()
@@ -130,7 +149,20 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
     cov = g("cov3D_precomp")
     view = cam.viewmatrix.to(dev); proj = cam.projmatrix.to(dev); cpos = cam.campos.to(dev)
     p = _C._ptr
-    rc = L.gsr_backward(ctypes.c_int(P), ctypes.c_int(D), ctypes.c_int(M), ctypes.c_int(hs["num_rendered"]), p(bg),
+    if options is not None:
+        opt = options if isinstance(options, GsrOptions) else make_options(L, **options)
+        rc = L.gsr_backward_ex(ctypes.byref(opt), ctypes.c_int(3), ctypes.c_int(0), ctypes.c_int(P), ctypes.c_int(P), ctypes.c_int(D),
+                               ctypes.c_int(M), ctypes.c_int(hs["num_rendered"]), p(bg), ctypes.c_int(cam.width), ctypes.c_int(cam.height),
+                               p(means), p(shs), p(None), p(col), p(scl), ctypes.c_float(scale_modifier), p(rot), p(cov), ctypes.c_int(0),
+                               ctypes.c_float(cam.tanfovx), ctypes.c_float(cam.tanfovy), p(hs["radii"]), p(hs["geom"]), p(hs["binning"]),
+                               p(hs["img"]), p(gc), p(gd), p(gm), p(go), p(out["dL_dmeans2D"]), p(out["dL_dopacity"]), p(out["dL_dcolors"]),
+                               p(out["dL_dmeans3D"]), p(out["dL_dcov3D"]), p(out["dL_dsh"]), p(None), p(out["dL_dscales"]),
+                               p(out["dL_drotations"]), p(scratch), ctypes.c_int(bool(debug)), _C._stream(dev))
+        if rc < 0:
+            raise _C._err(L, rc)
+        rc = 0
+    else:
+        rc = L.gsr_backward(ctypes.c_int(P), ctypes.c_int(D), ctypes.c_int(M), ctypes.c_int(hs["num_rendered"]), p(bg),
                         ctypes.c_int(cam.width), ctypes.c_int(cam.height), p(means), p(shs), p(col), p(scl),
                         ctypes.c_float(scale_modifier), p(rot), p(cov), p(view), p(proj), p(cpos),
                         ctypes.c_float(cam.tanfovx), ctypes.c_float(cam.tanfovy), p(hs["radii"]), p(hs["geom"]),
