@@ -417,7 +417,7 @@ def main():
     rs_list = [settings(c) for c in cams]
     rs = rs_list[0]
     rasterizers = [GaussianRasterizer(r) for r in rs_list]
-    factored = world > 1 and a.exchange == "factored" and not a.fwd_only
+    factored = world > 1 and a.exchange == "factored" and not a.fwd_only   # (step() reads it at call time)
     bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()), roles=params)
     fx = None
     if factored:
@@ -487,6 +487,25 @@ def main():
         return float(tmax.item()), f, b
 
     rotating_headline = a.rotate_cameras is not None and a.rotate_cameras > 0
+
+    # N > 1, factored exchange: one untimed step first.  If anything in it raises on this backend (it has only ever run over
+    # gloo and on two ranks sharing one GPU: no multi-GPU node was available to the builder), every rank falls back to the
+    # dense all-reduce together instead of losing the scaling run; the line says so (`comm.exchange_fallback`).
+    if factored:
+        ok = 1
+        try:
+            with mode:
+                step(False)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            state["fallback_reason"] = f"{type(e).__name__}: {e}"[:300]
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            factored = False
+            _C.set_grad_arena([])
+            state.setdefault("fallback_reason", "another rank failed")
 
     # ---- rotating mode: K cameras cycled, Adam update of every parameter between the steps ----
     def make_rotating(K):
@@ -620,7 +639,7 @@ def main():
             exposed = sum(e0.elapsed_time(e1) for e0, e1 in comm_ev) / len(comm_ev)
             comp_total = sum(v for k, v in (fwd_ms or {}).items() if k != "calls") + sum(v for k, v in (bwd_ms or {}).items() if k != "calls")
             n_it = max(1, a.steps + a.warmup)
-            comm = {"exchange": "factored" if factored else "dense",
+            comm = {"exchange": "factored" if factored else "dense", "exchange_fallback": state.get("fallback_reason"),
                     "compute_ms": round(comp_total * V, 4), "comm_exposed_ms": round(exposed, 4),
                     "note": "compute_ms = sum of the operator's kernel stages (HIP events) x views per rank; comm_exposed_ms = time "
                             "from the end of the last backward's enqueue to the end of the exchange on rank 0's stream (what the "
