@@ -304,8 +304,11 @@ class FactoredGradExchange:
         mine = self.colors[self.rank * V:(self.rank + 1) * V]
         rows = None
         if multi and self.compact:
-            # rows with a non-zero gradient in ANY view of ANY rank (a culled Gaussian's rows are exactly zero)
-            live = (mine.abs().amax(dim=(0, 2)) > 0) | (self.geo_views()["means3D"].abs().amax(dim=1) > 0)
+            # rows with a non-zero gradient in ANY view of ANY rank (a culled Gaussian's rows are exactly zero): every one of
+            # the 11 geometry floats and the colour slots counts, so that no partial row is left out of the sum
+            live = mine.abs().amax(dim=(0, 2)) > 0
+            for r in GEOMETRY_ROLES:
+                live |= views[r].reshape(P, -1).abs().amax(dim=1) > 0
             mask = live.to(torch.int32)
             dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
             rows = torch.nonzero(mask, as_tuple=False).flatten()
