@@ -79,7 +79,7 @@ print(f"kernel box test pass rate: 8x8 {hit88 / (4 * tot):.3f} (exact any-live {
 # instances passing its 8x8 box test (now) vs max over its four 4x4 quarters of their own pass counts, the quarters
 # re-synchronising every `batch` list entries (the staged batch).  Depth: the block's deepest n_contrib. ----
 ncp = ncpad.view(-1, 16, gx, 16).permute(0, 2, 1, 3).reshape(-1, 16, 16)   # [tile][y][x]
-it8 = 0; it4 = {64: 0, 256: 0, 1 << 30: 0}; it4_mean = 0; it2 = {256: 0}
+it8 = 0; it4 = {64: 0, 256: 0, 1 << 30: 0}; it4_mean = 0; it2 = {256: 0}; it8e = {256: 0}; it8e_mean = 0
 for t in tiles.tolist():
     a, b = int(r[t, 0]), int(r[t, 1])
     if b <= a: continue
@@ -108,9 +108,19 @@ for t in tiles.tolist():
         hh = torch.stack([hq[0] | hq[1], hq[2] | hq[3]])     # two 8x4 halves
         pad = (-depth) % 256
         it2[256] += int(torch.nn.functional.pad(hh, (0, pad)).view(2, -1, 256).sum(2).max(0).values.sum())
+        # eight 4x2 sub-blocks (8 lanes each): would finer lists pay?  
+        he = []
+        for e in range(8):
+            ex0 = bx0 + (e & 1) * 4; ey0 = by0 + (e >> 1) * 2
+            if ex0 > W - 1 or ey0 > H - 1: he.append(torch.zeros_like(h8)); continue
+            he.append(box_test(xy[sel], co[sel], ex0, ey0, min(ex0 + 3, W - 1), min(ey0 + 1, H - 1)) & h8)
+        he = torch.stack(he).long()
+        it8e_mean += float(he.sum()) / 8
+        it8e[256] += int(torch.nn.functional.pad(he, (0, pad)).view(8, -1, 256).sum(2).max(0).values.sum())
 print(f"wave walk length, 8x8 lists: {it8}; 4x4 quarter lists: mean-of-quarters {it4_mean:.0f} ({it4_mean / it8:.3f}), "
       + ", ".join(f"resync/{k if k < 1 << 30 else 'never'} {v} ({v / it8:.3f})" for k, v in it4.items())
-      + f"; 8x4 halves resync/256 {it2[256]} ({it2[256] / it8:.3f})")
+      + f"; 8x4 halves resync/256 {it2[256]} ({it2[256] / it8:.3f})"
+      + f"; 4x2 eighths: mean-of-eighths {it8e_mean:.0f} ({it8e_mean / it8:.3f}), resync/256 {it8e[256]} ({it8e[256] / it8:.3f})")
 
 # ---- composite_bwd with per-quarter lists: steps of a workgroup per batch of B staged instances = max over its four
 # waves of (max over the wave's quarters of its hits in the batch); walked back to front from the tile's deepest
