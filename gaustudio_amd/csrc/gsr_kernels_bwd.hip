@@ -463,6 +463,21 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 // fewer per step buy nothing here, the kernel is bound by latency, not by issue; a third mode -- hardware exp after a
 // BIT-EXACT forward, with a re-evaluation by gs_exp wherever opacity * G came within 4e-6 of 1/255 so that the decisions
 // stayed the forward's -- was built, passed the summation-bound tests and measured 0.5346 ms: removed.)
+// Diagnostic build only (make BWD_EXTRA=-DGSR_BWD_TIMING; tools/bwd_phase_timing.py): s_memtime around the phases of a
+// wave's life, accumulated in registers and stored to the wave's own slot at the end.  (A first version added the sums
+// with device atomics to twelve shared words: 420 k same-address atomics per launch stretched every workgroup's tail
+// and made the memory phases look four times as long as they are -- profiles/r03_composite_bwd_phases.txt.)
+#ifdef GSR_BWD_TIMING
+#define GSR_TM_SLOTS 40000
+__device__ unsigned long long g_bwd_phase_ticks[GSR_TM_SLOTS * 12];
+#define TM_DECL unsigned long long tm_last = __builtin_amdgcn_s_memtime(); unsigned long long tm_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define TM(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm_acc[k] += now_ - tm_last; tm_last = now_; }
+#define TM_END { const unsigned w_ = blockIdx.x * 4 + wv; if (lane == 0 && w_ < GSR_TM_SLOTS) { for (int k_ = 0; k_ < 12; k_++) g_bwd_phase_ticks[w_ * 12 + k_] += tm_acc[k_]; } }
+#else
+#define TM_DECL
+#define TM(k)
+#define TM_END
+#endif
 template <bool FLAGS, bool TSEL, bool FX>
 __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_quarter_kernel(
     int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
@@ -485,6 +500,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6, qd = lane >> 4;
+	TM_DECL
 	const int tx = tile % gx, ty = tile / gx;
 	// lane -> pixel as in composite_fwd_quarter_kernel: quarter qd of wave wv is one 4x4 block
 	const int lx = ((wv & 1) << 3) + ((qd & 1) << 2) + (lane & 3);
@@ -552,9 +568,11 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	const int qm2 = __builtin_amdgcn_readlane(qmax, 32), qm3 = __builtin_amdgcn_readlane(qmax, 48);
 	const int wmax = max(max(qm0, qm1), max(qm2, qm3));
 	if (lane == 0) s_max[wv] = wmax;
+	TM(0)
 	if (tid < 3) (tid == 0 ? sA : tid == 1 ? sB : sC)[GSR_BWQ_SENT] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
 	const int bmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+	TM(1)
 
 	// rows of list entries no pixel of the tile reaches (short-list regime; see composite_bwd_kernel)
 	for (int i = bmax + tid; !FLAGS && i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
@@ -566,6 +584,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
+	TM(2)
 	// ---- software-pipelined staging (as in composite_bwd_kernel) ----
 	// thread t fetches 16-B part (t & 3) of the records of staged instances (t >> 2) + 64 h
 	const int srec = tid >> 2, spart = tid & 3;
@@ -600,7 +619,9 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 
 	for (int top = bmax; top > 0; top -= GSR_BWQ_BATCH) {
 		const int cnt = min(GSR_BWQ_BATCH, top);
+		TM(3)
 		__syncthreads();   // the previous flush has read sA / sB / the planes
+		TM(4)
 #pragma unroll
 		for (int h = 0; h < GSR_BWQ_HALVES; h++) {
 			const int sr = srec + 64 * h;
@@ -616,6 +637,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 				}
 			}
 		}
+		TM(5)
 		float4 part_next[GSR_BWQ_HALVES];
 #pragma unroll
 		for (int h = 0; h < GSR_BWQ_HALVES; h++) {
@@ -629,7 +651,9 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			const uint32_t ss = GSR_BWQ_SENT * 0x01010101u;
 			reinterpret_cast<uint4*>(&s_list[wv][0][0])[lane] = make_uint4(ss, ss, ss, ss);
 		}
+		TM(6)
 		__syncthreads();
+		TM(7)
 		// median-depth gradient (backward.cu:566-569): to the Gaussian the forward recorded as this pixel's median
 		// (list position mpos, 1-based), when it is in this batch -- once per pixel per backward
 		if (mpos != 0u && dLm != 0.f && (uint32_t)top >= mpos && (uint32_t)top - mpos < (uint32_t)cnt)
@@ -667,6 +691,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		}
 #undef GSR_APPEND
 		__builtin_amdgcn_wave_barrier();
+		TM(8)
 		const int n = max(max(c0, c1), max(c2, c3));
 		const int my_cnt = qd == 0 ? c0 : qd == 1 ? c1 : qd == 2 ? c2 : c3;
 		// one list step of every quarter: (q, w) of the lane's pixel for the quarter's entry, into slab row `st`
@@ -799,7 +824,9 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			turn_write(qq);
 		}
 		// flush: one thread per staged instance adds the four planes in fixed order and stores the 48-B row
+		TM(9)
 		__syncthreads();
+		TM(10)
 		for (int fj = tid; fj < cnt; fj += GSR_BWD_THREADS) {
 			float v[10];
 #pragma unroll
@@ -820,8 +847,23 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		}
 #pragma unroll
 		for (int h = 0; h < GSR_BWQ_HALVES; h++) part_cur[h] = part_next[h];
+		TM(11)
 	}
+	TM_END
 }
+#ifdef GSR_BWD_TIMING
+}  // namespace gsr
+// out: GSR_TM_SLOTS x 12 tick sums (slot = workgroup * 4 + wave); reset: clear them afterwards
+extern "C" int gsr_debug_bwd_phase_ticks(unsigned long long* out, int reset)
+{
+	void* p = nullptr;
+	if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&p, HIP_SYMBOL(gsr::g_bwd_phase_ticks)) != hipSuccess) return -1;
+	if (out && hipMemcpy(out, p, sizeof(unsigned long long) * GSR_TM_SLOTS * 12, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+	if (reset && hipMemset(p, 0, sizeof(unsigned long long) * GSR_TM_SLOTS * 12) != hipSuccess) return -3;
+	return 0;
+}
+namespace gsr {
+#endif
 
 // v_rcp_f32(1.0) == 1.0 (and a few neighbours behave): composite_bwd relies on it to carry dead pixels through
 // without a select on T (TSEL = false).  Checked once per process by gsr_selftest; a failing device gets TSEL = true.

@@ -150,3 +150,37 @@ for t in tiles.tolist():
         res[B][0] += int(nw.max(0).values.sum()); res[B][1] += float(nw.float().mean(0).sum()); res[B][2] += float(hb.float().mean((0, 1)).sum())
 print("composite_bwd quarter-list census (steps per workgroup): " + "; ".join(
     f"B={B}: max-wave {v[0]}, mean-wave {v[1]:.0f} (max/mean {v[0] / v[1]:.3f}), mean-quarter {v[2]:.0f} (wave/quarter {v[1] / v[2]:.3f})" for B, v in res.items()))
+
+# ---- composite_bwd: how often do two quarters of a wave meet in an instance within one group of GSR_BWQ_U = 4 list
+# steps (the case the plane update's "turns" exist for)?  Per (wave, round of 128, group): the four quarters' list
+# entries of the group, pairwise disjoint or not. ----
+groups = coll = 0
+for t in tiles.tolist():
+    a, b = int(r[t, 0]), int(r[t, 1])
+    if b <= a: continue
+    ids = pl[a:b]; tx, ty = t % gx, t // gx
+    bmax = min(int(ncp[t].max()), len(ids))
+    if bmax == 0: continue
+    sel = ids[:bmax]
+    pos = torch.arange(bmax, device=xy.device)
+    for blk in range(4):
+        bx0 = tx * 16 + (blk & 1) * 8; by0 = ty * 16 + (blk >> 1) * 8
+        hq = []
+        for q in range(4):
+            qx0 = bx0 + (q & 1) * 4; qy0 = by0 + (q >> 1) * 4
+            if qx0 > W - 1 or qy0 > H - 1:
+                hq.append(torch.zeros(bmax, dtype=torch.bool)); continue
+            qmax = int(ncp[t, qy0 - ty * 16:qy0 - ty * 16 + 4, qx0 - tx * 16:qx0 - tx * 16 + 4].max())
+            hq.append((box_test(xy[sel], co[sel], qx0, qy0, min(qx0 + 3, W - 1), min(qy0 + 3, H - 1)) & (pos < qmax)).cpu())
+        for top in range(bmax, 0, -128):
+            lo = max(0, top - 128)
+            lists = [torch.nonzero(torch.flip(h[lo:top], dims=[0])).flatten().tolist() for h in hq]
+            n = max(len(l) for l in lists)
+            for g0 in range(0, n, 4):
+                seen = set(); c = False
+                for l in lists:
+                    s_ = set(l[g0:g0 + 4])
+                    if seen & s_: c = True
+                    seen |= s_
+                groups += 1; coll += int(c)
+print(f"composite_bwd groups of 4 steps: {groups}; with two quarters of the wave in the same instance: {coll} ({coll / max(1, groups):.3f})")
