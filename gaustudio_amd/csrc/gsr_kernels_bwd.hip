@@ -443,8 +443,10 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 //   Measured and not kept: LDS float atomics for the plane update (they serialise their lanes: 1.13 ms, the LDS pipe
 //   2.4x as busy); 8 steps per reduction with 8 pixels per lane (halves the fold, needs 165 VGPRs: 0.68 ms at 3
 //   waves/SIMD against 0.59 ms at 4); one float4 per lane and turn instead of three floats (spills: 0.69 ms); a fused
-//   v_add_f32_dpp fold by inline assembly and skipping the steps past the longest list (no change: the kernel is
-//   bound by latency at 4 waves/SIMD, not by its VALU count).
+//   v_add_f32_dpp fold by inline assembly and skipping the steps past the longest list (no change); branch-free turns
+//   (every lane reads / adds / writes in every turn, the other quarters' lanes into a dummy word, so that a group of four
+//   steps is one basic block: bit-equal, 0.5111 against 0.5097 ms).  profiles/r03_composite_bwd_phases.txt: a wave walks
+//   for 68 % of its life, and the walk is sensitive to VALU and LDS at once with neither saturated.
 // A wave walks max over its quarters (C3: 0.73x the steps of the 8x8 walk), and phase 2 touches only hit quarters.
 // The median-depth gradient (one Gaussian per pixel, the list position the forward recorded) is added once per pixel,
 // by an LDS atomic before the walk of the batch that position falls into.
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 
 // FX: exp on the transcendental unit (gs_exp_hw), after a forward that ran in fast_exp mode: same instruction, same
 // bits, same alpha >= 1/255 decisions as that forward.  (Measured at C3: 0.5108 -> 0.5084 ms -- nine VALU instructions
-// fewer per step buy nothing here, the kernel is bound by latency, not by issue; a third mode -- hardware exp after a
+// fewer per step, but v_exp_f32 issues at a quarter of their rate; a third mode -- hardware exp after a
 // BIT-EXACT forward, with a re-evaluation by gs_exp wherever opacity * G came within 4e-6 of 1/255 so that the decisions
 // stayed the forward's -- was built, passed the summation-bound tests and measured 0.5346 ms: removed.)
 // Diagnostic build only (make BWD_EXTRA=-DGSR_BWD_TIMING; tools/bwd_phase_timing.py): s_memtime around the phases of a
