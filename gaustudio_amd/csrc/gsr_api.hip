@@ -191,20 +191,26 @@ struct StageArgs {
 	int n[4];
 	uint32_t* word_dst;     // optional: one 32-bit word stored by the same launch (the forward's options word)
 	uint32_t word;
+	uint32_t* zero_dst;     // optional: up to 64 words cleared by the same launch, BEFORE word_dst is stored (the control block)
+	int zero_n;
 };
 __global__ void stage_cam_kernel(StageArgs a, float* dst0, float* dst1, float* dst2, float* dst3)
 {
 	float* dst[4] = {dst0, dst1, dst2, dst3};
 	const int which = threadIdx.x >> 4, i = threadIdx.x & 15;
 	if (dst[which] != nullptr && i < a.n[which]) dst[which][i] = a.dptr[which] ? a.dptr[which][i] : a.host[which][i];
+	if (a.zero_dst != nullptr && (int)threadIdx.x < a.zero_n) a.zero_dst[threadIdx.x] = 0u;
+	__syncthreads();
 	if (threadIdx.x == 0 && a.word_dst != nullptr) *a.word_dst = a.word;
 }
 hipError_t stage_small(const float* const src[4], float* const dst[4], const int n[4], hipStream_t s,
-                       uint32_t* word_dst = nullptr, uint32_t word = 0)
+                       uint32_t* word_dst = nullptr, uint32_t word = 0, uint32_t* zero_dst = nullptr, int zero_n = 0)
 {
 	StageArgs a;
 	a.word_dst = word_dst;
 	a.word = word;
+	a.zero_dst = zero_dst;
+	a.zero_n = zero_n;
 	for (int k = 0; k < 4; k++) {
 		a.n[k] = (dst[k] != nullptr) ? n[k] : 0;
 		a.dptr[k] = nullptr;
@@ -455,8 +461,11 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	uint32_t* med_pos = reinterpret_cast<uint32_t*>(img + il.med_pos);
 
 	Timer tm(prof_next(g_fwd_log), s, kFwdStages);
-	// control words + tile counters, then the camera block and the options this call runs with (one tiny launch)
-	HIP_TRY(hipMemsetAsync(img + il.ctl, 0, il.final_T - il.ctl, s));   // ctl + ranges + tile_count
+	// control words (+ tile counters: only the atomic-counter binning path needs them cleared -- the chunked path
+	// writes every tile's count and range itself), then the camera block and the options this call runs with: one tiny
+	// launch, which also clears the 8 control words
+	static_assert(sizeof(GsCtl) == 8 * sizeof(uint32_t), "stage_cam_kernel clears GsCtl word by word");
+	if (!lds_bin) HIP_TRY(hipMemsetAsync(img + il.ctl, 0, il.final_T - il.ctl, s));   // ctl + ranges + tile_count
 	{
 		const float* const src[4] = {viewmatrix, projmatrix, cam_pos, background};
 		float* const dst[4] = {cam->view, cam->proj, cam->campos, cam->bg};
@@ -465,7 +474,7 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		const uint32_t word = (ro.fast_exp ? GSR_CTL_OPT_FAST_EXP : 0u) | (ro.tight ? GSR_CTL_OPT_TIGHT : 0u) |
 		                      (ro.cull ? GSR_CTL_OPT_CULL : 0u) | (ro.fwd_variant == 1 ? GSR_CTL_OPT_WAVE_LISTS : 0u) |
 		                      (banded ? GSR_CTL_OPT_BAND : 0u);
-		HIP_TRY(stage_small(src, dst, n, s, &ctl->opts, word));
+		HIP_TRY(stage_small(src, dst, n, s, &ctl->opts, word, reinterpret_cast<uint32_t*>(ctl), 8));
 	}
 
 	FwdArgs a;
@@ -503,8 +512,10 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	// grows).
 	hipEvent_t ev = readback_event();
 	if (ev) HIP_TRY(hipEventRecord(ev, s));
-	launch_goff_apply(P, tiles_touched, bsums, reinterpret_cast<uint32_t*>(geom + gl.goff), s);
-	STAGE_CHECK("goff_apply", debug, s);
+	// Gaussian-major row offsets for the backward: computed by the chunked scatter kernel on its way (same Gaussians, same
+	// chunks); the other paths launch the small kernel of their own
+	uint32_t* goff = reinterpret_cast<uint32_t*>(geom + gl.goff);
+	bool goff_done = false;
 	tm.mark();
 
 	DevState& ds = dev_state();
@@ -518,11 +529,18 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		uint64_t* keys2 = reinterpret_cast<uint64_t*>(bin + bl.keys2);
 		uint32_t* point_list = reinterpret_cast<uint32_t*>(bin + bl.point_list);
 		if (cap > 0) {
-			if (lds_bin)
-				launch_bin_scatter2(P, il.gx, il.T, tiles_touched, recs, Hm, ranges, keys, ctl, cap, s);
+			if (lds_bin) {
+				launch_bin_scatter2(P, il.gx, il.T, tiles_touched, recs, Hm, ranges, keys, bsums, goff, ctl, cap, s);
+				goff_done = true;
+			}
 			else
 				launch_bin_scatter(P, il.gx, radii, tiles_touched, recs, ranges, tile_count, keys, ctl, cap, s);
 			STAGE_CHECK("bin_scatter", debug, s);
+		}
+		if (!goff_done) {
+			launch_goff_apply(P, tiles_touched, bsums, goff, s);
+			STAGE_CHECK("goff_apply", debug, s);
+			goff_done = true;
 		}
 		tm.mark();
 		if (cap > 0) {
@@ -699,21 +717,21 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	// The background is re-staged here because the reference reads the backward's own `background`
 	// argument (backward.cu:584-587), which the forward never dereferences.
 	Timer tm(prof_next(g_bwd_log), s, kBwdStages);
-	{
-		const float* const src[4] = {background, nullptr, nullptr, nullptr};
-		float* const dst[4] = {bg_dev, nullptr, nullptr, nullptr};
-		const int n[4] = {3, 0, 0, 0};
-		HIP_TRY(stage_small(src, dst, n, s));
-	}
 	// long lists (average > GSR_FLAG_AVG entries per tile): one validity byte per instance row, set by composite_bwd for the
 	// rows it writes; short lists: no flags, composite_bwd zeroes the rows of the entries its walk does not reach
 	const bool flagged = (size_t)(R > 0 ? R : 0) > (size_t)il.T * GSR_FLAG_AVG;
+	{
+		// the regime is recorded next to the staged background for gsr_inspect_backward_sums (word 8 of the bg block),
+		// by the launch that stages the background
+		const float* const src[4] = {background, nullptr, nullptr, nullptr};
+		float* const dst[4] = {bg_dev, nullptr, nullptr, nullptr};
+		const int n[4] = {3, 0, 0, 0};
+		HIP_TRY(stage_small(src, dst, n, s, reinterpret_cast<uint32_t*>(bg_dev + 8), flagged ? 1u : 0u));
+	}
 	if (flagged)
 		HIP_TRY(hipMemsetAsync(row_flags, 0, (size_t)R, s));
 	else
 		row_flags = nullptr;
-	// the regime is recorded next to the staged background for gsr_inspect_backward_sums (word 8 of the bg block)
-	HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bg_dev + 8), flagged ? 1 : 0, 1, s));
 
 	tm.mark();
 	if (R > 0) {

@@ -111,7 +111,7 @@ bool bin_lds_path_ok(int T);
 void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
                      uint32_t* tile_count, hipStream_t s);
 void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
-                         const uint2* ranges, uint64_t* keys, const GsCtl* ctl, uint32_t cap, hipStream_t s);
+                         const uint2* ranges, uint64_t* keys, const uint32_t* bsums, uint32_t* goff, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 // with_long: also launch the long-list (> GSR_SORT_LDS_MAX keys) kernel, which needs the keys2 buffer
 void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
                       uint32_t* point_list, const GsCtl* ctl, uint32_t cap, hipStream_t s);

@@ -452,12 +452,12 @@ void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, int nblk, uint
 }
 
 // goff[g] = bsums[block of g] + exclusive scan of tiles_touched inside the 256-Gaussian block (4 Gaussians per thread:
-// a 256-thread workgroup finishes four blocks).
-__global__ __launch_bounds__(256) void goff_apply_kernel(int P, const uint32_t* __restrict__ tiles_touched,
-                                                         const uint32_t* __restrict__ bsums, uint32_t* __restrict__ goff)
+// a 256-thread workgroup finishes four blocks).  The chunked scatter (bin_chunk_kernel<true>) does this on its way;
+// goff_apply_kernel is for the paths that do not run it.
+__device__ __forceinline__ void gs_goff_block(int P, int blk, int lane, const uint32_t* __restrict__ tiles_touched,
+                                              const uint32_t* __restrict__ bsums, uint32_t* __restrict__ goff)
 {
-	// wave w of the workgroup owns the 256-Gaussian block 4 * blockIdx.x + w: lane l holds Gaussians 4 l .. 4 l + 3
-	const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+	// one wave per 256-Gaussian block: lane l holds Gaussians 4 l .. 4 l + 3
 	const int base = blk * GSR_PRE_BLOCK + 4 * lane;
 	if (blk * GSR_PRE_BLOCK >= P) return;
 	uint32_t v[4];
@@ -480,6 +480,13 @@ __global__ __launch_bounds__(256) void goff_apply_kernel(int P, const uint32_t* 
 		for (int i = 0; i < 4; i++) if (base + i < P) goff[base + i] = o[i];
 	}
 	if (base <= P - 1 && P - 1 < base + 4) goff[P] = o[P - 1 - base] + v[P - 1 - base];
+}
+
+__global__ __launch_bounds__(256) void goff_apply_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+                                                         const uint32_t* __restrict__ bsums, uint32_t* __restrict__ goff)
+{
+	// wave w of the workgroup owns the 256-Gaussian block 4 * blockIdx.x + w
+	gs_goff_block(P, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, tiles_touched, bsums, goff);
 }
 
 void launch_goff_apply(int P, const uint32_t* tiles_touched, const uint32_t* bsums, uint32_t* goff, hipStream_t s)
@@ -544,14 +551,23 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int c
                                                         const uint32_t* __restrict__ tiles_touched,
                                                         const GsRec* __restrict__ recs,
                                                         uint32_t* __restrict__ Hm, const uint2* __restrict__ ranges,
-                                                        uint64_t* __restrict__ keys, const GsCtl* __restrict__ ctl,
+                                                        uint64_t* __restrict__ keys, const uint32_t* __restrict__ bsums,
+                                                        uint32_t* __restrict__ goff, const GsCtl* __restrict__ ctl,
                                                         uint32_t cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
-	if (SCATTER && ctl->num_binned > cap) return;   // see bin_scatter_kernel
 	const int tid = threadIdx.x;
 	const int g = blockIdx.x;   // (an XCD-banded chunk order was measured: no effect on the scatter)
+	if (SCATTER && goff != nullptr) {
+		// the backward's Gaussian-major row offsets (goff_apply_kernel's job) for this chunk, ahead of the capacity guard:
+		// a chunk is a whole number of 256-Gaussian blocks, one wave per block and pass
+		for (int b0 = g * chunk; b0 < (g + 1) * chunk && b0 < P; b0 += 4 * GSR_BIN_THREADS) {
+			const int blk = b0 / GSR_PRE_BLOCK + (tid >> 6);
+			if (blk * GSR_PRE_BLOCK < (g + 1) * chunk) gs_goff_block(P, blk, tid & 63, tiles_touched, bsums, goff);
+		}
+	}
+	if (SCATTER && ctl->num_binned > cap) return;   // see bin_scatter_kernel
 	uint32_t* row = Hm + (size_t)g * T;
 	for (int i = tid; i < T; i += GSR_BIN_THREADS) cnt[i] = SCATTER ? ranges[i].x + row[i] : 0u;
 	__syncthreads();
@@ -626,19 +642,20 @@ void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const 
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<false>, lds);
 	hipLaunchKernelGGL(bin_chunk_kernel<false>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
-	                   (const uint2*)nullptr, (uint64_t*)nullptr, (const GsCtl*)nullptr, 0u);
+	                   (const uint2*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const GsCtl*)nullptr, 0u);
 	hipLaunchKernelGGL(bin_colscan_kernel, dim3((T + 63) / 64), dim3(64 * GSR_COLSCAN_Q), 0, s, G, T, Hm, tile_count);
 }
 
 void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
-                         const uint2* ranges, uint64_t* keys, const GsCtl* ctl, uint32_t cap, hipStream_t s)
+                         const uint2* ranges, uint64_t* keys, const uint32_t* bsums, uint32_t* goff, const GsCtl* ctl,
+                         uint32_t cap, hipStream_t s)
 {
 	const int G = bin_chunks(P);
 	const int chunk = ((P + G - 1) / G + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS * GSR_BIN_THREADS;
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<true>, lds);
 	hipLaunchKernelGGL(bin_chunk_kernel<true>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
-	                   ranges, keys, ctl, cap);
+	                   ranges, keys, bsums, goff, ctl, cap);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _C
 from .options import current as _current_options
-from .rasterizer import _run_guarded
+from .rasterizer import _dense_image_grads, _run_guarded
 
 ACT_OPACITY_SIGMOID = 1
 ACT_SCALE_EXP = 2
@@ -42,12 +42,15 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings, ctx.num_rendered, ctx.act, ctx.gsr_options = rs, num_rendered, int(act), opts
         ctx.save_for_backward(means3D, f_dc, f_rest, raw_scales, raw_rotations, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)      # as in rasterizer._RasterizeGaussians
+        ctx.set_materialize_grads(False)
         return color, radii, depth, median, opacity
 
     @staticmethod
     def backward(ctx, g_color, g_radii, g_depth, g_median, g_opacity):
         rs = ctx.raster_settings
         means3D, f_dc, f_rest, raw_scales, raw_rotations, radii, geom, binning, img = ctx.saved_tensors
+        g_color, g_depth, g_median, g_opacity = _dense_image_grads(rs, means3D, g_color, g_depth, g_median, g_opacity)
         n = _C.native()
         call = (rs.bg, means3D, radii, f_dc, f_rest, raw_scales, raw_rotations, float(rs.scale_modifier), ctx.act,
                 float(rs.tanfovx), float(rs.tanfovy), g_color, g_depth, g_median, g_opacity, int(rs.sh_degree), geom,

@@ -48,6 +48,15 @@ def _run_guarded(fn, args, debug, dump_name, banner):
         raise
 
 
+def _dense_image_grads(rs, like, g_color, g_depth, g_median, g_opacity):
+    """The kernels read all four upstream gradients; the ones autograd did not produce (outputs the loss did not use:
+    set_materialize_grads(False)) are zeros of the output's shape (colour and median [3,H,W], depth and opacity [1,H,W])."""
+    H, W = int(rs.image_height), int(rs.image_width)
+    z = lambda c: torch.zeros((c, H, W), dtype=torch.float32, device=like.device)
+    return (z(3) if g_color is None else g_color, z(1) if g_depth is None else g_depth,
+            z(3) if g_median is None else g_median, z(1) if g_opacity is None else g_opacity)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -69,6 +78,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf,
                               binning_buf, img_buf)
+        # radii is an int tensor: no gradient, and no zero tensor materialised for it before every backward (autograd
+        # would fill P ints per call); outputs the loss did not use arrive as None and are replaced below
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
         return color, radii, depth, median_depth, final_opacity
 
     @staticmethod
@@ -76,6 +89,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf,
          img_buf) = ctx.saved_tensors
+        grad_out_color, grad_depth, grad_median_depth, grad_final_opacity = _dense_image_grads(
+            rs, means3D, grad_out_color, grad_depth, grad_median_depth, grad_final_opacity)
         # argument order of _C.rasterize_gaussians_backward (rasterize_points.h:40-65)
         call = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth,

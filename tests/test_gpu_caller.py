@@ -158,3 +158,33 @@ def test_renderer_debug_flag_and_mark_visible():
         b = _render_like_base_renderer(props, _Camera(cam, dev), 3, bg, debug=True)
     for k in ("render", "rendered_depth", "rendered_median_depth", "rendered_final_opacity", "radii"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("used", [(0,), (0, 2), (3,), (2, 4)])
+def test_loss_on_a_subset_of_the_outputs(used):
+    """Outputs the loss does not use get no materialised zero gradient from autograd (set_materialize_grads(False), radii
+    marked non-differentiable): the operator fills in the zeros itself, and the parameter gradients equal those of a
+    backward that was handed explicit zeros for the unused outputs."""
+    dev = "cuda"
+    cam = scenes.make_camera(200, 136)
+    sc = scenes.make_scene(4000, cam, seed=7)
+    rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+    gr = [g.to(dev) for g in scenes.make_output_grads(cam, seed=9)]          # for outputs 0, 2, 3, 4
+    slot = {0: 0, 2: 1, 3: 2, 4: 3}
+
+    def run(explicit_zeros):
+        P = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        m2 = torch.zeros_like(P["means3D"], requires_grad=True)
+        out = GaussianRasterizer(rs)(means3D=P["means3D"], means2D=m2, opacities=P["opacities"], shs=P["shs"],
+                                     scales=P["scales"], rotations=P["rotations"])
+        assert not out[1].requires_grad
+        if explicit_zeros:
+            idx = (0, 2, 3, 4)
+            torch.autograd.backward([out[i] for i in idx], [gr[slot[i]] if i in used else torch.zeros_like(out[i]) for i in idx])
+        else:
+            torch.autograd.backward([out[i] for i in used], [gr[slot[i]] for i in used])
+        return [P[k].grad for k in P] + [m2.grad]
+
+    for a, b in zip(run(False), run(True)):
+        assert a is not None and torch.equal(a, b)

@@ -3,7 +3,8 @@
 (`rocprofv3 --kernel-trace --stats -d DIR -o NAME -- cmd` writes DIR/NAME_results.db on ROCm 7.2).
 Dispatches are grouped by (kernel, grid size) so that the benchmark-sized launches are not averaged with the
 tiny start-up launches of runtime.warm_start().
-Usage: python tools/rocpd_summary.py gpurun_out/prof/x_results.db > profiles/rNN_x_kernel_stats.txt"""
+Usage: python tools/rocpd_summary.py gpurun_out/prof/x_results.db > profiles/rNN_x_kernel_stats.txt
+       python tools/rocpd_summary.py x_results.db --sequence 60   # the last 60 dispatches in launch order, with the idle gap before each"""
 import os
 import sqlite3
 import sys
@@ -33,5 +34,27 @@ def main(path):
         print(f"  {short:<58} {gx:>9} {wx:>4} {vg:>4} {lds:>6} {a[0]:>5} {a[4]:>4} {a[1] / 1e3:>10.1f} {a[1] / a[0] / 1e3:>9.2f} {a[2] / 1e3:>9.2f} {a[3] / 1e3:>9.2f} {100 * a[1] / total:>6.2f}")
 
 
+def sequence(path, n):
+    """the last n dispatches (kernels and, when the database has them, memory copies) in start order"""
+    db = sqlite3.connect(path)
+    rows = [(s, e, name, gx) for name, s, e, gx in db.execute("select name, start, end, grid_x from kernels")]
+    try:
+        rows += [(s, e, "<memcpy " + str(nm) + ">", sz) for nm, s, e, sz in db.execute("select name, start, end, size from memory_copies")]
+    except sqlite3.Error:
+        pass
+    rows.sort()
+    rows = rows[-n:]
+    prev = None
+    print(f"# {'start_us':>10} {'gap_us':>7} {'dur_us':>8}  {'grid':>9}  kernel")
+    t0 = rows[0][0]
+    for s, e, name, gx in rows:
+        gap = (s - prev) / 1e3 if prev is not None else 0.0
+        print(f"  {(s - t0) / 1e3:>10.1f} {gap:>7.1f} {(e - s) / 1e3:>8.1f}  {gx:>9}  {name[:90]}")
+        prev = max(prev, e) if prev is not None else e
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 3 and sys.argv[2] == "--sequence":
+        sequence(sys.argv[1], int(sys.argv[3]))
+    else:
+        main(sys.argv[1])
