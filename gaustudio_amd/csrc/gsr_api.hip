@@ -675,7 +675,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	if (!dL_dpix || !dL_dpix_depth || !dL_dpix_median_depth || !dL_dpix_final_opacity)
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL upstream gradient", __FILE__, __LINE__);
 	const bool sh_colors = (parts & GSR_BWD_PART_SH_COLORS) != 0;
-	if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
+	if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || (!dL_dcov3D && cov3D_precomp) || !dL_dscale || !dL_drot ||
 	    (M > 0 && !dL_dsh && !sh_colors))
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL output", __FILE__, __LINE__);
 	if (sh_colors && (!shs || shs_rest || colors_precomp))

@@ -1118,8 +1118,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 	}
 #pragma unroll
 	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] = dmean[i];   // the SH stage adds to it next: stays cached
+	if (dL_dcov != nullptr) {   // optional when the covariance came from scale / rotation: nobody reads it then
 #pragma unroll
-	for (int i = 0; i < 6; i++) gs_st_stream(dL_dcov + 6 * (size_t)idx + i, dcov[i]);
+		for (int i = 0; i < 6; i++) gs_st_stream(dL_dcov + 6 * (size_t)idx + i, dcov[i]);
+	}
 #pragma unroll
 	for (int i = 0; i < 3; i++) gs_st_stream(dL_dscale + 3 * (size_t)idx + i, dscale[i]);
 	gs_st_stream(reinterpret_cast<float4*>(dL_drot + 4 * (size_t)idx), make_float4(dq[0], dq[1], dq[2], dq[3]));

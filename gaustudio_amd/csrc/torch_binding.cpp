@@ -302,7 +302,11 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 	const bool in_arena = arena.outs.size() == 5;
 	const bool factored = arena.colors_out.defined() && M > 0 && sh.numel() != 0;
 	torch::Tensor dL_dmeans3D = in_arena ? arena.outs[0] : torch::empty({P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
-	torch::Tensor dL_dcolors = factored ? arena.colors_out : torch::empty({P, 3}, fo), dL_dcov3D = torch::empty({P, 6}, fo);
+	// dL_dcov3D only when the caller supplied covariances (rasterize_points.cu:129 allocates it always; with scale / rotation
+	// inputs nothing reads it: 24 B per Gaussian less to write)
+	const bool want_dcov = cov3D_precomp.numel() != 0;
+	torch::Tensor dL_dcolors = factored ? arena.colors_out : torch::empty({P, 3}, fo);
+	torch::Tensor dL_dcov3D = want_dcov ? torch::empty({P, 6}, fo) : torch::empty({0, 6}, fo);
 	torch::Tensor dL_dsh = factored ? torch::Tensor() : (in_arena ? arena.outs[1] : torch::empty({P, M, 3}, fo));
 	torch::Tensor dL_dopacity = in_arena ? arena.outs[2] : torch::empty({P, 1}, fo);
 	torch::Tensor dL_dscales = in_arena ? arena.outs[3] : torch::empty({P, 3}, fo);
@@ -319,7 +323,7 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 			    reinterpret_cast<const char*>(imageBuffer.data_ptr()), fptr(g_color, "dL_dout_color"),
 			    fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"), fptr(g_op, "dL_dout_final_opacity"),
 			    dL_dmeans2D.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
-			    dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), (M && !factored) ? dL_dsh.data_ptr<float>() : nullptr, nullptr,
+			    dL_dmeans3D.data_ptr<float>(), want_dcov ? dL_dcov3D.data_ptr<float>() : nullptr, (M && !factored) ? dL_dsh.data_ptr<float>() : nullptr, nullptr,
 			    dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(), reinterpret_cast<char*>(scratch.data_ptr()),
 			    debug ? 1 : 0, current_stream(means3D));
 			if (rc < 0) fail(rc);
@@ -428,7 +432,6 @@ RasterizeGaussiansRawBackward(const torch::Tensor& background, const torch::Tens
 	const auto fo = means3D.options().dtype(torch::kFloat32);
 	torch::Tensor dL_dmeans3D = torch::empty({P, 3}, fo), dL_dmeans2D = torch::empty({P, 3}, fo);
 	torch::Tensor dL_dcolors = torch::empty({P, 3}, fo), dL_dopacity = torch::empty_like(raw_scales_.new_empty({P, 1}));
-	torch::Tensor dL_dcov3D = torch::empty({P, 6}, fo);
 	torch::Tensor dL_df_dc = torch::empty_like(f_dc), dL_df_rest = torch::empty_like(f_rest);
 	torch::Tensor dL_dscales = torch::empty({P, 3}, fo), dL_drotations = torch::empty({P, 4}, fo);
 	if (P != 0) {
@@ -443,7 +446,7 @@ RasterizeGaussiansRawBackward(const torch::Tensor& background, const torch::Tens
 		    reinterpret_cast<const char*>(binningBuffer.data_ptr()), reinterpret_cast<const char*>(imageBuffer.data_ptr()),
 		    fptr(g_color, "dL_dout_color"), fptr(g_depth, "dL_dout_depth"), fptr(g_median, "dL_dout_median_depth"),
 		    fptr(g_op, "dL_dout_final_opacity"), dL_dmeans2D.data_ptr<float>(), dL_dopacity.data_ptr<float>(),
-		    dL_dcolors.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(),
+		    dL_dcolors.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(), nullptr /* dL_dcov3D: no reader */,
 		    dL_df_dc.data_ptr<float>(), M > 1 ? dL_df_rest.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
 		    dL_drotations.data_ptr<float>(), reinterpret_cast<char*>(scratch.data_ptr()), debug ? 1 : 0,
 		    current_stream(means3D));

@@ -100,6 +100,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians_backward, call, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         # back to the input order of forward(); the settings tuple gets no gradient
+        if g_cov3D.numel() == 0:      # covariances built from scale / rotation: the library did not write their gradient
+            g_cov3D = None
         return (g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3D, None)
 
 

@@ -111,7 +111,8 @@ size_t gsr_image_bytes(int width, int height);
  * 16-bit block mask of every list entry, which the compositing backward reads instead of recomputing a cull; a
  * flag in the image buffer says whether the forward left them).  Outputs (all fully overwritten, rows of culled Gaussians = 0):
  *   dL_dmean2D[P,3] (xy used, already scaled by 0.5*W / 0.5*H, backward.cu:493-494,598-599),
- *   dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3] (may be NULL if M==0),
+ *   dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6] (may be NULL when cov3D_precomp is NULL: the gradient
+ *   of a covariance the operator built itself from scale / rotation has no reader), dL_dsh[P,M,3] (may be NULL if M==0),
  *   dL_dscale[P,3], dL_drot[P,4].
  * Only channel 0 of dL_dpix_median_depth[3,H,W] is read (backward.cu:481-482). */
 int gsr_backward(int P, int D, int M, int R,

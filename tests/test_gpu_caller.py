@@ -188,3 +188,39 @@ def test_loss_on_a_subset_of_the_outputs(used):
 
     for a, b in zip(run(False), run(True)):
         assert a is not None and torch.equal(a, b)
+
+
+def test_covariance_gradient_only_when_covariances_were_supplied():
+    """dL_dcov3D has a reader only when the caller passed cov3D_precomp: then the autograd path returns it (equal to the
+    C-ABI's), otherwise the binding passes NULL and the library writes 24 B per Gaussian less; a NULL dL_dcov3D together
+    with a cov3D_precomp is an argument error; everything else is bit-equal either way."""
+    from util import hip_backward_raw, hip_forward, scene_kwargs
+    dev = "cuda"
+    cam = scenes.make_camera(200, 136)
+    sc = scenes.make_scene(4000, cam, seed=11)
+    grads = [g.to(dev) for g in scenes.make_output_grads(cam, seed=5)]
+    rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+    # (1) covariances supplied
+    kw = scene_kwargs(sc, True, True)
+    hs = hip_forward(sc, cam, 3, kw)
+    raw = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+    cov = kw["cov3D_precomp"].to(dev).requires_grad_(True)
+    xyz = sc.means3D.to(dev).requires_grad_(True)
+    out = GaussianRasterizer(rs)(means3D=xyz, means2D=torch.zeros_like(xyz, requires_grad=True), opacities=sc.opacities.to(dev),
+                                 shs=sc.shs.to(dev), cov3D_precomp=cov)
+    torch.autograd.backward([out[0], out[2], out[3], out[4]], grads)
+    assert cov.grad is not None and torch.equal(cov.grad, raw["dL_dcov3D"]) and float(cov.grad.abs().max()) > 0
+    assert torch.equal(xyz.grad, raw["dL_dmeans3D"])
+    with pytest.raises(Exception):
+        hip_backward_raw(hs, sc, cam, 3, kw, grads, no_dcov=True)
+    # (2) scale / rotation: NULL dL_dcov3D, the other seven outputs unchanged
+    kw = scene_kwargs(sc, True, False)
+    kw["rotations"] = sc.rotations
+    hs = hip_forward(sc, cam, 3, kw)
+    a = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+    b = hip_backward_raw(hs, sc, cam, 3, kw, grads, no_dcov=True)
+    for k in a:
+        if k != "dL_dcov3D":
+            assert torch.equal(a[k], b[k]), k
+    assert bool(torch.isnan(b["dL_dcov3D"]).all())       # untouched (the helper poisons its buffers with NaN)

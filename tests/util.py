@@ -124,7 +124,7 @@ def make_options(L, struct_bytes=None, **fields):
     return o
 
 
-def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False, options=None):
+def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False, options=None, no_dcov=False):
     """gsr_backward (or, with `options` = a GsrOptions / None-able dict, gsr_backward_ex) called straight through ctypes
     with a test-owned scratch buffer, so that the composite-stage accumulator rows (scratch[P,12]) can be inspected next
     to the 8 outputs."""
@@ -147,6 +147,7 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
     scratch = torch.full((nscratch,), 0xAB, dtype=torch.uint8, device=dev)   # poison: the library must zero it
     means = sc.means3D.to(dev); shs = g("shs"); col = g("colors_precomp"); scl = g("scales"); rot = g("rotations")
     cov = g("cov3D_precomp")
+    dcov = None if no_dcov else out["dL_dcov3D"]     # NULL is allowed when cov3D_precomp is NULL (include/gsrast.h)
     view = cam.viewmatrix.to(dev); proj = cam.projmatrix.to(dev); cpos = cam.campos.to(dev)
     p = _C._ptr
     if options is not None:
@@ -156,7 +157,7 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
                                p(means), p(shs), p(None), p(col), p(scl), ctypes.c_float(scale_modifier), p(rot), p(cov), ctypes.c_int(0),
                                ctypes.c_float(cam.tanfovx), ctypes.c_float(cam.tanfovy), p(hs["radii"]), p(hs["geom"]), p(hs["binning"]),
                                p(hs["img"]), p(gc), p(gd), p(gm), p(go), p(out["dL_dmeans2D"]), p(out["dL_dopacity"]), p(out["dL_dcolors"]),
-                               p(out["dL_dmeans3D"]), p(out["dL_dcov3D"]), p(out["dL_dsh"]), p(None), p(out["dL_dscales"]),
+                               p(out["dL_dmeans3D"]), p(dcov), p(out["dL_dsh"]), p(None), p(out["dL_dscales"]),
                                p(out["dL_drotations"]), p(scratch), ctypes.c_int(bool(debug)), _C._stream(dev))
         if rc < 0:
             raise _C._err(L, rc)
@@ -167,7 +168,7 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
                         ctypes.c_float(scale_modifier), p(rot), p(cov), p(view), p(proj), p(cpos),
                         ctypes.c_float(cam.tanfovx), ctypes.c_float(cam.tanfovy), p(hs["radii"]), p(hs["geom"]),
                         p(hs["binning"]), p(hs["img"]), p(gc), p(gd), p(gm), p(go), p(out["dL_dmeans2D"]),
-                        p(out["dL_dopacity"]), p(out["dL_dcolors"]), p(out["dL_dmeans3D"]), p(out["dL_dcov3D"]),
+                        p(out["dL_dopacity"]), p(out["dL_dcolors"]), p(out["dL_dmeans3D"]), p(dcov),
                         p(out["dL_dsh"]), p(out["dL_dscales"]), p(out["dL_drotations"]), p(scratch),
                         ctypes.c_int(bool(debug)), _C._stream(dev))
     if rc < 0:
