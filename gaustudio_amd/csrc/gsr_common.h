@@ -120,9 +120,12 @@ __device__ __forceinline__ float gs_log(float x)
 // +0.05; the box another 0.01 px.  Degenerate / non-positive-definite / NaN inputs keep the reference rect.
 // In/out: the reference rect; returns false when no tile can hold a live pixel.  Mirrored bit for bit by
 // oracle/gsr_oracle.c:orc_tight_rects (explicit ternaries instead of fmin/fmax so that NaN behaves identically).
+// qmax (out): 2 * teff, the bound on a dx^2 + 2 b dx dy + c dy^2 inside which every pixel that can pass lies -- for the
+// corner-tile test below; negative when the rect was kept as it was (no usable ellipse).
 __device__ __forceinline__ bool gs_tight_rect(float px, float py, float ca, float cb, float cc, float op, int gx, int gy,
-                                              int& rminx, int& rminy, int& rmaxx, int& rmaxy)
+                                              int& rminx, int& rminy, int& rmaxx, int& rmaxy, float& qmax)
 {
+	qmax = -1.0f;
 	if (op <= 0.0f) return false;                       // alpha = min(0.99, op * G) <= 0 < 1/255 everywhere
 	const float t = gs_log(255.0f * op) + 0.01f;
 	if (t <= 0.0f) return false;                        // 255 * op <= 0.99: alpha < 1/255 everywhere
@@ -132,6 +135,7 @@ __device__ __forceinline__ bool gs_tight_rect(float px, float py, float ca, floa
 	if (!(rel < 1.0e5f)) return true;
 	const float teff = FMA(t * 4.0e-5f, rel, t) + 0.05f;
 	if (!(teff > 0.0f)) return true;
+	qmax = 2.0f * teff;
 	const float ex = sqrtf((2.0f * teff) * (cc / det)) + 0.01f;
 	const float ey = sqrtf((2.0f * teff) * (ca / det)) + 0.01f;
 	// tile column k holds pixel centres 16k .. 16k+15
@@ -145,6 +149,78 @@ __device__ __forceinline__ bool gs_tight_rect(float px, float py, float ca, floa
 	rminx = max(rminx, (int)fx0); rmaxx = min(rmaxx, (int)fx1);
 	rminy = max(rminy, (int)fy0); rmaxy = min(rmaxy, (int)fy1);
 	return rmaxx > rminx && rmaxy > rminy;
+}
+
+// Corner tiles of the tight rect.  The rect is the bounding box of the ellipse q(d) = a dx^2 + 2 b dx dy + c dy^2 <= qmax
+// (gs_tight_rect); the ellipse does not reach into the corners of its box, and at C3 7 % of the binned instances are
+// corner tiles of a >= 2 x 2 rect that hold no live pixel (86 % of all dead instances, tools/scene_stats.py).  A corner
+// tile is dropped when the minimum of q over the tile's box of pixel centres exceeds qmax: the minimum of a convex
+// quadratic over a box that does not contain the centre lies on the edges facing the centre and is found in closed form
+// per edge.  Conservative: the box is the continuous hull of the pixel centres, qmax already carries the slack for the
+// rounding of the per-pixel `power` (gs_tight_rect), and this evaluation gets 1e-5 of its terms' magnitude + 0.05 of its
+// own; anything unordered (NaN) keeps the tile.  IEEE +, *, / only, mirrored operation for operation by
+// oracle/gsr_oracle.c:tile_may_touch -- the two must take the same decision for every tile.
+__device__ __forceinline__ bool gs_tile_may_touch(float px, float py, float ca, float cb, float cc, float qmax, int tx, int ty,
+                                                  int W, int H)
+{
+	const float bx0 = (float)(16 * tx), by0 = (float)(16 * ty);
+	float bx1 = bx0 + 15.0f, by1 = by0 + 15.0f;
+	const float wm = (float)(W - 1), hm = (float)(H - 1);
+	bx1 = bx1 < wm ? bx1 : wm;
+	by1 = by1 < hm ? by1 : hm;
+	const float X0 = px - bx1, X1 = px - bx0;   // range of dx = centre - pixel over the box
+	const float Y0 = py - by1, Y1 = py - by0;
+	const float xn = X0 > 0.0f ? X0 : (X1 < 0.0f ? X1 : 0.0f);   // point of the range nearest to 0
+	const float yn = Y0 > 0.0f ? Y0 : (Y1 < 0.0f ? Y1 : 0.0f);
+	if (xn == 0.0f && yn == 0.0f) return true;                   // centre inside the box
+	float best = 3.0e38f, mag = 0.0f;
+	if (xn != 0.0f) {   // edge dx = xn: q is minimal at dy = -b xn / c, clamped to the edge
+		float dy = -(cb * xn) / cc;
+		dy = dy < Y0 ? Y0 : dy;
+		dy = dy > Y1 ? Y1 : dy;
+		const float t0 = (ca * xn) * xn, t1 = ((2.0f * cb) * xn) * dy, t2 = (cc * dy) * dy;
+		best = (t0 + t2) + t1;
+		mag = (t0 + t2) + (t1 < 0.0f ? -t1 : t1);
+	}
+	if (yn != 0.0f) {   // edge dy = yn
+		float dx = -(cb * yn) / ca;
+		dx = dx < X0 ? X0 : dx;
+		dx = dx > X1 ? X1 : dx;
+		const float t0 = (cc * yn) * yn, t1 = ((2.0f * cb) * yn) * dx, t2 = (ca * dx) * dx;
+		const float q = (t0 + t2) + t1, m = (t0 + t2) + (t1 < 0.0f ? -t1 : t1);
+		if (q < best) { best = q; mag = m; }
+	}
+	return !(best > qmax + (1.0e-5f * mag + 0.05f));
+}
+
+// Bits 0..3: the top-left, top-right, bottom-left, bottom-right tile of the rect [rminx, rmaxx) x [rminy, rmaxy) holds no
+// pixel that can pass (rects of at least 2 x 2 tiles only; qmax < 0: no usable ellipse, nothing dropped).
+__device__ __forceinline__ uint32_t gs_dead_corners(float px, float py, float ca, float cb, float cc, float qmax, int rminx,
+                                                    int rminy, int rmaxx, int rmaxy, int W, int H)
+{
+	if (!(qmax > 0.0f) || rmaxx - rminx < 2 || rmaxy - rminy < 2) return 0u;
+	uint32_t dead = 0u;
+	if (!gs_tile_may_touch(px, py, ca, cb, cc, qmax, rminx, rminy, W, H)) dead |= 1u;
+	if (!gs_tile_may_touch(px, py, ca, cb, cc, qmax, rmaxx - 1, rminy, W, H)) dead |= 2u;
+	if (!gs_tile_may_touch(px, py, ca, cb, cc, qmax, rminx, rmaxy - 1, W, H)) dead |= 4u;
+	if (!gs_tile_may_touch(px, py, ca, cb, cc, qmax, rmaxx - 1, rmaxy - 1, W, H)) dead |= 8u;
+	return dead;
+}
+
+// q3 of a record = {rect min (x | y << 16), rect max, clamp bits (0..2) | dead corners << 8, binned tiles}.
+#define GSR_Q3Z_DEAD_SHIFT 8
+// Position of tile (tx, ty) among the BINNED tiles of the Gaussian (row-major over its rect, dead corners left out): the
+// instance's row behind goff[id] in the backward's Gaussian-major row buffer.
+__device__ __forceinline__ uint32_t gs_row_in_rect(uint32_t q3x, uint32_t q3y, uint32_t dead, int tx, int ty)
+{
+	const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
+	int idx = (ty - rminy) * rw + (tx - rminx);
+	if (dead != 0u) {
+		const int rh = (int)(q3y >> 16) - rminy;
+		// dead corners in front of idx (the bottom-right one is last: never in front)
+		idx -= (int)((dead & 1u) && idx > 0) + (int)(((dead >> 1) & 1u) && idx > rw - 1) + (int)(((dead >> 2) & 1u) && idx > (rh - 1) * rw);
+	}
+	return (uint32_t)idx;
 }
 
 // Streaming accesses (read once / written once, never re-read by the same kernel): the nontemporal hint keeps

@@ -271,8 +271,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	for (int i = bmax + tid; !FLAGS && i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
 		const uint32_t id = point_list[range.x + i];
 		const uint4 q3 = recs[id].q3;
-		const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
-		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx))) * GSR_ROW_STRIDE);
+		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(goff[id] + gs_row_in_rect(q3.x, q3.y, (q3.z >> GSR_Q3Z_DEAD_SHIFT) & 15u, tx, ty)) * GSR_ROW_STRIDE);
 		dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -307,8 +306,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 				// Gaussian-major row of this (tile, Gaussian) instance: goff[g] (fetched with the record) + raster index
 				// of the tile inside the Gaussian's tile rect
 				const uint32_t q3x = __float_as_uint(part_cur.x), q3y = __float_as_uint(part_cur.y), q3w = __float_as_uint(part_cur.w);
-				const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
-				s_row[srec] = q3w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
+				s_row[srec] = q3w + gs_row_in_rect(q3x, q3y, (__float_as_uint(part_cur.z) >> GSR_Q3Z_DEAD_SHIFT) & 15u, tx, ty);
 			}
 		}
 		// request the next batch's records and the ids of the one after: in flight during this batch's walk
@@ -580,8 +578,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	for (int i = bmax + tid; !FLAGS && i < (int)(range.y - range.x); i += GSR_BWD_THREADS) {
 		const uint32_t id = point_list[range.x + i];
 		const uint4 q3 = recs[id].q3;
-		const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rw = (int)(q3.y & 0xffff) - rminx;
-		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(goff[id] + (uint32_t)((ty - rminy) * rw + (tx - rminx))) * GSR_ROW_STRIDE);
+		float4* dst = reinterpret_cast<float4*>(rows + (size_t)(goff[id] + gs_row_in_rect(q3.x, q3.y, (q3.z >> GSR_Q3Z_DEAD_SHIFT) & 15u, tx, ty)) * GSR_ROW_STRIDE);
 		dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 		dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -598,9 +595,10 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 		if (t > 0 && srec + 64 * h < min(GSR_BWQ_BATCH, t)) {
 			v = reinterpret_cast<const float4*>(recs + id)[spart];
-			if (spart == 3) {   // q3 = {rect min, rect max, clamp bits, tiles}: .w <- first row, .z <- the forward's block mask
+			if (spart == 3) {   // q3 = {rect min, rect max, clamp bits | dead corners, tiles}: .w <- first row, .z <- dead corners << 16 | the forward's block mask
 				v.w = __uint_as_float(goff[id]);
-				if (have_qmask) v.z = __uint_as_float((uint32_t)qmask[range.x + (uint32_t)(t - 1 - (srec + 64 * h))]);
+				const uint32_t dead = (__float_as_uint(v.z) >> GSR_Q3Z_DEAD_SHIFT) & 15u;
+				v.z = __uint_as_float((dead << 16) | (have_qmask ? (uint32_t)qmask[range.x + (uint32_t)(t - 1 - (srec + 64 * h))] : 0u));
 			}
 		}
 		return v;
@@ -633,9 +631,9 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 				else if (spart == 2) sC[sr] = part_cur[h];
 				else {
 					const uint32_t q3x = __float_as_uint(part_cur[h].x), q3y = __float_as_uint(part_cur[h].y), q3w = __float_as_uint(part_cur[h].w);
-					const int rminx = q3x & 0xffff, rminy = q3x >> 16, rw = (int)(q3y & 0xffff) - rminx;
-					s_row[sr] = q3w + (uint32_t)((ty - rminy) * rw + (tx - rminx));
-					s_qmask[sr] = (uint16_t)__float_as_uint(part_cur[h].z);
+					const uint32_t q3z = __float_as_uint(part_cur[h].z);
+					s_row[sr] = q3w + gs_row_in_rect(q3x, q3y, (q3z >> 16) & 15u, tx, ty);
+					s_qmask[sr] = (uint16_t)q3z;
 				}
 			}
 		}

@@ -51,17 +51,22 @@ void launch_mark_visible(int P, const float* means3D, const float* view, unsigne
 #define GSR_COOP_TILES 32
 
 template <typename F>
-__device__ __forceinline__ void for_each_tile(bool active, int rminx, int rminy, int rmaxx, int rmaxy,
+__device__ __forceinline__ void for_each_tile(bool active, int rminx, int rminy, int rmaxx, int rmaxy, uint32_t dead,
                                               uint32_t pay0, uint32_t pay1, F&& f)
 {
 	// f(x, y, p0, p1): p0/p1 are the OWNING lane's payload (shuffled in the cooperative path; the
 	// shuffles sit outside the divergent tile loop so that the source lane is always active).
+	// dead: corner tiles of the rect that are not binned (gs_dead_corners; 0 for rects under 2 x 2).
 	const int w = rmaxx - rminx, h = rmaxy - rminy;
 	const int n = active ? w * h : 0;
 	const bool big = n > GSR_COOP_TILES;
 	if (n > 0 && !big) {
-		for (int y = rminy; y < rmaxy; y++)
-			for (int x = rminx; x < rmaxx; x++) f(x, y, pay0, pay1);
+		// one loop for all lanes of the wave (lanes with and without dead corners take the same path): a dead corner
+		// shortens the first / last row by a tile at its end
+		for (int y = rminy; y < rmaxy; y++) {
+			const uint32_t drow = y == rminy ? dead : (y == rmaxy - 1 ? dead >> 2 : 0u);
+			for (int x = rminx + (int)(drow & 1u); x < rmaxx - (int)((drow >> 1) & 1u); x++) f(x, y, pay0, pay1);
+		}
 	}
 	unsigned long long m = __ballot(big);
 	const int lane = threadIdx.x & 63;
@@ -70,8 +75,15 @@ __device__ __forceinline__ void for_each_tile(bool active, int rminx, int rminy,
 		m &= m - 1;
 		const int sx = __shfl(rminx, src, 64), sy = __shfl(rminy, src, 64);
 		const int sw = __shfl(w, src, 64), sn = __shfl(n, src, 64);
+		const uint32_t sd = (uint32_t)__shfl((int)dead, src, 64);
 		const uint32_t p0 = (uint32_t)__shfl((int)pay0, src, 64), p1 = (uint32_t)__shfl((int)pay1, src, 64);
-		for (int t = lane; t < sn; t += 64) f(sx + t % sw, sy + t / sw, p0, p1);
+		const int sh = sn / sw;
+		for (int t = lane; t < sn; t += 64) {
+			const int cx = t % sw, cy = t / sw;
+			if (sd != 0u && (cx == 0 || cx == sw - 1) && (cy == 0 || cy == sh - 1) && ((sd >> ((cx == 0 ? 0 : 1) + (cy == 0 ? 0 : 2))) & 1u))
+				continue;
+			f(sx + cx, sy + cy, p0, p1);
+		}
 	}
 }
 
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 		} while (0);
 	}
 
-	uint32_t my_tiles = 0;
+	uint32_t my_tiles = 0, dead = 0;
 	if (vis) {
 		float rgb[3];
 		uint32_t clamped = 0;
@@ -244,14 +256,17 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 		const float op = gs_act_opacity(op_raw, act);
 		// bin into the tight sub-rect of the reference's square (radii and the reported num_rendered keep the
 		// reference's definition); a Gaussian that cannot reach alpha >= 1/255 anywhere is binned nowhere
-		if (tight && !gs_tight_rect(pix_x, pix_y, conic_x, conic_y, conic_z, op, gx, gy, rminx, rminy, rmaxx, rmaxy))
+		float qmax = -1.0f;
+		if (tight && !gs_tight_rect(pix_x, pix_y, conic_x, conic_y, conic_z, op, gx, gy, rminx, rminy, rmaxx, rmaxy, qmax))
 			rminx = rminy = rmaxx = rmaxy = 0;
 		// tile-grid sharding of one view across GPUs (gsr_set_option("tile_row_lo" / "tile_row_hi")): this process only
 		// bins -- and therefore only composites and differentiates -- the tile rows of its band
 		rminy = max(rminy, band_lo);
 		rmaxy = min(rmaxy, band_hi);
 		if (rmaxy <= rminy) rminx = rminy = rmaxx = rmaxy = 0;
-		my_tiles = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
+		// ... and not into the corner tiles of that rect the ellipse does not reach
+		dead = gs_dead_corners(pix_x, pix_y, conic_x, conic_y, conic_z, qmax, rminx, rminy, rmaxx, rmaxy, W, H);
+		my_tiles = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx)) - (uint32_t)__popc(dead);
 		// pcut: power < pcut  ==>  op*exp(power) < 1/255 with a 1e-3 margin, so skipping the pair is
 		// bit-identical to evaluating it and failing `alpha < 1/255` (forward.cu:346).  Clamped to the
 		// domain of gs_exp.  op <= 0 -> +inf (always skipped); NaN -> -80 (never skipped by pcut).
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 		rec.q1 = make_float4(-0.5f * conic_z, op, depth, pcut);
 		rec.q2 = make_float4(rgb[0], rgb[1], rgb[2], __int_as_float(mr));
 		rec.q3 = make_uint4((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16),
-		                    clamped, my_tiles);
+		                    clamped | (dead << GSR_Q3Z_DEAD_SHIFT), my_tiles);
 		recs[idx] = rec;
 	}
 	if (idx < P) {
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 	// fallback binning only (tile grids too large for the LDS histogram): count instances per tile with
 	// device-scope atomics.  The default path counts in bin_hist_kernel without global atomics.
 	if (tile_count != nullptr)
-		for_each_tile(my_tiles > 0, rminx, rminy, rmaxx, rmaxy, 0u, 0u,
+		for_each_tile(my_tiles > 0, rminx, rminy, rmaxx, rmaxy, dead, 0u, 0u,
 		              [&](int x, int y, uint32_t, uint32_t) { atomicAdd(&tile_count[y * gx + x], 1u); });
 }
 
@@ -508,15 +523,16 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const i
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	bool vis = false;
 	int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
-	uint32_t dbits = 0;
+	uint32_t dbits = 0, dead = 0;
 	if (idx < P && radii[idx] > 0 && tiles_touched[idx] > 0) {
 		vis = true;
 		const uint4 q3 = recs[idx].q3;
 		rminx = q3.x & 0xffff; rminy = q3.x >> 16;
 		rmaxx = q3.y & 0xffff; rmaxy = q3.y >> 16;
+		dead = (q3.z >> GSR_Q3Z_DEAD_SHIFT) & 15u;
 		dbits = (uint32_t)__float_as_int(recs[idx].q1.z);
 	}
-	for_each_tile(vis, rminx, rminy, rmaxx, rmaxy, dbits, (uint32_t)idx, [&](int x, int y, uint32_t d, uint32_t id) {
+	for_each_tile(vis, rminx, rminy, rmaxx, rmaxy, dead, dbits, (uint32_t)idx, [&](int x, int y, uint32_t d, uint32_t id) {
 		// key = | depth bits | id |: within a tile the order is (depth, id) exactly as the stable
 		// radix sort of rasterizer_impl.cu:98-109,306-311 produces (depth > 0.2 so bits order as uint)
 		const int tile = y * gx + x;
@@ -576,15 +592,16 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int c
 		const int idx = base + off + tid;
 		bool vis = false;
 		int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
-		uint32_t dbits = 0;
+		uint32_t dbits = 0, dead = 0;
 		if (idx < P && tiles_touched[idx] > 0) {
 			vis = true;
 			const uint4 q3 = recs[idx].q3;
 			rminx = q3.x & 0xffff; rminy = q3.x >> 16;
 			rmaxx = q3.y & 0xffff; rmaxy = q3.y >> 16;
+			dead = (q3.z >> GSR_Q3Z_DEAD_SHIFT) & 15u;
 			if (SCATTER) dbits = (uint32_t)__float_as_int(recs[idx].q1.z);
 		}
-		for_each_tile(vis, rminx, rminy, rmaxx, rmaxy, dbits, (uint32_t)idx, [&](int x, int y, uint32_t d, uint32_t id) {
+		for_each_tile(vis, rminx, rminy, rmaxx, rmaxy, dead, dbits, (uint32_t)idx, [&](int x, int y, uint32_t d, uint32_t id) {
 			const uint32_t slot = atomicAdd(&cnt[y * gx + x], 1u);   // ds_add(_rtn)_u32
 			if (SCATTER) keys[slot] = ((uint64_t)d << 32) | id;
 		});

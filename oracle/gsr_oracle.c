@@ -406,8 +406,9 @@ static inline float orc_log(float x)
 }
 
 static int tight_rect(float px, float py, float ca, float cb, float cc, float op, int gx, int gy, int* rminx,
-                      int* rminy, int* rmaxx, int* rmaxy)
+                      int* rminy, int* rmaxx, int* rmaxy, float* qmax)
 {
+	*qmax = -1.0f;
 	if (op <= 0.0f) return 0;
 	const float t = orc_log(255.0f * op) + 0.01f;
 	if (t <= 0.0f) return 0;
@@ -417,6 +418,7 @@ static int tight_rect(float px, float py, float ca, float cb, float cc, float op
 	if (!(rel < 1.0e5f)) return 1;
 	const float teff = FMA(t * 4.0e-5f, rel, t) + 0.05f;
 	if (!(teff > 0.0f)) return 1;
+	*qmax = 2.0f * teff;
 	const float ex = sqrtf((2.0f * teff) * (cc / det)) + 0.01f;
 	const float ey = sqrtf((2.0f * teff) * (ca / det)) + 0.01f;
 	float fx0 = ceilf((px - ex - 15.0f) * 0.0625f), fx1 = floorf((px + ex) * 0.0625f) + 1.0f;
@@ -431,31 +433,89 @@ static int tight_rect(float px, float py, float ca, float cb, float cc, float op
 	return *rmaxx > *rminx && *rmaxy > *rminy;
 }
 
-/* tight != 0: gs_tight_rect; tight == 0: the reference's getRect squares.  Returns the number of instances. */
+/* gsr_common.h gs_tile_may_touch, operation for operation: can a pixel centre of tile (tx, ty) lie inside the ellipse
+ * a dx^2 + 2 b dx dy + c dy^2 <= qmax?  (The product does not bin the corner tiles of a tight rect for which this says no.) */
+static int tile_may_touch(float px, float py, float ca, float cb, float cc, float qmax, int tx, int ty, int W, int H)
+{
+	const float bx0 = (float)(16 * tx), by0 = (float)(16 * ty);
+	float bx1 = bx0 + 15.0f, by1 = by0 + 15.0f;
+	const float wm = (float)(W - 1), hm = (float)(H - 1);
+	bx1 = bx1 < wm ? bx1 : wm;
+	by1 = by1 < hm ? by1 : hm;
+	const float X0 = px - bx1, X1 = px - bx0;
+	const float Y0 = py - by1, Y1 = py - by0;
+	const float xn = X0 > 0.0f ? X0 : (X1 < 0.0f ? X1 : 0.0f);
+	const float yn = Y0 > 0.0f ? Y0 : (Y1 < 0.0f ? Y1 : 0.0f);
+	if (xn == 0.0f && yn == 0.0f) return 1;
+	float best = 3.0e38f, mag = 0.0f;
+	if (xn != 0.0f) {
+		float dy = -(cb * xn) / cc;
+		dy = dy < Y0 ? Y0 : dy;
+		dy = dy > Y1 ? Y1 : dy;
+		const float t0 = (ca * xn) * xn, t1 = ((2.0f * cb) * xn) * dy, t2 = (cc * dy) * dy;
+		best = (t0 + t2) + t1;
+		mag = (t0 + t2) + (t1 < 0.0f ? -t1 : t1);
+	}
+	if (yn != 0.0f) {
+		float dx = -(cb * yn) / ca;
+		dx = dx < X0 ? X0 : dx;
+		dx = dx > X1 ? X1 : dx;
+		const float t0 = (cc * yn) * yn, t1 = ((2.0f * cb) * yn) * dx, t2 = (ca * dx) * dx;
+		const float q = (t0 + t2) + t1, m = (t0 + t2) + (t1 < 0.0f ? -t1 : t1);
+		if (q < best) { best = q; mag = m; }
+	}
+	return !(best > qmax + (1.0e-5f * mag + 0.05f));
+}
+
+/* gs_dead_corners: bits 0..3 = top-left, top-right, bottom-left, bottom-right tile of the rect not binned */
+static uint32_t dead_corners(float px, float py, float ca, float cb, float cc, float qmax, const int* r, int W, int H)
+{
+	if (!(qmax > 0.0f) || r[2] - r[0] < 2 || r[3] - r[1] < 2) return 0u;
+	uint32_t dead = 0u;
+	if (!tile_may_touch(px, py, ca, cb, cc, qmax, r[0], r[1], W, H)) dead |= 1u;
+	if (!tile_may_touch(px, py, ca, cb, cc, qmax, r[2] - 1, r[1], W, H)) dead |= 2u;
+	if (!tile_may_touch(px, py, ca, cb, cc, qmax, r[0], r[3] - 1, W, H)) dead |= 4u;
+	if (!tile_may_touch(px, py, ca, cb, cc, qmax, r[2] - 1, r[3] - 1, W, H)) dead |= 8u;
+	return dead;
+}
+
+static inline int corner_is_dead(const int32_t* r, uint32_t dead, int x, int y)
+{
+	if (dead == 0u) return 0;
+	if (!((x == r[0] || x == r[2] - 1) && (y == r[1] || y == r[3] - 1))) return 0;
+	return (int)((dead >> ((x == r[0] ? 0 : 1) + (y == r[1] ? 0 : 2))) & 1u);
+}
+
+/* tight != 0: gs_tight_rect + gs_dead_corners (dead[P], may be NULL when tight == 0); tight == 0: the reference's getRect
+ * squares.  Returns the number of instances. */
 int64_t orc_rects(int P, int W, int H, const float* means2D, const float* conic_opacity, const int* radii, int tight,
-                  int32_t* rects, uint32_t* tiles)
+                  int32_t* rects, uint32_t* tiles, uint8_t* dead)
 {
 	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 	int64_t R = 0;
 	for (int idx = 0; idx < P; idx++) {
 		int r[4] = {0, 0, 0, 0};
+		uint32_t dc = 0u;
 		if (radii[idx] > 0) {
 			getRect(means2D[2 * idx], means2D[2 * idx + 1], radii[idx], gx, gy, &r[0], &r[1], &r[2], &r[3]);
 			const float* co = conic_opacity + 4 * (size_t)idx;
+			float qmax = -1.0f;
 			if (tight && !tight_rect(means2D[2 * idx], means2D[2 * idx + 1], co[0], co[1], co[2], co[3], gx, gy, &r[0],
-			                         &r[1], &r[2], &r[3]))
+			                         &r[1], &r[2], &r[3], &qmax))
 				r[0] = r[1] = r[2] = r[3] = 0;
+			if (tight) dc = dead_corners(means2D[2 * idx], means2D[2 * idx + 1], co[0], co[1], co[2], qmax, r, W, H);
 		}
+		if (dead) dead[idx] = (uint8_t)dc;
 		for (int k = 0; k < 4; k++) rects[4 * (size_t)idx + k] = r[k];
-		const uint32_t n = (uint32_t)((r[2] - r[0]) * (r[3] - r[1]));
+		const uint32_t n = (uint32_t)((r[2] - r[0]) * (r[3] - r[1])) - (uint32_t)__builtin_popcount(dc);
 		if (tiles) tiles[idx] = n;
 		R += n;
 	}
 	return R;
 }
 
-/* orc_bin_sort over explicit rects (see orc_rects) */
-void orc_bin_sort_rects(int P, int W, int H, const float* depths, const int32_t* rects, int64_t R,
+/* orc_bin_sort over explicit rects and their dead corners (see orc_rects; dead may be NULL) */
+void orc_bin_sort_rects(int P, int W, int H, const float* depths, const int32_t* rects, const uint8_t* dead, int64_t R,
                         uint32_t* point_list, uint32_t* ranges)
 {
 	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
@@ -467,6 +527,7 @@ void orc_bin_sort_rects(int P, int W, int H, const float* depths, const int32_t*
 		memcpy(&dbits, &depths[idx], 4);
 		for (int y = r[1]; y < r[3]; y++)
 			for (int x = r[0]; x < r[2]; x++) {
+				if (dead && corner_is_dead(r, dead[idx], x, y)) continue;
 				uint64_t key = (uint64_t)(y * gx + x);
 				key <<= 32;
 				key |= dbits;

@@ -83,8 +83,8 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
     """Returns a dict with the five outputs + radii + every intermediate buffer (the state the
     reference keeps in geomBuffer / binningBuffer / imgBuffer).
 
-    tight=False follows the reference exactly (getRect squares).  tight=True bins into the product's tight rects
-    (gs_tight_rect, restated in gsr_oracle.c:orc_rects): `num_rendered` stays the reference's count, `num_binned`,
+    tight=False follows the reference exactly (getRect squares).  tight=True bins into the product's tight rects minus their
+    dead corner tiles (gs_tight_rect / gs_dead_corners, restated in gsr_oracle.c:orc_rects): `num_rendered` stays the reference's count, `num_binned`,
     `tiles_touched`, `point_list`, `ranges`, `n_contrib` describe the shorter lists; images must not change."""
     L = lib()
     means3D = _f32(means3D)
@@ -117,11 +117,12 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
     if tight:
         st["rects"] = np.zeros((P, 4), np.int32)
         st["tiles_touched"] = np.zeros(P, np.uint32)
+        st["dead_corners"] = np.zeros(P, np.uint8)       # bits 0..3: TL, TR, BL, BR tile of the rect not binned
         R = int(L.orc_rects(P, int(W), int(H), _p(st["means2D"]), _p(st["conic_opacity"]), _p(st["radii"]), 1,
-                            _p(st["rects"]), _p(st["tiles_touched"])))
+                            _p(st["rects"]), _p(st["tiles_touched"]), _p(st["dead_corners"])))
         pl = np.zeros(max(R, 1), np.uint32)
-        L.orc_bin_sort_rects(P, int(W), int(H), _p(st["depths"]), _p(st["rects"]), ctypes.c_int64(R), _p(pl),
-                             _p(st["ranges"]))
+        L.orc_bin_sort_rects(P, int(W), int(H), _p(st["depths"]), _p(st["rects"]), _p(st["dead_corners"]),
+                             ctypes.c_int64(R), _p(pl), _p(st["ranges"]))
     else:
         pl = np.zeros(max(R, 1), np.uint32)
         L.orc_bin_sort(P, int(W), int(H), _p(st["means2D"]), _p(st["depths"]), _p(st["radii"]),

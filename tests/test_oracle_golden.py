@@ -155,6 +155,14 @@ def test_tight_binning_is_invisible_in_the_oracle(oracle, case):
     assert int(b["tiles_touched"].sum()) == b["num_binned"]
     if case != "op1":
         assert b["num_binned"] < a["num_binned"]
+    # the corner tiles of the tight rects that the ellipse does not reach are not binned either (gs_dead_corners): the
+    # cases with rects of 2 x 2 tiles and more must exercise it
+    dc = b["dead_corners"]
+    w_, h_ = b["rects"][:, 2] - b["rects"][:, 0], b["rects"][:, 3] - b["rects"][:, 1]
+    assert not dc[(w_ < 2) | (h_ < 2)].any()
+    assert int(b["tiles_touched"].sum()) == int((w_ * h_).sum()) - int(sum(bin(int(v)).count("1") for v in dc))
+    if case in ("c1", "ragged", "huge", "aniso_lowop", "ring"):
+        assert int((dc != 0).sum()) > 0, "no dead corner in a case that should have some"
     # per tile: sub-sequence + every contributor kept.  A contributor of pixel p is a list entry that passes the
     # alpha test at p before p's last_contributor; the union over the tile's pixels must survive.
     W, H = cam.width, cam.height

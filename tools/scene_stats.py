@@ -184,3 +184,29 @@ for t in tiles.tolist():
                     seen |= s_
                 groups += 1; coll += int(c)
 print(f"composite_bwd groups of 4 steps: {groups}; with two quarters of the wave in the same instance: {coll} ({coll / max(1, groups):.3f})")
+
+# ---- dead instances (no live pixel in the tile) by their place in the Gaussian's tile rect: how many would a cull of the
+# rect's four CORNER tiles remove?  (rect of a Gaussian = min / max tile of its instances: the binning emits whole rects) ----
+tile_of = torch.repeat_interleave(torch.arange(L.numel(), device=pl.device), L)            # tile of every list position
+txs, tys = tile_of % gx, tile_of // gx
+big = 1 << 20
+mnx = torch.full((P,), big, device=pl.device).scatter_reduce(0, pl, txs, "amin"); mxx = torch.full((P,), -1, device=pl.device).scatter_reduce(0, pl, txs, "amax")
+mny = torch.full((P,), big, device=pl.device).scatter_reduce(0, pl, tys, "amin"); mxy = torch.full((P,), -1, device=pl.device).scatter_reduce(0, pl, tys, "amax")
+n_inst = n_dead = n_corner = n_dead_corner = n_corner_elig = 0
+for t in tiles.tolist():
+    a, b = int(r[t, 0]), int(r[t, 1])
+    if b <= a: continue
+    ids = pl[a:b]; tx, ty = t % gx, t // gx
+    ys, xs = torch.meshgrid(torch.arange(16, device=xy.device), torch.arange(16, device=xy.device), indexing="ij")
+    pxs = (tx * 16 + xs).reshape(-1).float(); pys = (ty * 16 + ys).reshape(-1).float()
+    inb = ((pxs < W) & (pys < H))[:, None]
+    dx = xy[ids, 0][None] - pxs[:, None]; dy = xy[ids, 1][None] - pys[:, None]
+    c = co[ids]
+    power = -0.5 * (c[:, 0][None] * dx * dx + c[:, 2][None] * dy * dy) - c[:, 1][None] * dx * dy
+    alpha = torch.clamp_max(c[:, 3][None] * torch.exp(power), 0.99)
+    dead = ~(((power <= 0) & (alpha >= 1 / 255) & inb).any(0))
+    w_ = mxx[ids] - mnx[ids] + 1; h_ = mxy[ids] - mny[ids] + 1
+    corner = ((mnx[ids] == tx) | (mxx[ids] == tx)) & ((mny[ids] == ty) | (mxy[ids] == ty)) & (w_ >= 2) & (h_ >= 2)
+    n_inst += ids.numel(); n_dead += int(dead.sum()); n_corner += int(corner.sum()); n_dead_corner += int((dead & corner).sum())
+print(f"dead instances (no live pixel in the tile): {n_dead / n_inst:.4f} of the binned instances; at a corner of a >= 2x2 rect: "
+      f"{n_dead_corner / n_inst:.4f} ({n_dead_corner / max(1, n_dead):.3f} of the dead; {n_dead_corner / max(1, n_corner):.3f} of the corner instances are dead)")
