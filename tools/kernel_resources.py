@@ -9,7 +9,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fP
        "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-munsafe-fp-atomics",
        "-fno-slp-vectorize",   # as in csrc/Makefile for the kernel files
        "-I" + os.path.dirname(os.path.abspath(f)), "-Rpass-analysis=kernel-resource-usage", "-c", f, "-o", "/dev/null"]
-if "kernels_bwd" in f:
+if "kernels_bwd" in f or "kernels_fwd" in f:
     cmd[1:1] = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
