@@ -1318,6 +1318,47 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 	}
 }
 
+// The same for rows that hold MORE coefficients than the active degree uses (MS > (D+1)^2: the first iterations of a
+// training run, which raise the degree every 1000 steps over [P,16,3] storage): the few active coefficients are read per
+// lane, the gradient rows -- active part, zeros above -- leave through the LDS slab as full streams.  (The per-lane kernel
+// below writes a 192-B row with twelve 16-B stores at a stride of 192 B per lane: 0.127 ms at C3 against 0.090.)
+template <int D, int MS>
+__global__ __launch_bounds__(256) void preprocess_bwd_sh_wide_kernel(
+    int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
+    const GsCam* __restrict__ cam, const GsRec* __restrict__ recs, const float* __restrict__ dL_dcolor,
+    float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh)
+{
+	extern __shared__ __attribute__((aligned(16))) float sh_slab[];
+	constexpr int NC = (D + 1) * (D + 1);
+	constexpr int RF = MS * 3;                     // floats per stored row
+	static_assert(NC < MS && RF % 4 == 0, "wide rows only");
+	const int idx = g_base + blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int g0 = g_base + blockIdx.x * 256 + wv * 64;
+	const int nrows = min(64, P - g0);
+	if (nrows <= 0) return;   // wave-uniform
+	const bool vis = idx < P && radii[idx] > 0;
+	constexpr int RFP = gs_row_stride<RF>();
+	float* slab = sh_slab + wv * 64 * RFP;
+	float* row = slab + lane * RFP;
+#pragma unroll
+	for (int i = 0; i < RF / 4; i++) reinterpret_cast<float4*>(row)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (vis) {
+		float sh[NC * 3], dc[NC], dRGB[3], dmean_sh[3];
+		const float* shp = shs + (size_t)idx * RF;
+#pragma unroll
+		for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
+#pragma unroll
+		for (int i = 0; i < NC * 3; i++) row[i] = dc[i / 3] * dRGB[i % 3];
+#pragma unroll
+		for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] += dmean_sh[i];
+	}
+	__builtin_amdgcn_wave_barrier();
+	gs_wave_lds_to_rows<RF>(dL_dsh + (size_t)g0 * RF, nrows, slab, lane);
+}
+
 template <int D, bool SPLIT, bool COLORS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
     int g_base, int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
@@ -1454,7 +1495,18 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL, COL>), grid, block,                                  \
 	                   sizeof(float) * 256 * gs_row_stride<gs_sh_row_floats(DEG, SPL)>(), s, sh_g0, sh_end, \
 	                   a.means3D, a.radii, a.shs, a.shs_rest, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
-		if (colors && coop) {
+		// stored rows wider than the active degree ([P,16,3] storage while the degree is still being raised): the wide kernel
+		const bool wide = !colors && !split && a.M == 16 && NCd < 16 && (sh_g0 % 256 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
+#define GSR_LAUNCH_SHW(DEG)                                                                                            \
+	hipLaunchKernelGGL((preprocess_bwd_sh_wide_kernel<DEG, 16>), grid, block, sizeof(float) * 256 * gs_row_stride<48>(), s, sh_g0, \
+	                   sh_end, a.means3D, a.radii, a.shs, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh)
+		if (wide) {
+			switch (a.D) {
+				case 0: GSR_LAUNCH_SHW(0); break;
+				case 1: GSR_LAUNCH_SHW(1); break;
+				default: GSR_LAUNCH_SHW(2); break;
+			}
+		} else if (colors && coop) {
 			switch (a.D) {
 				case 0: GSR_LAUNCH_SHC(0, false, true); break;
 				case 1: GSR_LAUNCH_SHC(1, false, true); break;
@@ -1485,6 +1537,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 			constexpr bool SPLIT = false, COLORS = false;
 			GSR_LAUNCH_SH_D()
 		}
+#undef GSR_LAUNCH_SHW
 #undef GSR_LAUNCH_SHC
 #undef GSR_LAUNCH_SH_D
 #undef GSR_LAUNCH_SH

@@ -88,7 +88,8 @@ def test_backward_ring_camera(oracle):
     _check(oracle, sc, cam, 3, scene_kwargs(sc, True, False))
 
 
-def test_backward_zero_rows_for_culled(oracle):
+@pytest.mark.parametrize("D", [3, 1])      # 1: [P,16,3] rows wider than the active degree (preprocess_bwd_sh_wide_kernel)
+def test_backward_zero_rows_for_culled(oracle, D):
     cam = scenes.make_camera(128, 96)
     sc = scenes.make_scene(4000, cam, seed=6)
     m = sc.means3D.clone()
@@ -96,13 +97,16 @@ def test_backward_zero_rows_for_culled(oracle):
     sc = sc._replace(means3D=m.contiguous())
     kw = scene_kwargs(sc, True, False)
     grads = scenes.make_output_grads(cam)
-    hs = hip_forward(sc, cam, 3, kw)
-    hb = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+    hs = hip_forward(sc, cam, D, kw)
+    hb = hip_backward_raw(hs, sc, cam, D, kw, grads)
     culled = to_np(hs["radii"]) == 0
     assert culled.sum() >= 4000 // 3
     for k in GRAD_KEYS:
         assert not to_np(hb[k])[culled].any(), k
-    _check(oracle, sc, cam, 3, kw)
+    if D < 3:                                   # coefficients above the active degree get exact zeros, visible or not
+        assert not to_np(hb["dL_dsh"])[:, (D + 1) ** 2:, :].any()
+        assert to_np(hb["dL_dsh"])[~culled][:, :(D + 1) ** 2, :].any()
+    _check(oracle, sc, cam, D, kw)
 
 
 def test_autograd_function_end_to_end(oracle):
