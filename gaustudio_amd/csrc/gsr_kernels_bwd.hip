@@ -32,6 +32,7 @@ __device__ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
 // Doing these "transposing" steps on pairs of quantities shrinks ten per-lane quantities to three registers whose
 // rows carry different quantities; GSR_DPP_ADD(v, ctrl) is a fused v_add_f32_dpp.
 #define GSR_DPP_ADD(v, ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+#define GSR_DPP_OF(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
 __device__ __forceinline__ float half_swap_sum(float a, float b)
 {
 	// v_permlane32_swap(X, Y): X.rows23 <-> Y.rows01
@@ -546,7 +547,11 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
 		for (int sx = 0; sx < 4; sx++) {
 			const int pl = (qd << 4) + (r2 << 2) + sx;   // lane that owns pixel (sx, r2) of this quarter
-			g_pix[sx] = tmp[2 * pl];
+			const float4 gp = tmp[2 * pl];
+			// XOR Latin square for the transposed fold of phase 2: slot k of row r2 holds component k ^ r2 of (r, g, b, depth)
+			const float c0 = gp.x, c1 = gp.y, c2 = gp.z, c3 = gp.w;
+			g_pix[sx] = make_float4(r2 == 0 ? c0 : r2 == 1 ? c1 : r2 == 2 ? c2 : c3, r2 == 0 ? c1 : r2 == 1 ? c0 : r2 == 2 ? c3 : c2,
+			                        r2 == 0 ? c2 : r2 == 1 ? c3 : r2 == 2 ? c0 : c1, r2 == 0 ? c3 : r2 == 1 ? c2 : r2 == 2 ? c1 : c0);
 			g_op[sx] = tmp[2 * pl + 1].x;
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 		// median-depth gradient (backward.cu:566-569): to the Gaussian the forward recorded as this pixel's median
 		// (list position mpos, 1-based), when it is in this batch -- once per pixel per backward
 		if (mpos != 0u && dLm != 0.f && (uint32_t)top >= mpos && (uint32_t)top - mpos < (uint32_t)cnt)
-			atomicAdd(&plane[((uint32_t)top - mpos) * GSR_PLANE_STRIDE + 9], dLm);
+			atomicAdd(&plane[((uint32_t)top - mpos) * GSR_PLANE_STRIDE + 7], dLm);   // slot 7: the depth sum
 		// lane l: which of the wave's four 4x4 blocks can staged instance l + 64 h touch, and is it still in front of
 		// the quarter's last contributor; the hits of each quarter are appended to its list in list order
 		int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -805,14 +810,19 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 				float a4 = dy * a1;
 				// fold the four rows (lanes r2 = 0..3 of the same quarter and step): quad butterflies
 				GSR_DPP_ADD(a0, 0xB1); GSR_DPP_ADD(a1, 0xB1); GSR_DPP_ADD(a2, 0xB1); GSR_DPP_ADD(a3, 0xB1); GSR_DPP_ADD(a4, 0xB1);
-				GSR_DPP_ADD(a5, 0xB1); GSR_DPP_ADD(a6, 0xB1); GSR_DPP_ADD(a7, 0xB1); GSR_DPP_ADD(a8, 0xB1); GSR_DPP_ADD(a9, 0xB1);
+				GSR_DPP_ADD(a5, 0xB1);
 				GSR_DPP_ADD(a0, 0x4E); GSR_DPP_ADD(a1, 0x4E); GSR_DPP_ADD(a2, 0x4E); GSR_DPP_ADD(a3, 0x4E); GSR_DPP_ADD(a4, 0x4E);
-				GSR_DPP_ADD(a5, 0x4E); GSR_DPP_ADD(a6, 0x4E); GSR_DPP_ADD(a7, 0x4E); GSR_DPP_ADD(a8, 0x4E); GSR_DPP_ADD(a9, 0x4E);
-				// lane r2 takes sums r2, 4 + r2 and (r2 < 2) 8 + r2 to the instance's slot of the wave's plane (pending)
+				GSR_DPP_ADD(a5, 0x4E);
+				// the four colour / depth sums: a6 .. a9 of row r2 hold component k ^ r2 (g_pix above), so two cross-register
+				// quad exchanges and one more leave component r2, summed over the four rows, in row r2 -- 3 DPP adds for four
+				// sums, and no select: it is the sum this row owns (slot 4 + r2)
+				const float k1 = a6 + GSR_DPP_OF(a7, 0xB1), k2 = a8 + GSR_DPP_OF(a9, 0xB1);
+				// lane r2 takes sums r2, 4 + r2 and (r2 < 2) 8 + r2 to the instance's slot of the wave's plane (pending):
+				// slots 0..3 = a0..a3, 4..7 = colour r, g, b and depth, 8 = a4, 9 = a5
 				const bool lo1 = (r2 & 1) != 0;
 				pn0 = r2_hi ? (lo1 ? a3 : a2) : (lo1 ? a1 : a0);
-				pn1 = r2_hi ? (lo1 ? a7 : a6) : (lo1 ? a5 : a4);
-				pn2 = lo1 ? a9 : a8;
+				pn1 = k1 + GSR_DPP_OF(k2, 0x4E);
+				pn2 = lo1 ? a5 : a4;
 				pn_act = act;
 				pn_dst = plane + j * GSR_PLANE_STRIDE + r2;
 			}
@@ -835,14 +845,14 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 				        s_plane[2][fj * GSR_PLANE_STRIDE + k]) + s_plane[3][fj * GSR_PLANE_STRIDE + k];
 			const float4 A = sA[fj], B = sB[fj];
 			const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x, op = B.y;
-			const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[4];
+			const float M10 = v[0], M01 = v[1], M20 = v[2], M11 = v[3], M02 = v[8];
 			const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);   // backward.cu:493-494
 			const uint32_t my_row = s_row[fj];
 			float4* dst = reinterpret_cast<float4*>(rows + (size_t)my_row * GSR_ROW_STRIDE);
 			dst[0] = make_float4(-(op * FMA(cb, M01, ca * M10)) * ddelx_dx, -(op * FMA(cb, M10, cc * M01)) * ddely_dy,
 			                     -0.5f * op * M20, -0.5f * op * M11);
-			dst[1] = make_float4(-0.5f * op * M02, v[5], v[6], v[7]);
-			dst[2] = make_float4(v[8], v[9], 0.f, 0.f);
+			dst[1] = make_float4(-0.5f * op * M02, v[9], v[4], v[5]);   // row layout unchanged: (.., opacity, r, g), (b, depth)
+			dst[2] = make_float4(v[6], v[7], 0.f, 0.f);
 			if (FLAGS) row_flags[my_row] = 1;
 		}
 #pragma unroll
