@@ -268,7 +268,8 @@ def run_extract(a, dev, scenes, _C):
         # :110 compacts `pts[~invalid]` for the CPU library; here a masked pixel's point IS the sensor origin (depth 0) and
         # the integrate kernel skips zero-length rays, so the whole [H*W,3] map goes in: no nonzero / gather pass, no host
         # synchronisation for the count (tests/test_tsdf.py: identical volume)
-        vol.integrate(pts.view(-1, 3), c.campos)                                # :115 vdb_volume.integrate
+        # (the [H,W,3] map goes in as a map: the kernel then works in 32 x 32 pixel patches; `--tsdf-linear` = as a flat list)
+        vol.integrate(pts.view(-1, 3) if a.tsdf_linear else pts, c.campos)     # :115 vdb_volume.integrate
         if timed:
             e[5].record()
             marks.append(e)
@@ -352,6 +353,7 @@ def main():
                     help="N > 1: dense = ONE all-reduce of the flat 236 B/Gaussian gradient buffer; factored = all-gather of the "
                          "per-view colour gradients (12 B/Gaussian/view) + all-reduce of the 44 B/Gaussian geometry block, the SH "
                          "gradient rebuilt locally (gaustudio_amd/parallel.py)")
+    ap.add_argument("--tsdf-linear", action="store_true", help="C3-extract: integrate the point map as a flat list (256 consecutive points per workgroup) instead of 32x32 patches")
     ap.add_argument("--views-per-rank", type=int, default=1, help="cameras rendered (and accumulated) per rank and step")
     ap.add_argument("--rotate-cameras", type=int, default=None,
                     help="K: cycle a ring of K cameras (a different one every step) and apply an Adam update of every parameter "

@@ -128,23 +128,37 @@ __device__ __forceinline__ bool tsdf_commit(unsigned long long* __restrict__ key
 // long space-carving rays) go straight to the volume as before.  Integer adds commute, so the volume is bit-identical
 // to the unaggregated one (tests/test_tsdf.py compares the integer state with the oracle's).
 #define GSR_TSDF_LNS 2048   // slots of the workgroup-local table (24 KiB of LDS)
-__global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __restrict__ points, int N, float ox, float oy, float oz,
+// row_w > 0: `points` is an image-shaped point map [N / row_w][row_w] (what depth2point returns) and a workgroup takes a
+// square PATCH of it instead of consecutive points of one row: neighbouring rows walk through the same voxels as
+// neighbouring columns do, so the workgroup's table holds several times fewer distinct voxels per ray and commits that
+// many fewer device atomics (C3-extract: 0.297 ms as a list, 0.150 in 16 x 16 patches, 0.131 in 32 x 32 with a table
+// of twice the size).  The volume is the same to the bit either way: integer adds commute.
+template <int NT>   // threads per workgroup: 256 (plain list) or 1024 (32 x 32 patches of a map)
+__global__ __launch_bounds__(NT) void tsdf_integrate_kernel(const float* __restrict__ points, int N, int row_w, float ox, float oy, float oz,
                                                              float voxel_size, float sdf_trunc, int space_carving,
                                                              unsigned long long* __restrict__ keys, uint64_t mask,
                                                              unsigned long long* __restrict__ vox, uint32_t* __restrict__ status)
 {
-	__shared__ uint32_t lkeys[GSR_TSDF_LNS];
-	__shared__ unsigned long long lvals[GSR_TSDF_LNS];
+	constexpr int LNS = NT == 1024 ? 2 * GSR_TSDF_LNS : GSR_TSDF_LNS, LNB = NT == 1024 ? 12 : 11;   // table slots, log2
+	__shared__ uint32_t lkeys[LNS];
+	__shared__ unsigned long long lvals[LNS];
 	__shared__ int s_org[3];
 	__shared__ int s_first;
 	const int tid = threadIdx.x;
-	for (int k = tid; k < GSR_TSDF_LNS; k += 256) { lkeys[k] = 0xffffffffu; lvals[k] = 0ull; }
-	if (tid == 0) { s_first = 256; s_org[0] = s_org[1] = s_org[2] = 0; }
+	for (int k = tid; k < LNS; k += NT) { lkeys[k] = 0xffffffffu; lvals[k] = 0ull; }
+	if (tid == 0) { s_first = NT; s_org[0] = s_org[1] = s_org[2] = 0; }
 	const float inv_vs = 1.0f / voxel_size;
 	int64_t cached_slot = -1;
 	int cbx = 0x7fffffff, cby = 0, cbz = 0;
-	const int i = blockIdx.x * 256 + tid;
+	int i = blockIdx.x * NT + tid;
 	bool active = i < N;
+	if (row_w > 0) {
+		constexpr int PS = NT == 1024 ? 32 : 16, PB = NT == 1024 ? 5 : 4;   // patch side
+		const int px_tiles = (row_w + PS - 1) >> PB, rows = N / row_w;
+		const int x = (int)(blockIdx.x % px_tiles) * PS + (tid & (PS - 1)), y = (int)(blockIdx.x / px_tiles) * PS + (tid >> PB);
+		active = x < row_w && y < rows;
+		i = y * row_w + x;
+	}
 	float px = 0.f, py = 0.f, pz = 0.f, depth = 0.f;
 	if (active) {
 		px = points[3 * (size_t)i]; py = points[3 * (size_t)i + 1]; pz = points[3 * (size_t)i + 2];
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
 				bool placed = false;
 				if ((rx | ry | rz) < 1024u) {
 					const uint32_t lkey = rx | (ry << 10) | (rz << 20);
-					uint32_t h = (lkey * 2654435761u) >> (32 - 11);   // 11 bits = log2(GSR_TSDF_LNS)
+					uint32_t h = (lkey * 2654435761u) >> (32 - LNB);
 #pragma unroll 1
 					for (int probe = 0; probe < 8 && !placed; probe++) {
 						const uint32_t old = atomicCAS(&lkeys[h], 0xffffffffu, lkey);
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
 							atomicAdd(&lvals[h], add);
 							placed = true;
 						}
-						h = (h + 1) & (GSR_TSDF_LNS - 1);
+						h = (h + 1) & (LNS - 1);
 					}
 				}
 				if (!placed && !tsdf_commit(keys, mask, vox, status, vx, vy, vz, add, cached_slot, cbx, cby, cbz)) break;
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
 	}
 	// commit the workgroup's aggregated voxels, one device atomic each
 	__syncthreads();
-	for (int k = tid; k < GSR_TSDF_LNS; k += 256) {
+	for (int k = tid; k < LNS; k += NT) {
 		const uint32_t lkey = lkeys[k];
 		if (lkey == 0xffffffffu) continue;
 		const int vx = orgx + (int)(lkey & 1023u), vy = orgy + (int)((lkey >> 10) & 1023u), vz = orgz + (int)(lkey >> 20);
@@ -467,18 +481,36 @@ bool pow2(uint64_t v) { return v && !(v & (v - 1)); }
 
 extern "C" {
 
-int gsr_tsdf_integrate(const float* points, int num_points, const float origin[3], float voxel_size, float sdf_trunc,
-                       int space_carving, uint64_t* block_keys, uint64_t capacity, uint64_t* voxels, uint32_t* status,
-                       void* stream)
+int gsr_tsdf_integrate_map(const float* points, int num_points, int row_width, const float origin[3], float voxel_size,
+                           float sdf_trunc, int space_carving, uint64_t* block_keys, uint64_t capacity, uint64_t* voxels,
+                           uint32_t* status, void* stream)
 {
 	if (num_points <= 0) return GSR_OK;
 	if (!points || !origin || !block_keys || !voxels || !status || !pow2(capacity) || !(voxel_size > 0.f) || !(sdf_trunc > 0.f))
 		return GSR_ERR_ARG;
-	hipLaunchKernelGGL(tsdf_integrate_kernel, dim3((num_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, points,
-	                   num_points, origin[0], origin[1], origin[2], voxel_size, sdf_trunc, space_carving,
+	if (row_width < 0 || (row_width > 0 && num_points % row_width != 0)) return GSR_ERR_ARG;
+	if (row_width > 0) {   // 32 x 32 patches, 1024 threads, 4096-slot table (measured at C3-extract: 0.297 ms as a list, 0.150 in 16 x 16 patches, 0.131 in 32 x 32)
+		const unsigned grid = (unsigned)(((row_width + 31) / 32) * ((num_points / row_width + 31) / 32));
+		hipLaunchKernelGGL(tsdf_integrate_kernel<1024>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, points,
+		                   num_points, row_width, origin[0], origin[1], origin[2], voxel_size, sdf_trunc, space_carving,
+		                   reinterpret_cast<unsigned long long*>(block_keys), capacity - 1,
+		                   reinterpret_cast<unsigned long long*>(voxels), status);
+		return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+	}
+	const unsigned grid = (unsigned)((num_points + 255) / 256);
+	hipLaunchKernelGGL(tsdf_integrate_kernel<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, points,
+	                   num_points, row_width, origin[0], origin[1], origin[2], voxel_size, sdf_trunc, space_carving,
 	                   reinterpret_cast<unsigned long long*>(block_keys), capacity - 1,
 	                   reinterpret_cast<unsigned long long*>(voxels), status);
 	return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
+
+int gsr_tsdf_integrate(const float* points, int num_points, const float origin[3], float voxel_size, float sdf_trunc,
+                       int space_carving, uint64_t* block_keys, uint64_t capacity, uint64_t* voxels, uint32_t* status,
+                       void* stream)
+{
+	return gsr_tsdf_integrate_map(points, num_points, 0, origin, voxel_size, sdf_trunc, space_carving, block_keys, capacity,
+	                              voxels, status, stream);
 }
 
 int gsr_tsdf_export_blocks(const uint64_t* voxels, const uint32_t* block_slots, int num_blocks, float sdf_trunc,

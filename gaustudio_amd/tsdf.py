@@ -39,7 +39,9 @@ class TSDFVolume:
     # ------------------------------------------------------------------ integrate
     def integrate(self, points, extrinsic=None, origin=None):
         """VDBVolume.integrate(points, extrinsic): `extrinsic` is the sensor origin [3] (what the reference passes,
-        extract_mesh.py:115) or a 4x4 camera-to-world pose whose translation is the origin."""
+        extract_mesh.py:115) or a 4x4 camera-to-world pose whose translation is the origin.
+        `points`: [N,3], or an image-shaped point map [H,W,3] (what depth_to_points returns): the kernel then works in
+        32 x 32 pixel patches, whose rays share voxels in both image directions -- same volume to the bit, fewer atomics."""
         o = origin if origin is not None else extrinsic
         if o is None:
             raise ValueError("integrate needs the sensor origin")
@@ -49,20 +51,25 @@ class TSDFVolume:
         if o.shape != (3,):
             raise ValueError("origin must have shape [3] or [4,4]")
         pts = torch.as_tensor(points)
+        row_w = 0
+        if pts.dim() == 3 and pts.shape[2] == 3:
+            row_w = int(pts.shape[1])
+            pts = pts.reshape(-1, 3)
         if pts.dim() != 2 or pts.shape[1] != 3:
-            raise ValueError("points must have shape [N,3]")
+            raise ValueError("points must have shape [N,3] or [H,W,3]")
         pts = pts.to(device=self.device, dtype=torch.float32).contiguous()
         if pts.shape[0] == 0:
             return
         origin_c = (ctypes.c_float * 3)(*[float(v) for v in o])
         L = _C.lib()
         with torch.cuda.device(self.device):
-            rc = L.gsr_tsdf_integrate(_C._ptr(pts), ctypes.c_int(pts.shape[0]), origin_c, ctypes.c_float(self.voxel_size),
-                                      ctypes.c_float(self.sdf_trunc), ctypes.c_int(int(self.space_carving)), _C._ptr(self.keys),
-                                      ctypes.c_uint64(self.capacity), _C._ptr(self.voxels), _C._ptr(self.status),
-                                      _C._stream(self.device))
+            rc = L.gsr_tsdf_integrate_map(_C._ptr(pts), ctypes.c_int(pts.shape[0]), ctypes.c_int(row_w), origin_c,
+                                          ctypes.c_float(self.voxel_size), ctypes.c_float(self.sdf_trunc),
+                                          ctypes.c_int(int(self.space_carving)), _C._ptr(self.keys),
+                                          ctypes.c_uint64(self.capacity), _C._ptr(self.voxels), _C._ptr(self.status),
+                                          _C._stream(self.device))
         if rc < 0:
-            raise RuntimeError(f"gsr_tsdf_integrate failed (rc={rc})")
+            raise RuntimeError(f"gsr_tsdf_integrate_map failed (rc={rc})")
 
     def _check_overflow(self):
         st = int(self.status.item())

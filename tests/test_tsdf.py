@@ -167,6 +167,32 @@ def test_masked_pixels_at_the_sensor_origin_need_no_compaction():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(64, 96), (37, 53), (32, 32), (1, 300), (200, 7), (270, 480)])
+def test_point_map_in_patches_gives_the_same_volume_as_the_flat_list(H, W):
+    """integrate([H,W,3]) -- workgroups take 32 x 32 patches of the map (gsr_tsdf_integrate_map) -- against
+    integrate([H*W,3]): identical volumes (integer adds commute), ragged edges and masked pixels (points at the origin)
+    included."""
+    from gaustudio_amd.tsdf import TSDFVolume
+    rng = np.random.default_rng(H * 1000 + W)
+    o = np.array([0.1, -0.2, 0.3], np.float32)
+    u, v = np.meshgrid(np.linspace(-0.6, 0.6, W, dtype=np.float32), np.linspace(-0.4, 0.4, H, dtype=np.float32))
+    d = np.stack([u, v, np.ones_like(u)], -1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    depth = (2.0 + 0.3 * np.sin(7 * u) * np.cos(5 * v) + rng.uniform(0, 0.01, u.shape)).astype(np.float32)
+    pts = o + d * depth[..., None]
+    pts[rng.random((H, W)) < 0.2] = o                        # masked pixels
+    pmap = torch.from_numpy(pts.astype(np.float32)).cuda()
+    a = TSDFVolume(0.03, 0.12, capacity_blocks=1 << 13)
+    a.integrate(pmap.reshape(-1, 3), o)
+    b = TSDFVolume(0.03, 0.12, capacity_blocks=1 << 13)
+    b.integrate(pmap, o)
+    xa, xb = a.export_voxels(), b.export_voxels()
+    assert xa[0].shape[0] > 0
+    for x, y in zip(xa, xb):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
 def test_integrate_is_order_independent_and_deterministic():
     scans = _sphere_scan(n=20000, seed=3)
     a = _gpu_volume(0.02, 0.08, scans, capacity=1 << 14)
