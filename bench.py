@@ -246,7 +246,7 @@ def run_extract(a, dev, scenes, _C):
     # scene's would -- voxels of 4 cm (scene depth 2 .. 20) and 2^22 hash slots (16 GiB of the 288) hold it
     vol = TSDFVolume(voxel_size=0.04, sdf_trunc=0.16, space_carving=False, device=dev, capacity_blocks=1 << 22)
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    stage_names = ("render", "mask", "points", "normals", "integrate")
+    stage_names = ("render", "mask", "points", "normals", "integrate")   # fused epilogue: mask = points = 0, everything under "normals"
     acc = {k: 0.0 for k in stage_names}
     marks = []
 
@@ -258,13 +258,22 @@ def run_extract(a, dev, scenes, _C):
             _, _, _, median, opacity = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=m2, opacities=params["opacities"],
                                                                shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
         if timed: e[1].record()
-        invalid = opacity[0] < 0.5                                               # extract_mesh.py:104
-        depth = median[0].masked_fill(invalid, 0.0)                              # :107
-        if timed: e[2].record()
-        pts = pp.depth_to_points(depth, Kc, E, "world")                         # :109 Camera.depth2point(..., 'world')
-        if timed: e[3].record()
-        nrm = pp.depth_to_normals(depth, Kc, E, coordinate="world")             # Camera.depth2normal (gs-extract-pcd / normal maps)
-        if timed: e[4].record()
+        if a.epilogue_separate:
+            invalid = opacity[0] < 0.5                                           # extract_mesh.py:104
+            depth = median[0].masked_fill(invalid, 0.0)                          # :107
+            if timed: e[2].record()
+            pts = pp.depth_to_points(depth, Kc, E, "world")                     # :109 Camera.depth2point(..., 'world')
+            if timed: e[3].record()
+            nrm = pp.depth_to_normals(depth, Kc, E, coordinate="world")         # Camera.depth2normal (gs-extract-pcd / normal maps)
+            if timed: e[4].record()
+        else:
+            # the three steps in one pass over the frame (gsr_depth_epilogue: mask applied while the tile is read, points and
+            # normals written together; value for value the same -- tests/test_postprocess.py); the stage split reports it all
+            # under "points + normals"
+            if timed: e[2] = e[3] = e[1]                      # (no extra event records: each costs ~5 us of stream time)
+            pts, nrm = pp.depth_epilogue(median[0], Kc, E, opacity=opacity[0], min_opacity=0.5, coordinate="world")
+            invalid = None
+            if timed: e[4].record()
         # :110 compacts `pts[~invalid]` for the CPU library; here a masked pixel's point IS the sensor origin (depth 0) and
         # the integrate kernel skips zero-length rays, so the whole [H*W,3] map goes in: no nonzero / gather pass, no host
         # synchronisation for the count (tests/test_tsdf.py: identical volume)
@@ -285,6 +294,11 @@ def run_extract(a, dev, scenes, _C):
         _, inv = step(i, timed=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if inv is None:                                          # fused epilogue: recompute the mask of the last frame outside the clock
+        with torch.no_grad():
+            rs = rss[(a.steps - 1) % K]
+            inv = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=m2, opacities=params["opacities"], shs=params["shs"],
+                                         scales=params["scales"], rotations=params["rotations"])[4][0] < 0.5
     n_valid = int((~inv).sum().item()) * a.steps             # (after the clock: the first reduction loads a torch code object)
     fwd_ms = _C.last_forward_ms()
     _C.set_profiling(False)
@@ -295,8 +309,11 @@ def run_extract(a, dev, scenes, _C):
     status = int(vol.status.item())
     blocks = int((vol.keys != -1).sum().item())
     HW = H * W
-    epi = {"points": {"ms": stage_ms["points"], "algorithmic_bytes": HW * 16},
-           "normals": {"ms": stage_ms["normals"], "algorithmic_bytes": HW * 16}}
+    if a.epilogue_separate:
+        epi = {"points": {"ms": stage_ms["points"], "algorithmic_bytes": HW * 16},
+               "normals": {"ms": stage_ms["normals"], "algorithmic_bytes": HW * 16}}
+    else:   # one pass: depth + opacity read, points + normals written
+        epi = {"mask+points+normals (fused)": {"ms": stage_ms["normals"], "algorithmic_bytes": HW * 32}}
     for v in epi.values():
         v["GB/s"] = round(v["algorithmic_bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
         v["frac_hbm"] = round(v["GB/s"] / 8000.0, 4)
@@ -353,6 +370,7 @@ def main():
                     help="N > 1: dense = ONE all-reduce of the flat 236 B/Gaussian gradient buffer; factored = all-gather of the "
                          "per-view colour gradients (12 B/Gaussian/view) + all-reduce of the 44 B/Gaussian geometry block, the SH "
                          "gradient rebuilt locally (gaustudio_amd/parallel.py)")
+    ap.add_argument("--epilogue-separate", action="store_true", help="C3-extract: mask, depth_to_points and depth_to_normals as separate steps (torch ops + two kernels) instead of the fused gsr_depth_epilogue")
     ap.add_argument("--tsdf-linear", action="store_true", help="C3-extract: integrate the point map as a flat list (256 consecutive points per workgroup) instead of 32x32 patches")
     ap.add_argument("--views-per-rank", type=int, default=1, help="cameras rendered (and accumulated) per rank and step")
     ap.add_argument("--rotate-cameras", type=int, default=None,

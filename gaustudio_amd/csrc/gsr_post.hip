@@ -72,9 +72,15 @@ __device__ __forceinline__ void normal_from_taps(float zc, float3 pt, float3 pb,
 #define GSR_POST_KH 2
 #define GSR_POST_BW 64
 #define GSR_POST_BH 8
-template <int k>
+// FUSED (gsr_depth_epilogue): the whole step between the render and the fusion in ONE pass over the frame -- the opacity
+// mask of extract_mesh.py:104-107 (depth <- 0 where opacity < min_opacity) applied while the tile is read, the tile's own
+// points written out as Camera.depth2point(..., coordinate) would (the masked pixels land on the camera centre), and the
+// normals: 8 B read and 24 B written per pixel instead of three kernels and two [H,W] intermediates.
+template <int k, bool FUSED>
 __global__ __launch_bounds__(256) void depth_to_normals_tile_kernel(const float* __restrict__ depth, int W, int H, PostCam c,
-                                                                    float d_min, float d_max, float* __restrict__ normals)
+                                                                    float d_min, float d_max, float* __restrict__ normals,
+                                                                    const float* __restrict__ opacity, float min_opacity,
+                                                                    float* __restrict__ points)
 {
 	constexpr int tw = GSR_POST_BW + 2 * k, th = GSR_POST_BH + 2 * k;
 	__shared__ float s_x[th * tw], s_y[th * tw], s_z[th * tw];
@@ -82,7 +88,11 @@ __global__ __launch_bounds__(256) void depth_to_normals_tile_kernel(const float*
 	for (int t = threadIdx.x; t < tw * th; t += 256) {
 		const int lx = t % tw, ly = t / tw, gx = ox + lx, gy = oy + ly;   // tw is a compile-time constant
 		float3 p = {0.f, 0.f, 0.f};   // F.pad(..., value=0)
-		if (gx >= 0 && gx < W && gy >= 0 && gy < H) p = unproject(gx, gy, depth[(size_t)gy * W + gx], W, H, c);
+		if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+			float z = depth[(size_t)gy * W + gx];
+			if (FUSED && opacity != nullptr && opacity[(size_t)gy * W + gx] < min_opacity) z = 0.f;
+			p = unproject(gx, gy, z, W, H, c);
+		}
 		s_x[t] = p.x; s_y[t] = p.y; s_z[t] = p.z;
 	}
 	__syncthreads();
@@ -92,8 +102,20 @@ __global__ __launch_bounds__(256) void depth_to_normals_tile_kernel(const float*
 		const int ly = (threadIdx.x >> 6) + 4 * r + k, y = oy + ly;
 		if (x >= W || y >= H) continue;
 		auto at = [&](int ax, int ay) { const int t = ay * tw + ax; return float3{s_x[t], s_y[t], s_z[t]}; };
-		normal_from_taps(s_z[ly * tw + lx], at(lx, ly - k), at(lx, ly + k), at(lx - k, ly), at(lx + k, ly), d_min, d_max, c,
-		                 normals + 3 * ((size_t)y * W + x));
+		if (normals != nullptr)
+			normal_from_taps(s_z[ly * tw + lx], at(lx, ly - k), at(lx, ly + k), at(lx - k, ly), at(lx + k, ly), d_min, d_max, c,
+			                 normals + 3 * ((size_t)y * W + x));
+		if (FUSED && points != nullptr) {
+			float3 p = at(lx, ly);
+			if (c.to_world) {   // depth_to_points_kernel's arithmetic
+				const float3 q = p;
+				p.x = FMA(c.c2w[2], q.z, FMA(c.c2w[1], q.y, c.c2w[0] * q.x)) + c.c2w[3];
+				p.y = FMA(c.c2w[6], q.z, FMA(c.c2w[5], q.y, c.c2w[4] * q.x)) + c.c2w[7];
+				p.z = FMA(c.c2w[10], q.z, FMA(c.c2w[9], q.y, c.c2w[8] * q.x)) + c.c2w[11];
+			}
+			float* o = points + 3 * ((size_t)y * W + x);
+			o[0] = p.x; o[1] = p.y; o[2] = p.z;
+		}
 	}
 }
 
@@ -274,18 +296,43 @@ int gsr_depth_to_normals(const float* depth, int width, int height, const float*
 	if (rc != GSR_OK) return rc;
 	const int kd = (k - 1) / 2;   // tap distance (depth2normal: k = (k - 1) // 2)
 	const dim3 tgrid((width + GSR_POST_BW - 1) / GSR_POST_BW, (height + GSR_POST_BH - 1) / GSR_POST_BH);
+	const float* no_op = nullptr;
+	float* no_pts = nullptr;
 	if (kd == 0)
-		hipLaunchKernelGGL(depth_to_normals_tile_kernel<0>, tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
-		                   d_min, d_max, normals);
+		hipLaunchKernelGGL((depth_to_normals_tile_kernel<0, false>), tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals, no_op, 0.f, no_pts);
 	else if (kd == 1)
-		hipLaunchKernelGGL(depth_to_normals_tile_kernel<1>, tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
-		                   d_min, d_max, normals);
+		hipLaunchKernelGGL((depth_to_normals_tile_kernel<1, false>), tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals, no_op, 0.f, no_pts);
 	else if (kd == 2)
-		hipLaunchKernelGGL(depth_to_normals_tile_kernel<2>, tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
-		                   d_min, d_max, normals);
+		hipLaunchKernelGGL((depth_to_normals_tile_kernel<2, false>), tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals, no_op, 0.f, no_pts);
 	else
 		hipLaunchKernelGGL(depth_to_normals_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, (hipStream_t)stream,
 	                   depth, width, height, c, kd, d_min, d_max, normals);
+	return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
+
+int gsr_depth_epilogue(const float* depth, const float* opacity, float min_opacity, int width, int height,
+                       const float* intrinsics, int k, float d_min, float d_max, const float* world_to_camera, float* points,
+                       float* normals, void* stream)
+{
+	if (!depth || (!points && !normals) || width <= 0 || height <= 0 || k < 1) return GSR_ERR_ARG;
+	const int kd = (k - 1) / 2;
+	if (kd > GSR_POST_KH) return GSR_ERR_ARG;   // larger tap distances: the separate entry points
+	PostCam c;
+	const int rc = setup(intrinsics, world_to_camera, c);
+	if (rc != GSR_OK) return rc;
+	const dim3 tgrid((width + GSR_POST_BW - 1) / GSR_POST_BW, (height + GSR_POST_BH - 1) / GSR_POST_BH);
+	if (kd == 0)
+		hipLaunchKernelGGL((depth_to_normals_tile_kernel<0, true>), tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals, opacity, min_opacity, points);
+	else if (kd == 1)
+		hipLaunchKernelGGL((depth_to_normals_tile_kernel<1, true>), tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals, opacity, min_opacity, points);
+	else
+		hipLaunchKernelGGL((depth_to_normals_tile_kernel<2, true>), tgrid, dim3(256), 0, (hipStream_t)stream, depth, width, height, c,
+		                   d_min, d_max, normals, opacity, min_opacity, points);
 	return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }
 

@@ -68,6 +68,34 @@ def depth_to_normals(depth, intrinsics, extrinsics=None, k=3, d_min=1e-3, d_max=
     return out
 
 
+def depth_epilogue(depth, intrinsics, extrinsics=None, opacity=None, min_opacity=0.5, k=3, d_min=1e-3, d_max=100000.0,
+                   coordinate="world", want_points=True, want_normals=True):
+    """The step between the render and the fusion of gs-extract-mesh in one kernel (extract_mesh.py:101-110 +
+    depth2normal): `depth[opacity < min_opacity] = 0`, `depth2point(depth, coordinate)` and `depth2normal(depth, k, d_min,
+    d_max, coordinate)` -- returns (points [H,W,3] or None, normals [H,W,3] or None), value for value what the three
+    separate steps give."""
+    if coordinate not in ("camera", "world"):
+        raise ValueError("Invalid coordinate system.")
+    depth = _check(depth)
+    H, W = depth.shape
+    if opacity is not None:
+        opacity = _check(opacity.reshape(H, W))
+    K = _host16(intrinsics, 9)
+    E = _host16(extrinsics, 16) if coordinate == "world" else None
+    if coordinate == "world" and E is None:
+        raise ValueError("extrinsics are required for world coordinates")
+    pts = torch.empty((H, W, 3), dtype=torch.float32, device=depth.device) if want_points else None
+    nrm = torch.empty((H, W, 3), dtype=torch.float32, device=depth.device) if want_normals else None
+    L = _C.lib()
+    with torch.cuda.device(depth.device):
+        rc = L.gsr_depth_epilogue(_C._ptr(depth), _C._ptr(opacity), ctypes.c_float(float(min_opacity)), ctypes.c_int(W),
+                                  ctypes.c_int(H), K, ctypes.c_int(int(k)), ctypes.c_float(d_min), ctypes.c_float(d_max), E,
+                                  _C._ptr(pts), _C._ptr(nrm), _C._stream(depth.device))
+    if rc < 0:
+        raise RuntimeError(f"gsr_depth_epilogue failed (rc={rc}): k > 5, or singular intrinsics / extrinsics?")
+    return pts, nrm
+
+
 def masked_bilateral_filter(depth_map, mask, d=3, sigma_color=75, sigma_space=75):
     """gaustudio/scripts/extract_pcd.py:185-238 masked_bilateral_filter, on the GPU (the reference goes through numpy and
     cv2 on the CPU): returns (filtered_depth, new_mask), new_mask in `mask`'s dtype.  cv2 is restated from its published

@@ -318,6 +318,13 @@ int gsr_depth_to_points(const float* depth, int width, int height, const float* 
  * outside the image. */
 int gsr_depth_to_normals(const float* depth, int width, int height, const float* intrinsics, int k, float d_min,
                          float d_max, const float* world_to_camera, float* normals, void* stream);
+/* Both of the above in one pass, with the opacity mask of gs-extract-mesh in front (extract_mesh.py:104-110: the depth of a
+ * pixel with opacity < min_opacity counts as 0, so its point is the camera centre and its normal invalid): depth[H,W],
+ * opacity[H,W] or NULL (no mask), points[H,W,3] and normals[H,W,3] in the coordinates world_to_camera selects (NULL =
+ * camera), either output may be NULL.  Tap distance (k - 1) / 2 <= 2.  Same arithmetic per value as the separate calls. */
+int gsr_depth_epilogue(const float* depth, const float* opacity, float min_opacity, int width, int height,
+                       const float* intrinsics, int k, float d_min, float d_max, const float* world_to_camera, float* points,
+                       float* normals, void* stream);
 
 /* Replaces masked_bilateral_filter (gaustudio/scripts/extract_pcd.py:185-238: numpy + cv2.dilate + cv2.bilateralFilter
  * on the CPU, between the render and depth2point in gs-extract-pcd).  mask[H,W] u8 (non-zero = valid) -> new_mask[H,W]

@@ -124,6 +124,37 @@ def test_epilogue_at_block_boundaries_against_numpy_restatement(W, H):
             assert np.abs(n - ref)[~ia].max(initial=0.0) < 2e-4, (k, w2c is not None)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(2, 3), (64, 8), (65, 9), (130, 17), (480, 270)])
+def test_fused_epilogue_equals_the_three_separate_steps(W, H):
+    """gsr_depth_epilogue (opacity mask + depth2point + depth2normal in one pass) against the separate steps
+    -- torch mask, gsr_depth_to_points, gsr_depth_to_normals -- bit for bit, in camera and world coordinates, with and
+    without an opacity map, one output or both, for the three tap distances of the tiled path."""
+    from gaustudio_amd import postprocess as pp
+    rng = np.random.default_rng(W * 7 + H)
+    depth = torch.from_numpy((2.0 + rng.random((H, W))).astype(np.float32)).cuda()
+    opac = torch.from_numpy(rng.random((H, W)).astype(np.float32)).cuda()
+    K = torch.tensor([[W * 0.9, 0, W / 2], [0, W * 0.9, H / 2], [0, 0, 1]], dtype=torch.float32)
+    a = 0.4
+    E = torch.eye(4)
+    E[:3, :3] = torch.tensor([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=torch.float32)
+    E[:3, 3] = torch.tensor([0.3, -0.2, 1.0])
+    for coord in ("camera", "world"):
+        for use_op in (True, False):
+            masked = depth.masked_fill(opac < 0.5, 0.0) if use_op else depth
+            for k in (1, 3, 5):
+                p_ref = pp.depth_to_points(masked, K, E, coord)
+                n_ref = pp.depth_to_normals(masked, K, E, k=k, coordinate=coord)
+                p, n = pp.depth_epilogue(depth, K, E, opacity=opac if use_op else None, min_opacity=0.5, k=k, coordinate=coord)
+                assert torch.equal(p, p_ref) and torch.equal(n, n_ref), (coord, use_op, k)
+    p, n = pp.depth_epilogue(depth, K, E, opacity=opac, want_normals=False)
+    assert n is None and torch.equal(p, pp.depth_to_points(depth.masked_fill(opac < 0.5, 0.0), K, E, "world"))
+    p, n = pp.depth_epilogue(depth, K, E, opacity=opac, want_points=False)
+    assert p is None and torch.equal(n, pp.depth_to_normals(depth.masked_fill(opac < 0.5, 0.0), K, E, coordinate="world"))
+    with pytest.raises(RuntimeError):
+        pp.depth_epilogue(depth, K, E, k=7)                     # tap distance 3: the separate entry points
+
+
 def test_masked_bilateral_restatement_on_a_hand_checked_case():
     """extract_pcd.py:185-238 restated (cv2 absent: its dilate / bilateralFilter follow OpenCV's published float32
     algorithm).  With sigma = 75 on a [0, 1]-normalised image the weights are 1 to within 1e-4, so the filter is the
