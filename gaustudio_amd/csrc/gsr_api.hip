@@ -720,13 +720,20 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	// long lists (average > GSR_FLAG_AVG entries per tile): one validity byte per instance row, set by composite_bwd for the
 	// rows it writes; short lists: no flags, composite_bwd zeroes the rows of the entries its walk does not reach
 	const bool flagged = (size_t)(R > 0 ? R : 0) > (size_t)il.T * GSR_FLAG_AVG;
-	{
-		// the regime is recorded next to the staged background for gsr_inspect_backward_sums (word 8 of the bg block),
-		// by the launch that stages the background
-		const float* const src[4] = {background, nullptr, nullptr, nullptr};
-		float* const dst[4] = {bg_dev, nullptr, nullptr, nullptr};
-		const int n[4] = {3, 0, 0, 0};
-		HIP_TRY(stage_small(src, dst, n, s, reinterpret_cast<uint32_t*>(bg_dev + 8), flagged ? 1u : 0u));
+	// the background and the regime word (word 8 of the scratch's bg block, for gsr_inspect_backward_sums) ride in
+	// composite_bwd's argument block (GsBg): a device-resident background is read by the kernel where it lies, host
+	// values are copied into the arguments -- no staging launch in front of the kernel.  Without instances the kernel
+	// does not run: the word is then stored by the small staging launch.
+	GsBg bgv;
+	bgv.dptr = (background != nullptr && is_device_ptr(background)) ? background : nullptr;
+	for (int i = 0; i < 3; i++) bgv.host[i] = (background != nullptr && bgv.dptr == nullptr) ? background[i] : 0.f;
+	bgv.flag_dst = reinterpret_cast<uint32_t*>(bg_dev + 8);
+	bgv.flag = flagged ? 1u : 0u;
+	if (R <= 0) {
+		const float* const src[4] = {nullptr, nullptr, nullptr, nullptr};
+		float* const dst[4] = {nullptr, nullptr, nullptr, nullptr};
+		const int n[4] = {0, 0, 0, 0};
+		HIP_TRY(stage_small(src, dst, n, s, bgv.flag_dst, bgv.flag));
 	}
 	if (flagged)
 		HIP_TRY(hipMemsetAsync(row_flags, 0, (size_t)R, s));
@@ -749,7 +756,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 			if (variant & 2) return fail(GSR_ERR_ARG, "gsr_backward: fast_exp needs the per-quarter kernel (bwd_variant bit 1 clear)", __FILE__, __LINE__);
 			variant |= 8;   // bit 3: the forward used the hardware exp -- the backward takes the same decisions with it
 		}
-		launch_composite_bwd(il, width, height, bg_dev, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix,
+		launch_composite_bwd(il, width, height, bgv, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix,
 		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags,
 		                     reinterpret_cast<const GsCtl*>(image_buffer + il.ctl), variant, s);
 		STAGE_CHECK("composite_bwd", debug, s);

@@ -155,8 +155,17 @@ struct BwdLayout {
 		total = rows + align_up(sizeof(float) * GSR_ROW_STRIDE * (R > 0 ? R : 1));
 	}
 };
+// The backward's own `background` (backward.cu:584-587 reads it; the forward never does) travels as a kernel
+// argument: a device pointer is read by the kernel, host values ride in the argument block -- no staging launch.  The
+// same argument carries the regime word gsr_inspect_backward_sums reads (stored by the kernel's first thread).
+struct GsBg {
+	const float* dptr;     // device-resident background, or nullptr
+	float host[3];         // the values when dptr == nullptr (absent background: zeros)
+	uint32_t* flag_dst;    // word 8 of the scratch's background block
+	uint32_t flag;
+};
 // variant: 0 = default; other values select A/B variants of the kernel (gsr_set_option("bwd_variant", v))
-void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
+void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const uint32_t* med_pos, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,

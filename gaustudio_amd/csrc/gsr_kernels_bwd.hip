@@ -189,7 +189,7 @@ __device__ __forceinline__ void gs_bwd_phase2(const int n, const float2* __restr
 // TSEL: keep a select on T for devices where v_rcp_f32(1.0) != 1.0 (gsr_selftest).
 template <bool FLAGS, bool TSEL>
 __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
-    int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
+    int T, int chunk, int gx, int W, int H, const GsBg bgv, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ med_pos,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	__shared__ float2 s_slab[4][GSR_BWD_UNITS * GSR_SLAB_STRIDE];
 	__shared__ float4 s_tab[4][8 * GSR_TAB_ROW];            // per-pixel constants of phase 2
 	__shared__ int s_max[4];
+	if (blockIdx.x == 0 && threadIdx.x == 0 && bgv.flag_dst != nullptr) *bgv.flag_dst = bgv.flag;   // regime word (GsBg)
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		t[1] = make_float4(dLo, dLm, __uint_as_float(mpos), 0.f);
 	}
 	// bg . dL_dpixel (backward.cu:584-586), loop invariant
-	const float bg_dot = FMA(bg[2], dLp2, FMA(bg[1], dLp1, FMA(bg[0], dLp0, 0.f)));
+	const float bg0 = bgv.dptr ? bgv.dptr[0] : bgv.host[0], bg1 = bgv.dptr ? bgv.dptr[1] : bgv.host[1], bg2 = bgv.dptr ? bgv.dptr[2] : bgv.host[2];
+	const float bg_dot = FMA(bg2, dLp2, FMA(bg1, dLp1, FMA(bg0, dLp0, 0.f)));
 	// wave-uniform: with a black background (the common case) the term is skipped by a scalar branch
 	const bool any_bg = __ballot(bg_dot != 0.f) != 0ull;
 	float T_ = T_final;
@@ -481,7 +483,7 @@ __device__ unsigned long long g_bwd_phase_ticks[GSR_TM_SLOTS * 12];
 #endif
 template <bool FLAGS, bool TSEL, bool FX>
 __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_quarter_kernel(
-    int T, int chunk, int gx, int W, int H, const float* __restrict__ bg, const uint2* __restrict__ ranges,
+    int T, int chunk, int gx, int W, int H, const GsBg bgv, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ med_pos,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth, const float* __restrict__ dL_dpix_median,
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	__shared__ __attribute__((aligned(16))) float2 s_slab[4][4 * GSR_BWQ_QSTRIDE];
 	__shared__ __attribute__((aligned(16))) uint8_t s_list[4][4][GSR_BWQ_LIST];
 	__shared__ int s_max[4];
+	if (blockIdx.x == 0 && threadIdx.x == 0 && bgv.flag_dst != nullptr) *bgv.flag_dst = bgv.flag;   // regime word (GsBg)
 	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
 	const int tid = threadIdx.x;
@@ -558,7 +561,8 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	}
 	const float y2 = fby + (float)(((qd >> 1) << 2) + r2), x2 = fbx + (float)((qd & 1) << 2);   // first pixel of that row
 	// bg . dL_dpixel (backward.cu:584-586), loop invariant
-	const float bg_dot = FMA(bg[2], dLp2, FMA(bg[1], dLp1, FMA(bg[0], dLp0, 0.f)));
+	const float bg0 = bgv.dptr ? bgv.dptr[0] : bgv.host[0], bg1 = bgv.dptr ? bgv.dptr[1] : bgv.host[1], bg2 = bgv.dptr ? bgv.dptr[2] : bgv.host[2];
+	const float bg_dot = FMA(bg2, dLp2, FMA(bg1, dLp1, FMA(bg0, dLp0, 0.f)));
 	const bool any_bg = __ballot(bg_dot != 0.f) != 0ull;
 	float T_ = T_final;
 	float S = 0.f;   // <accum_rec, dL_dpixel>, see composite_bwd_kernel
@@ -892,7 +896,7 @@ void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s)
 	hipLaunchKernelGGL(bwd_selftest_kernel, dim3(1), dim3(1), 0, s, in, out);
 }
 
-void launch_composite_bwd(const ImgLayout& il, int W, int H, const float* bg, const uint2* ranges,
+void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,
                           const uint32_t* n_contrib, const uint32_t* med_pos, const float* dL_dpix, const float* dL_dpix_depth,
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
