@@ -397,8 +397,16 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    if world > 1:
+    # GSR_BENCH_FORCE_PG=1: run the N > 1 code path (process group, armed buckets, chunk hooks, all-gather / all-reduce,
+    # comm block) even at world_size 1 -- every collective call of the multi-GPU step then meets RCCL on a single GPU
+    # (tests/test_distributed.py::test_nccl_world1_*); a sum over one rank is the identity, so the numbers are the N = 1 ones
+    force_pg = os.environ.get("GSR_BENCH_FORCE_PG") == "1"
+    multi = world > 1 or force_pg
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -411,6 +419,7 @@ def main():
     # one-time process initialisation (not a benchmark step): load the gfx950 code objects with a 512-Gaussian
     # call and reserve an allocator pool, as a long-running trainer / server would at start-up
     runtime.warm_start(dev)
+    parallel.FORCE_COLLECTIVES = force_pg
     if a.workload == "C3-extract":
         if world != 1:
             raise SystemExit("C3-extract is a single-GPU workload")
@@ -437,7 +446,7 @@ def main():
     rs_list = [settings(c) for c in cams]
     rs = rs_list[0]
     rasterizers = [GaussianRasterizer(r) for r in rs_list]
-    factored = world > 1 and a.exchange == "factored" and not a.fwd_only   # (step() reads it at call time)
+    factored = multi and a.exchange == "factored" and not a.fwd_only   # (step() reads it at call time)
     bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()), roles=params)
     fx = None
     if factored:
@@ -466,26 +475,26 @@ def main():
             last = v == len(rasts) - 1
             if factored:
                 fx.arm(v)                                   # colour gradients of view v go to their all-gather slot
-            elif world > 1 and len(rasts) == 1:
+            elif multi and len(rasts) == 1:
                 # gradients are born in the flat all-reduce buffer; the SH ranges are reduced while the backward runs
                 bucket.arm(a.overlap_chunks)
             color, radii, depth, median, opac = render(v, r)
             torch.autograd.backward([color, depth, median, opac], grads)
             if last:
                 state["out"] = (color, radii, depth, median, opac)
-        if world > 1 and timed:
+        if multi and timed:
             e0 = torch.cuda.Event(enable_timing=True); e0.record()
         if factored:
             fx.exchange(campos_all)
         else:
             parallel.allreduce_gaussian_grads(bucket)      # the tail of the one logical reduction (no-op at N=1)
-        if world > 1 and timed:
+        if multi and timed:
             e1 = torch.cuda.Event(enable_timing=True); e1.record()
             comm_ev.append((e0, e1))
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -502,7 +511,7 @@ def main():
         f, b = _C.last_forward_ms(), _C.last_backward_ms()
         _C.set_profiling(False)
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()), f, b
 
@@ -559,7 +568,7 @@ def main():
             opt_ms = None
 
     extras = {}
-    if world == 1 and not a.no_extras and not rotating_headline and a.workload in ("C3", "C3D0") and not a.fast_exp:
+    if not multi and not a.no_extras and not rotating_headline and a.workload in ("C3", "C3D0") and not a.fast_exp:
         # beside the static-camera headline: (1) the rotating / optimizer-contended step, (2) the opt-in fast_exp mode
         K = 8
         rot_fn, opt_ev = make_rotating(K)
@@ -626,7 +635,7 @@ def main():
                             "access-pattern calibration of profiles/r02_fetch_write_calibration.txt (`traffic_upper` = 2*FETCH + "
                             "WRITE); the kernel is VALU-issue bound (256 pixel evaluations per staged 48-B record): `valu.issue_frac` "
                             "is the fraction of the SIMDs' issue cycles its VALU instructions fill, see DESIGN.md s4"}
-        if world > 1:
+        if multi:
             par = (f"{V} camera(s) per GPU x{world}, one logical gradient exchange per step: " +
                    (f"all-gather of {fx.color_bytes_per_rank} B/rank of colour gradients + all-reduce of {fx.geometry_bytes} B of "
                     f"geometry gradients (SH gradient rebuilt locally)" if factored else
@@ -654,7 +663,7 @@ def main():
         line.update(extras)
         if bwd_ms:
             line["valu_composite_bwd"] = valu_issue(counters, "composite_bwd", bwd_ms.get("composite_bwd"))
-        if world > 1 and comm_ev:
+        if multi and comm_ev:
             torch.cuda.synchronize()
             exposed = sum(e0.elapsed_time(e1) for e0, e1 in comm_ev) / len(comm_ev)
             comp_total = sum(v for k, v in (fwd_ms or {}).items() if k != "calls") + sum(v for k, v in (bwd_ms or {}).items() if k != "calls")
@@ -679,7 +688,7 @@ def main():
         if world == 1 and not a.no_ref_ab and not a.fwd_only:
             line["reference_hipified_ms"] = reference_ab(sc, cam, D, grads_cpu, dev)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -21,6 +21,7 @@ chunks partition it, every element is reduced exactly once, and the result is bi
 
 The same code runs on CPU tensors with the "gloo" backend (tests/test_distributed.py, world_size 2).
 """
+import os
 from typing import Iterable, List, Optional, Sequence
 
 import torch
@@ -31,8 +32,13 @@ ARENA_ROLES = ("means3D", "shs", "opacities", "scales", "rotations")
 _KEY_ROLES = ("means3D", "shs", "scales", "rotations")      # the operator inputs the backward sees (arena key)
 
 
+# True: take the collective code paths even in a process group of ONE rank (a sum / gather over one rank is the identity).
+# For exercising every RCCL call of the N > 1 step on a single GPU (tests, bench.py with GSR_BENCH_FORCE_PG=1).
+FORCE_COLLECTIVES = os.environ.get("GSR_FORCE_COLLECTIVES") == "1"
+
+
 def _multi(group=None):
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
 
 
 class FlatGradBucket:
@@ -300,7 +306,7 @@ class FactoredGradExchange:
                 v.zero_()
             elif not (p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape and p.grad.is_contiguous()):
                 v.copy_(p.grad)
-        multi = W > 1
+        multi = _multi(self.group)
         mine = self.colors[self.rank * V:(self.rank + 1) * V]
         rows = None
         if multi and self.compact:

@@ -14,8 +14,12 @@ if [ ! -d "$RAST/cuda_rasterizer" ]; then
 	echo "[build_ref] reference checkout not found at $RAST -- skipping (prebuilt $OUT/libgsref.so is used if present)"
 	exit 0
 fi
-if [ -f "$OUT/libgsref.so" ] && [ "$OUT/libgsref.so" -nt "$HERE/ref_shim.cpp" ] && [ "$OUT/libgsref.so" -nt "$HERE/build_ref.sh" ]; then
-	echo "[build_ref] $OUT/libgsref.so is up to date"
+uptodate=1
+for lib in libgsref.so libgsref_nocontract.so; do
+	if ! { [ -f "$OUT/$lib" ] && [ "$OUT/$lib" -nt "$HERE/ref_shim.cpp" ] && [ "$OUT/$lib" -nt "$HERE/build_ref.sh" ]; }; then uptodate=0; fi
+done
+if [ "$uptodate" = 1 ]; then
+	echo "[build_ref] $OUT/libgsref.so and libgsref_nocontract.so are up to date"
 	exit 0
 fi
 TMP="$(mktemp -d /tmp/gsref.XXXXXX)"
@@ -30,8 +34,19 @@ sed -i -e 's/^#include ""$//' \
        -e 's/__trap();/abort();/' \
        -e 's/<< </<<</g' -e 's/>> >/>>>/g' "$TMP"/*.cu "$TMP"/*.h
 mkdir -p "$OUT"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w \
-	-I "$TMP" -I "$RAST/third_party/glm" \
-	"$TMP/forward.cu" "$TMP/backward.cu" "$TMP/rasterizer_impl.cu" "$HERE/ref_shim.cpp" \
-	-o "$OUT/libgsref.so"
-echo "[build_ref] built $OUT/libgsref.so from $RAST"
+# Two builds of the SAME reference sources: hipcc's default floating-point contraction (fast: mul+add pairs are fused at the
+# compiler's discretion, as nvcc --fmad=true does for the CUDA binary) and -ffp-contract=off (no fusion at all).  The pair
+# is the reference's own compile-to-compile noise floor: tests/test_gpu_ref.py measures how many pixels and how much
+# gradient two legitimate builds of the reference differ by, and ties this implementation's tolerances to that.
+build() {  # $1 = output name, $2... = extra flags
+	local out="$1"; shift
+	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w "$@" \
+		-I "$TMP" -I "$RAST/third_party/glm" \
+		"$TMP/forward.cu" "$TMP/backward.cu" "$TMP/rasterizer_impl.cu" "$HERE/ref_shim.cpp" \
+		-o "$OUT/$out"
+	echo "[build_ref] built $OUT/$out from $RAST ($*)"
+}
+build libgsref.so &
+build libgsref_nocontract.so -ffp-contract=off &
+wait
+[ -f "$OUT/libgsref.so" ] && [ -f "$OUT/libgsref_nocontract.so" ]

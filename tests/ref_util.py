@@ -5,21 +5,24 @@ import os
 
 import torch
 
-_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libgsref.so")
-_L = None
+_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+# two builds of the same reference sources (oracle/build_ref.sh): hipcc's default contraction, and -ffp-contract=off
+_FILES = {"default": "libgsref.so", "nocontract": "libgsref_nocontract.so"}
+_PATH = os.path.join(_DIR, _FILES["default"])
+_L = {}
 
 
-def available():
-    return os.path.exists(_PATH) and torch.cuda.is_available()
+def available(variant="default"):
+    return os.path.exists(os.path.join(_DIR, _FILES[variant])) and torch.cuda.is_available()
 
 
-def lib():
-    global _L
-    if _L is None:
-        _L = ctypes.CDLL(_PATH)
-        _L.ref_create.restype = ctypes.c_void_p
-        _L.ref_destroy.argtypes = [ctypes.c_void_p]
-    return _L
+def lib(variant="default"):
+    if variant not in _L:
+        L = ctypes.CDLL(os.path.join(_DIR, _FILES[variant]))
+        L.ref_create.restype = ctypes.c_void_p
+        L.ref_destroy.argtypes = [ctypes.c_void_p]
+        _L[variant] = L
+    return _L[variant]
 
 
 def _p(t):
@@ -28,9 +31,9 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def run(sc, cam, D, kw, grads=None, scale_modifier=1.0, bg=None, dev="cuda"):
+def run(sc, cam, D, kw, grads=None, scale_modifier=1.0, bg=None, dev="cuda", variant="default"):
     """Forward (+ backward when grads is given) of the reference rasterizer.  Returns a dict of CPU tensors."""
-    L = lib()
+    L = lib(variant)
     h = ctypes.c_void_p(L.ref_create())
     try:
         P = sc.means3D.shape[0]

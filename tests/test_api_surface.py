@@ -158,3 +158,44 @@ def test_reference_renderers_load_our_op_unchanged():
                 del sys.modules[k]
         for k in stubs:
             sys.modules.pop(k, None)
+
+
+def test_replay_of_the_renderer_calls_equals_the_recording():
+    """tests/caller_replay.py (the hand-written restatement of renderers/base.py:10-63 + get_gaussians_properties that the GPU
+    tests drive the operator with) against tests/golden/py_render_calls.json (what the UNMODIFIED classes hand the operator,
+    recorded in the dev container): identical records for all cases, on the CPU."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import caller_replay
+    import render_call_record as rcr
+    fixture = json.load(open(os.path.join(ROOT, "tests", "golden", "py_render_calls.json")))["cases"]
+    assert sorted(fixture) == sorted(c["name"] for c in rcr.CASES) and len(fixture) == 8
+    for case in rcr.CASES:
+        got = caller_replay.replay_case(case, "cpu")
+        want = fixture[case["name"]]
+        assert json.loads(json.dumps(rcr.comparable(got))) == rcr.comparable(want), case["name"]
+        assert got["returns"] == want["returns"]
+    # facts of the recording the operator depends on (SURVEY.md s8b "Device conventions", "Absent-input convention")
+    v = fixture["vanilla_train_deg2"]
+    assert v["positional_args"] == 0 and v["settings"]["bg"]["tensor"]["shape"] == [3] and v["bg_is_the_renderers_cpu_tensor"]
+    assert v["settings"]["viewmatrix"]["tensor"]["contiguous"] is False          # a transposed view: the op must .contiguous() it
+    assert v["arguments"]["means2D"]["is_leaf"] is False and v["arguments"]["means2D"]["retains_grad"] is True
+    assert v["arguments"]["colors_precomp"] is None and v["arguments"]["cov3D_precomp"] is None
+    p = fixture["pcd_default"]
+    assert p["arguments"]["opacities"]["shape"] == [64, 3] and p["arguments"]["shs"] is None and p["settings"]["sh_degree"]["value"] == 1
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gaustudio/renderers"), reason="reference checkout not present")
+def test_recorded_renderer_calls_are_current():
+    """Re-runs the recording against the reference checkout (dev container) and compares with the committed fixture."""
+    import json
+    import subprocess
+    import tempfile
+    gold = os.path.join(ROOT, "tests", "golden")
+    with tempfile.TemporaryDirectory() as d:
+        code = ("import sys, os; sys.path.insert(0, %r); import make_ref_py_fixtures as m; m.HERE = %r; m.make_render_calls_fixture(); m.make_ply_fixture()" % (gold, d))
+        subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, timeout=300)
+        assert json.load(open(os.path.join(d, "py_render_calls.json"))) == json.load(open(os.path.join(gold, "py_render_calls.json")))
+        import numpy as np
+        a, b = np.load(os.path.join(d, "py_ply.npz")), np.load(os.path.join(gold, "py_ply.npz"))
+        assert sorted(a.files) == sorted(b.files) and all(np.array_equal(a[k], b[k]) for k in a.files)

@@ -57,7 +57,7 @@ def _pixel(alphas, rgb, depths):
 
 
 def test_alpha_threshold_flip_is_attributed_and_a_wrong_value_is_not():
-    a_mid = (1.0 / 255.0) * (1.0 + 5e-6)                     # inside WIN_ALPHA: either decision is legitimate
+    a_mid = (1.0 / 255.0) * (1.0 + 2e-6)                     # inside WIN_ALPHA: either decision is legitimate
     st = _hand_state(a_mid)
     with_mid = _pixel([0.6, a_mid, 0.7], st["rgb"].astype(np.float64), st["depths"].astype(np.float64))
     without = _pixel([0.6, 0.7], st["rgb"][[0, 2]].astype(np.float64), st["depths"][[0, 2]].astype(np.float64))

@@ -376,3 +376,107 @@ def test_two_ranks_factored_exchange_real_kernels(tmp_path, compact):
     for k in KEYS:
         assert torch.equal(got[0][k], got[1][k]), k
         assert torch.equal(got[0][k], want[k]), k
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the RCCL calls themselves, world_size 1
+def _nccl_world1_worker(rank, world, port, out_dir):
+    """Every collective call of the N > 1 step on backend "nccl" (= RCCL) with a process group of ONE rank on the leased GPU:
+    init_process_group(device_id=...), the armed flat bucket with SH chunks reduced from inside the backward (async work
+    handles on the communicator's stream), the in-place all_gather_into_tensor, the geometry all-reduce, the mask all-reduce
+    of the compacted form.  A sum / gather over one rank is the identity, so every result must equal the no-collective
+    run BIT FOR BIT."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from gaustudio_amd import GaussianRasterizationSettings, GaussianRasterizer
+        parallel.FORCE_COLLECTIVES = True
+        sc, cams = _scene_and_cams(2)
+        report = {}
+        # --- dense: gradients born in the flat bucket, SH stage in 4 ranges, each all-reduced asynchronously from the hook
+        params = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in KEYS}
+        bucket = parallel.FlatGradBucket(list(params.values()), roles=params)
+        m2 = torch.zeros_like(params["means3D"])
+
+        def render(cam):
+            rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                               cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+            out = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=m2, opacities=params["opacities"], shs=params["shs"],
+                                         scales=params["scales"], rotations=params["rotations"])
+            g = [t.to(dev) for t in scenes.make_output_grads(cam, seed=5)]
+            torch.autograd.backward([out[0], out[2], out[3], out[4]], g)
+
+        parallel.render_views_and_reduce(render, cams[:1], bucket, overlap_chunks=4)
+        torch.cuda.synchronize()
+        # 1500 Gaussians in 4 requested ranges of multiples of 256 -> 512 + 512 + 476: three chunk collectives + the tail
+        assert bucket.stats["chunks"] == 3 and bucket.stats["chunk_bytes"] + bucket.stats["tail_bytes"] == bucket.nbytes, bucket.stats
+        report["dense"] = {k: p.grad.cpu() for k, p in params.items()}
+        # two local views: no chunking (a later local accumulation would follow the partial reduction), one all-reduce
+        parallel.render_views_and_reduce(render, cams, bucket, overlap_chunks=4)
+        torch.cuda.synchronize()
+        report["dense2"] = {k: p.grad.cpu() for k, p in params.items()}
+        # --- factored: colour all-gather (in place) + geometry all-reduce, with and without visible-row compaction
+        for compact in (False, True):
+            got, fx = _factored_step(sc, cams[:1], cams[:1], dev, V=1, compact=compact)
+            assert fx.world == 1 and parallel._multi(None)
+            report[f"factored_compact{int(compact)}"] = got
+            got2, _ = _factored_step(sc, cams, cams, dev, V=2, compact=compact)
+            report[f"factored2_compact{int(compact)}"] = got2
+        torch.save(report, os.path.join(out_dir, "nccl1.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn_with_timeout(fn, args, nprocs, timeout_s):
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > timeout_s:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+            pytest.fail(f"worker did not finish within {timeout_s} s (RCCL initialisation or a collective hangs)")
+
+
+@pytest.mark.gpu
+def test_nccl_world1_every_collective_call_of_the_step(tmp_path):
+    """backend "nccl" (RCCL), world_size 1, on the leased GPU: the dense step (arm(overlap_chunks=4): chunk hooks + tail) and
+    the factored step (FactoredGradExchange.exchange, with and without `compact`, V = 1 and 2) give gradients bit-equal to
+    the run without any collective.  The N > 1 path had only ever met gloo (missing #2)."""
+    _spawn_with_timeout(_nccl_world1_worker, (1, _free_port(), str(tmp_path)), 1, 240)
+    got = torch.load(os.path.join(tmp_path, "nccl1.pt"))
+    dev = torch.device("cuda", 0)
+    sc, cams = _scene_and_cams(2)
+    want1 = _accumulate_views_dense(sc, cams[:1], dev)
+    want2 = _accumulate_views_dense(sc, cams, dev)
+    for name, want in (("dense", want1), ("dense2", want2), ("factored_compact0", want1), ("factored_compact1", want1),
+                       ("factored2_compact0", want2), ("factored2_compact1", want2)):
+        for k in KEYS:
+            assert torch.equal(got[name][k], want[k]), (name, k)
+    assert float(want1["shs"].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["dense", "factored"])
+def test_nccl_world1_through_bench_py(tmp_path, exchange):
+    """`bench.py --gpus 1` with GSR_BENCH_FORCE_PG=1: the exact code path of the driver's N > 1 runs (init_process_group("nccl",
+    device_id=...), armed bucket / FactoredGradExchange, barrier + MAX all-reduce of the clock, comm block) on one GPU.
+    The line must carry a `comm` block of the requested exchange WITHOUT a fallback."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSR_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "C2", "--steps", "4", "--warmup", "2",
+                        "--exchange", exchange, "--no-cpu-baseline", "--no-ref-ab"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["comm"]["exchange"] == exchange and line["comm"]["exchange_fallback"] is None, line["comm"]
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    if exchange == "dense":
+        assert line["comm"]["chunks_per_step"] == 4 and line["comm"]["tail_bytes_per_step"] > 0

@@ -10,6 +10,11 @@ the point cloud, models/vanilla_sg.py:33-37) and PCDRenderer.get_gaussians_prope
 opacity = ones_like(xyz) i.e. [P,3], scales = ones * kernel_size, identity rotations, colors_precomp = rgb / 255)
 produce.  Results are checked against the CPU oracle.  (On a machine that has /root/reference, the import-level test
 in test_api_surface.py additionally loads the unmodified renderer classes against this module.)
+
+The replay itself (tests/caller_replay.py) is PINNED to the real classes: tests/golden/py_render_calls.json is a recording of
+what the operator receives when the unmodified VanillaRenderer / PCDRenderer run (dev container, recording rasterizer), and
+`test_replay_equals_the_recorded_reference_calls` asserts that the replay produces the identical record on this box -- then
+pushes the very same calls through the real operator.
 """
 import math
 
@@ -20,44 +25,21 @@ import torch
 from gaustudio_amd import scenes
 from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
+import caller_replay
 from util import to_np
 
 pytestmark = pytest.mark.gpu
 
 
-class _Camera:
-    """The attributes of gaustudio.datasets.Camera that BaseRenderer.render reads (datasets/__init__.py:138-183)."""
-
-    def __init__(self, cam: scenes.Cam, dev):
-        self.image_height, self.image_width = cam.height, cam.width
-        self.FoVx, self.FoVy = 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy)
-        self.world_view_transform = cam.viewmatrix.to(dev)
-        self.full_proj_transform = cam.projmatrix.to(dev)
-        self.camera_center = cam.campos.to(dev)
+from caller_replay import render_like_base_renderer as _render_like_base_renderer      # base.py:10-63, call for call
 
 
-def _render_like_base_renderer(props, camera, active_sh_degree, bg_color, scaling_modifier=1.0, debug=False):
-    """base.py:10-63, call for call."""
-    xyz, shs, colors_precomp, opacity, scales, rotations, cov3D_precomp = props
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device="cuda") + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(camera.image_height), image_width=int(camera.image_width),
-        tanfovx=math.tan(camera.FoVx * 0.5), tanfovy=math.tan(camera.FoVy * 0.5), bg=bg_color,
-        scale_modifier=scaling_modifier, viewmatrix=camera.world_view_transform,
-        projmatrix=camera.full_proj_transform, sh_degree=active_sh_degree if shs is not None else 1,
-        campos=camera.camera_center, prefiltered=False, debug=debug)
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-    image, radii, depth, median_map, final_opacity = rasterizer(
-        means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": image, "rendered_depth": depth, "rendered_median_depth": median_map[0:1],
-            "rendered_median_weight": median_map[1:2], "rendered_median_id": median_map[2:3].int(),
-            "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-            "rendered_final_opacity": final_opacity, "radii": radii}
+def _Camera(cam: scenes.Cam, dev):
+    """The attributes of gaustudio.datasets.Camera that BaseRenderer.render reads (datasets/__init__.py:138-183), with the
+    strides the reference's Camera produces: a transposed-view world_view_transform, a sliced camera_center."""
+    view = cam.viewmatrix.t().contiguous().t()
+    return caller_replay.Camera(cam.width, cam.height, 2 * math.atan(cam.tanfovx), 2 * math.atan(cam.tanfovy), view.to(dev),
+                                cam.projmatrix.to(dev), torch.inverse(view)[3][:3].to(dev))
 
 
 def test_vanilla_renderer_call_pattern_forward_and_backward(oracle):
@@ -224,3 +206,46 @@ def test_covariance_gradient_only_when_covariances_were_supplied():
         if k != "dL_dcov3D":
             assert torch.equal(a[k], b[k]), k
     assert bool(torch.isnan(b["dL_dcov3D"]).all())       # untouched (the helper poisons its buffers with NaN)
+
+
+def _fixture_cases():
+    import json
+    import os
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import render_call_record as rcr
+    return rcr, json.load(open(os.path.join(gold, "py_render_calls.json")))["cases"]
+
+
+def test_replay_equals_the_recorded_reference_calls():
+    """Every recorded case (8: VanillaRenderer training / no_grad / white bg + modifier + debug / cov3D in Python / SH in
+    Python / 2-column scales; PCDRenderer default / kernel + white bg): the replay on the GPU gives the record the
+    unmodified reference classes gave -- settings tuple field by field, keyword set, None-ness, shapes, dtypes, strides'
+    contiguity, requires_grad / leaf / retained grad, grad mode, the CPU `bg` -- and the package it returns has the recorded
+    keys, dtypes and shapes.  Then the same properties go through the REAL operator."""
+    import json
+    rcr, fixture = _fixture_cases()
+    assert sorted(fixture) == sorted(c["name"] for c in rcr.CASES)
+    for case in rcr.CASES:
+        want = fixture[case["name"]]
+        got = caller_replay.replay_case(case, "cuda")
+        assert json.loads(json.dumps(rcr.comparable(got))) == rcr.comparable(want), case["name"]
+        assert got["returns"] == want["returns"] and got["bg_is_the_renderers_cpu_tensor"] and want["bg_is_the_renderers_cpu_tensor"]
+        assert want["torch_factory_calls_with_device_cuda"][-1] == ["zeros_like", "cuda"]          # base.py:13: the carrier is asked for on "cuda"
+        # the real operator on the same call
+        raw = rcr.raw_attributes(case, "cuda")
+        c = scenes.make_camera(96, 64)
+        cam = _Camera(c, "cuda")
+        bg, modifier, debug, conf = caller_replay.renderer_state(case["renderer"], case["config"])
+        with torch.set_grad_enabled(not case.get("no_grad", False)):
+            raw["xyz"] = raw["xyz"] * 0.5 + torch.tensor([0.0, 0.0, 5.0], device="cuda")        # in front of the camera
+            props = caller_replay.properties_like_reference(case["renderer"], conf, raw, case["active_sh_degree"], cam)
+            pkg = _render_like_base_renderer(props, cam, case["active_sh_degree"], bg, modifier, debug)
+        for k, v in want["returns"].items():
+            assert list(pkg[k].shape) == v["shape"] and str(pkg[k].dtype) == v["dtype"], (case["name"], k)
+            assert bool(torch.isfinite(pkg[k].float()).all())
+        assert int(pkg["visibility_filter"].sum()) > 0, case["name"]
+        if torch.is_grad_enabled() and not case.get("no_grad", False) and pkg["render"].requires_grad:
+            pkg["render"].sum().backward()
+            assert pkg["viewspace_points"].grad is not None

@@ -11,7 +11,18 @@ changes by up to alpha*T*c ~ 4e-3.  Such pixels are not merely counted: EVERY pi
 be ATTRIBUTED to such an event by tests/attribution.py -- a float64 replay of the pixel's list in which only decisions
 inside stated windows of their thresholds may be taken either way has to reproduce this implementation's value with
 one set of decisions and the reference's value with another.  `unattributed == 0` is asserted; the counts go to
-profiles/r03_parity.json as a report.
+profiles/r04_parity.json as a report.
+
+Both compositing modes of the library are held against the reference here: the bit-exact default (`fast_exp` = 0, the
+mode the CPU oracle pins to the bit) and `fast_exp` = 1 (v_exp_f32; include/gsrast.h gsr_options.fast_exp) -- the same
+scenes, the same attribution, the same gradient bounds (forward.cu:338-361, backward.cu:519-540 are what both restate).
+
+THE REFERENCE'S OWN NOISE FLOOR.  oracle/build_ref.sh builds the reference sources twice (hipcc's default contraction;
+-ffp-contract=off).  Two legitimate builds of the same kernels differ from each other at threshold events exactly as
+this library differs from either, and two RUNS of one build differ in every gradient (float atomicAdd in no fixed order,
+backward.cu:559-607).  `_noise_floor` measures both per configuration; the gradient tolerance of this library against
+the reference is GRAD_K x that measured floor (not a constant chosen by the builder), and the flip counts are reported
+next to the reference-vs-reference flip counts.
 """
 import glob
 import os
@@ -31,6 +42,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REF_FILES = sorted(glob.glob(os.path.join(GOLD, "ref_*.npz")))
 GRAD_KEYS = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+# gradient tolerance against the reference = GRAD_K x the reference's OWN floor, measured in the same test on the same
+# inputs: how far the reference's two builds (and two runs of one build) are from each other, relative to each tensor's
+# scale.  The MAXIMUM deviation is set by the handful of threshold flips of the frame (each build flips at different
+# pixels, and a flip lands in whichever of the eight tensors its Gaussian weighs most), so the floor for the maximum is
+# the largest build-vs-build deviation over the eight tensors of the configuration; the MEAN deviation is arithmetic
+# noise and is compared per tensor.  Measured (profiles/r04_parity.json): floors 1.9e-4 (C1) .. 3.9e-3 (C5); this library
+# sits at 0.1x .. 2.0x its configuration's floor in both modes.  Rounds 1-3 asserted a builder-chosen 5e-4.
+GRAD_K = 3.0
 
 
 def _compare(hs, ref, config, W, H):
@@ -69,59 +88,131 @@ def _compare(hs, ref, config, W, H):
     return stats
 
 
-def _dump_parity(config, stats):
-    """GSR_DUMP_PARITY=1: merge the measured report into gpurun_out/r03_parity.json (copied to profiles/ by hand)."""
+def _dump_parity(config, stats, section="configs"):
+    """GSR_DUMP_PARITY=1: merge the measured report into gpurun_out/r04_parity.json (copied to profiles/ by hand)."""
     if os.environ.get("GSR_DUMP_PARITY") != "1":
         return
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = os.path.join(root, "gpurun_out", "r03_parity.json")
+    out = os.path.join(root, "gpurun_out", "r04_parity.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    data = json.load(open(out)) if os.path.exists(out) else {"what": "HIP path vs the reference's own kernels (oracle/_ref/libgsref.so, the "
-                                                              "reference source compiled by hipcc) on an MI355X: values differing by more than "
-                                                              "1e-5 abs, each attributed to a threshold event (tests/attribution.py)", "configs": {}}
-    data["configs"][config] = stats
+    data = json.load(open(out)) if os.path.exists(out) else {
+        "what": "HIP path (both compositing modes) vs the reference's own kernels (oracle/_ref/libgsref.so, the reference source "
+                "compiled by hipcc) on an MI355X: values differing by more than 1e-5 abs, each attributed to a threshold event "
+                "(tests/attribution.py); `reference_vs_reference` = the same measurement between two builds of the reference "
+                "(default contraction vs -ffp-contract=off) and between two runs of one build (atomic order)",
+        "configs": {}, "reference_vs_reference": {}}
+    data.setdefault(section, {})[config] = stats
     json.dump(data, open(out, "w"), indent=1, sort_keys=True)
 
 
+_REF_RUNS = {}       # config -> reference runs of the configuration under test (one entry: the C4 / C5 tensors are large)
+
+
+def _reference_runs(config, sc, cam, D, kw, grads):
+    """The reference's kernels on this scene: the default build twice (two runs: the backward's atomics land in a different
+    order) and the -ffp-contract=off build once."""
+    if config not in _REF_RUNS:
+        _REF_RUNS.clear()
+        _REF_RUNS[config] = {"a": ref_util.run(sc, cam, D, kw, grads), "a2": ref_util.run(sc, cam, D, kw, grads),
+                             "b": ref_util.run(sc, cam, D, kw, grads, variant="nocontract")}
+    return _REF_RUNS[config]
+
+
+def _grad_rel(x, y):
+    """(max, mean) of |x - y| relative to the scale of y."""
+    x = np.asarray(x, np.float64); y = np.asarray(y, np.float64).reshape(x.shape)
+    scale = max(float(np.abs(y).max()), 1e-30)
+    d = np.abs(x - y)
+    return float(d.max() / scale), float(d.mean() / scale)
+
+
+def _noise_floor(hs, runs, W, H):
+    """What two legitimate builds / two runs of the REFERENCE differ by, measured like `_compare` measures this library:
+    values beyond 1e-5 between the builds (attributed with the same machinery, from this library's bit-checked records),
+    integer outputs, and the gradient differences (build vs build: threshold flips + contraction; run vs run: atomics)."""
+    a, a2, b = runs["a"], runs["a2"], runs["b"]
+    fl = {"radii_differ": int((a["radii"] != b["radii"]).sum()), "num_rendered": [int(a["num_rendered"]), int(b["num_rendered"])],
+          "median_id_differ": int((a["median"][2] != b["median"][2]).sum())}
+    ia = {k: a[k].numpy() for k in ("color", "depth", "opacity")}
+    ib = {k: b[k].numpy() for k in ("color", "depth", "opacity")}
+    for k in ia:
+        d = np.abs(ia[k].astype(np.float64) - ib[k].astype(np.float64))
+        fl[k] = {"over_1e-5": int((d > 1e-5).sum()), "values": int(d.size), "max_abs": float(d.max())}
+        # forward is deterministic: two runs of one build agree to the bit
+        assert np.array_equal(ia[k], a2[k].numpy()), f"reference forward is not run-to-run deterministic ({k})"
+    rep = attribution.attribute_images(hs, W, H, ia, ib, tol=1e-5, depth_scale=20.0, radii_b=b["radii"].numpy(), tol_a=1e-5,
+                                       radii_a=a["radii"].numpy())
+    fl["attribution"] = {k: rep[k] for k in ("flagged", "attributed", "by_kind", "max_margin")}
+    fl["attribution"]["unattributed"] = len(rep["unattributed"])
+    fl["grads_build_vs_build"], fl["grads_run_vs_run"] = {}, {}
+    for k in GRAD_KEYS:
+        if a[k].numel() == 0:
+            continue
+        mx, mn = _grad_rel(b[k].numpy(), a[k].numpy())
+        fl["grads_build_vs_build"][k] = {"max_rel": mx, "mean_rel": mn}
+        mx, mn = _grad_rel(a2[k].numpy(), a[k].numpy())
+        fl["grads_run_vs_run"][k] = {"max_rel": mx, "mean_rel": mn}
+    return fl
+
+
+@pytest.mark.parametrize("fast_exp", [0, 1], ids=["exact", "fast_exp"])
 @pytest.mark.parametrize("P,W,H,D", [(10000, 400, 400, 0), (300000, 800, 800, 3), (1000000, 1920, 1080, 3),
                                      (5000000, 1297, 840, 3), (2500000, 3840, 2160, 3)],
                          ids=["C1", "C2", "C3", "C4", "C5"])
-def test_hip_vs_reference_kernels_at_baseline_configs(request, P, W, H, D):
+def test_hip_vs_reference_kernels_at_baseline_configs(request, P, W, H, D, fast_exp):
     """BASELINE configs C1, C2, the full-size headline C3 and one view of the C4 / C5 sizes (5 M Gaussians with ~3.7 k
-    entries per tile: the long-list sort and row-flag regime; a 4K frame), forward and backward, against the reference's
-    own kernels.
+    entries per tile: the long-list sort and row-flag regime; a 4K frame), forward and backward, BOTH compositing modes
+    (bit-exact default; fast_exp = hardware exp), against the reference's own kernels.
     oracle/_ref/libgsref.so is built in the dev container (oracle/build_ref.sh) and travels with the snapshot: its
     absence on a GPU box is a FAILURE, not a skip -- this comparison is what pins the parity claim."""
-    if not ref_util.available():
-        pytest.fail("oracle/_ref/libgsref.so is missing: run oracle/build_ref.sh in the dev container (needs "
-                    "/root/reference) before shipping the tree to the GPU box")
-    config = request.node.callspec.id
+    if not (ref_util.available() and ref_util.available("nocontract")):
+        pytest.fail("oracle/_ref/libgsref.so / libgsref_nocontract.so missing: run oracle/build_ref.sh in the dev container "
+                    "(needs /root/reference) before shipping the tree to the GPU box")
+    import gaustudio_amd
+    config = request.node.callspec.id.split("-")[0]
+    mode = "fast_exp" if fast_exp else "exact"
     cam = scenes.make_camera(W, H)
     sc = scenes.make_scene(P, cam, seed=0)
     kw = scene_kwargs(sc, True, False)
     grads = scenes.make_output_grads(cam)
-    ref = ref_util.run(sc, cam, D, kw, grads)
-    hs = hip_forward(sc, cam, D, kw)
+    runs = _reference_runs(config, sc, cam, D, kw, grads)
+    ref = runs["a"]
+    with gaustudio_amd.options(fast_exp=bool(fast_exp)):
+        hs = hip_forward(sc, cam, D, kw)
     stats = _compare(hs, ref, config, W, H)
-    if config == "C3":
+    if not fast_exp:
+        floor = _noise_floor(hs, runs, W, H)
+        _dump_parity(config, floor, section="reference_vs_reference")
+        assert floor["attribution"]["unattributed"] == 0, "two builds of the reference differ at a pixel that is no threshold event"
+    if config == "C3" and not fast_exp:
         # report: how often the reference's backward would route the median-depth gradient differently (DESIGN.md s3)
         stats["median_gradient_census"] = attribution.median_gradient_census(hs, W, H)
-    hb = hip_backward_raw(hs, sc, cam, D, kw, grads)
+    hb = hip_backward_raw(hs, sc, cam, D, kw, grads, options=dict(fast_exp=fast_exp), debug=True)   # debug: mode checked against the forward's record
     stats["grads"] = {}
-    for k in GRAD_KEYS:
+    floors = {k: (max(_grad_rel(runs["b"][k].numpy(), ref[k].numpy())[0], _grad_rel(runs["a2"][k].numpy(), ref[k].numpy())[0]),
+                  max(_grad_rel(runs["b"][k].numpy(), ref[k].numpy())[1], _grad_rel(runs["a2"][k].numpy(), ref[k].numpy())[1]))
+              for k in GRAD_KEYS if ref[k].numel()}
+    floor_max = max(f[0] for f in floors.values())          # the configuration's floor for a MAXIMUM: see GRAD_K
+    stats["reference_floor_max_rel_any_tensor"] = floor_max
+    for k in floors:
         a = to_np(hb[k]); b = ref[k].numpy().reshape(a.shape)
-        scale = np.abs(b).max()
-        stats["grads"][k] = {"max_rel": float(np.abs(a - b).max() / max(scale, 1e-30)), "mean_rel": float(np.abs(a - b).mean() / max(scale, 1e-30))}
-        # both sides sum thousands of fp32 terms per Gaussian in different orders, plus rare branch flips
-        assert np.abs(a - b).max() <= 5e-4 * scale, (k, float(np.abs(a - b).max()), float(scale))
-        assert np.abs(a - b).mean() <= 1e-6 * scale, k
-    _dump_parity(config, stats)
+        mx, mn = _grad_rel(a, b)
+        mx_b = _grad_rel(a, runs["b"][k].numpy())[0]          # (report) distance to the -ffp-contract=off build of the reference
+        stats["grads"][k] = {"max_rel": mx, "mean_rel": mn, "max_rel_vs_nocontract_build": mx_b, "reference_floor_max_rel": floors[k][0],
+                             "reference_floor_mean_rel": floors[k][1], "max_rel_over_config_floor": mx / max(floor_max, 1e-30)}
+        # both sides sum thousands of fp32 terms per Gaussian in different orders, plus rare branch flips: no further from
+        # the reference than GRAD_K x what the reference is from itself
+        assert mx <= GRAD_K * floor_max, (k, mode, mx, floor_max)
+        assert mn <= GRAD_K * max(floors[k][1], 1e-9), (k, mode, mn, floors[k][1])
+    _dump_parity(config, stats, section="configs" if not fast_exp else "configs_fast_exp")
 
 
+@pytest.mark.parametrize("fast_exp", [0, 1], ids=["exact", "fast_exp"])
 @pytest.mark.parametrize("path", REF_FILES, ids=[os.path.basename(p)[:-4] for p in REF_FILES])
-def test_hip_vs_committed_reference_fixtures(path):
-    """Same comparison against the committed fixtures (works even where libgsref.so is absent)."""
+def test_hip_vs_committed_reference_fixtures(path, fast_exp):
+    """Same comparison against the committed fixtures (works even where libgsref.so is absent), both compositing modes."""
+    import gaustudio_amd
     z = np.load(path)
     cam = scenes.Cam(int(z["width"]), int(z["height"]), float(z["tanfovx"]), float(z["tanfovy"]),
                      torch.from_numpy(z["viewmatrix"]), torch.from_numpy(z["projmatrix"]), torch.from_numpy(z["campos"]))
@@ -131,14 +222,15 @@ def test_hip_vs_committed_reference_fixtures(path):
     kw = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
     bg = torch.from_numpy(z["bg"])
     D, mod = int(z["D"]), float(z["scale_modifier"])
-    hs = hip_forward(sc, cam, D, kw, scale_modifier=mod, bg=bg)
+    with gaustudio_amd.options(fast_exp=bool(fast_exp)):
+        hs = hip_forward(sc, cam, D, kw, scale_modifier=mod, bg=bg)
     assert hs["num_rendered"] == int(z["ref_num_rendered"])
     assert np.array_equal(to_np(hs["radii"]), z["ref_radii"])
     for k in ("color", "depth", "opacity"):
         assert np.abs(to_np(hs[k]) - z["ref_" + k]).max() <= 1e-5, k
     assert np.array_equal(to_np(hs["median"])[2], z["ref_median"][2])
     grads = [torch.from_numpy(z[k]) for k in ("grad_color", "grad_depth", "grad_median", "grad_opacity")]
-    hb = hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=mod, bg=bg)
+    hb = hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=mod, bg=bg, options=dict(fast_exp=fast_exp), debug=True)
     for k in GRAD_KEYS:
         ref = z["ref_" + k]
         if ref.size == 0:
