@@ -376,7 +376,9 @@ def main():
     ap.add_argument("--rotate-cameras", type=int, default=None,
                     help="K: cycle a ring of K cameras (a different one every step) and apply an Adam update of every parameter "
                          "between the steps; default: the headline is the static camera and a K=8 block is reported beside it")
-    ap.add_argument("--fast-exp", action="store_true", help="run the whole benchmark in the opt-in fast_exp mode")
+    ap.add_argument("--fast-exp", action="store_true", help="run the whole benchmark in the fast_exp mode (the library default since round 4; explicit here)")
+    ap.add_argument("--exact", action="store_true", help="run the whole benchmark in the bit-exact mode (reproducible polynomial exp: the CPU oracle's bits; "
+                                                         "the test suite's mode) instead of the library default")
     ap.add_argument("--no-extras", action="store_true", help="skip the rotating-camera and fast_exp blocks of the default line")
     ap.add_argument("--traffic", type=float, default=None,
                     help="measured HBM bytes per composite_fwd launch from a rocprofv3 --pmc pass; default: the "
@@ -454,7 +456,11 @@ def main():
         campos_all = torch.stack([c.campos for c in all_cams]).to(dev)
     state = {}
     comm_ev = []       # (backward enqueued, exchange finished) events of the timed steps, N > 1 only
-    mode = gaustudio_amd.options(fast_exp=True) if a.fast_exp else gaustudio_amd.options()
+    # compositing mode: the library default (fast_exp = v_exp_f32 unless GSR_FAST_EXP=0) or the one asked for
+    if a.fast_exp and a.exact:
+        raise SystemExit("--fast-exp and --exact exclude each other")
+    fast_mode = True if a.fast_exp else (False if a.exact else bool(_C.get_option("fast_exp")))
+    mode = gaustudio_amd.options(fast_exp=fast_mode)
 
     def render(i, rasterizer):
         out = rasterizer(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], shs=params["shs"],
@@ -568,11 +574,12 @@ def main():
             opt_ms = None
 
     extras = {}
-    if not multi and not a.no_extras and not rotating_headline and a.workload in ("C3", "C3D0") and not a.fast_exp:
-        # beside the static-camera headline: (1) the rotating / optimizer-contended step, (2) the opt-in fast_exp mode
+    if not multi and not a.no_extras and not rotating_headline and a.workload in ("C3", "C3D0"):
+        # beside the static-camera headline: (1) the rotating / optimizer-contended step (same mode), (2) the OTHER compositing mode
         K = 8
         rot_fn, opt_ev = make_rotating(K)
-        rdt, rf, rb = timed_run(rot_fn, 24, 8)
+        with mode:
+            rdt, rf, rb = timed_run(rot_fn, 24, 8)
         torch.cuda.synchronize()
         ro = sum(x.elapsed_time(y) for x, y in opt_ev) / max(1, len(opt_ev)) if opt_ev else 0.0
         rstep = rdt / 24 * 1e3 - ro
@@ -586,14 +593,15 @@ def main():
         if not a.fwd_only:
             for p in params.values():
                 p.grad = None
-        with gaustudio_amd.options(fast_exp=True):
+        with gaustudio_amd.options(fast_exp=not fast_mode):
             fdt, ff, fb = timed_run(lambda timed: step(timed), 24, 8)
-        extras["variants"] = {"fast_exp": {"steps": 24, "ms_per_step": round(fdt / 24 * 1e3, 4),
-                                           "value": round(V * H * W / (fdt / 24) / 1e6, 3), "unit": "Mpixels/s",
-                                           "stage_ms": {"forward": ff, "backward": fb},
-                                           "note": "opt-in (gaustudio_amd.options(fast_exp=True) / gsr_options.fast_exp): v_exp_f32 in both "
-                                                   "compositing kernels; not bit-reproducible against the CPU oracle, parity evidence in "
-                                                   "tests/test_gpu_fastexp.py + profiles/r03_fastexp_parity.json"}}
+        other = "bit_exact" if fast_mode else "fast_exp"
+        extras["variants"] = {other: {"steps": 24, "ms_per_step": round(fdt / 24 * 1e3, 4),
+                                      "value": round(V * H * W / (fdt / 24) / 1e6, 3), "unit": "Mpixels/s",
+                                      "stage_ms": {"forward": ff, "backward": fb},
+                                      "note": ("gaustudio_amd.options(fast_exp=False) / GSR_FAST_EXP=0: the reproducible 9-instruction exp, every output "
+                                               "bit-identical to the CPU oracle (the test suite's mode)") if fast_mode else
+                                              ("gaustudio_amd.options(fast_exp=True): v_exp_f32 in both compositing kernels (the library default)")}}
 
     # instance counts of this rank's view (they drive every composite-stage byte count): the reference-defined
     # num_rendered and the instances actually binned; per-tile list lengths
@@ -654,7 +662,10 @@ def main():
                        "views_per_step": world * V, "views_per_rank": V,
                        "camera": (f"ring of {a.rotate_cameras}, a different one every step, Adam update between the steps "
                                   f"({round(opt_ms, 4)} ms, excluded)") if rotating_headline else "static (the same view every step)",
-                       "mode": "fast_exp" if a.fast_exp else "bit-exact (default)",
+                       "mode": ("fast_exp (library default: v_exp_f32 in the compositing kernels; pinned to the reference's kernels and to the "
+                                "CPU oracle by threshold-event attribution, tests/test_gpu_ref.py + tests/test_gpu_fastexp_oracle.py, "
+                                "profiles/r04_parity.json)") if fast_mode else
+                               "bit-exact (reproducible exp: every output bit-identical to the CPU oracle; --exact / GSR_FAST_EXP=0)",
                        "parallelism": par},
             "stage_ms": {"forward": fwd_ms, "backward": bwd_ms},
             "stage_roofline": stage_roofline(P, vis, R, T, H, W, D, fwd_ms, bwd_ms, a.fwd_only),

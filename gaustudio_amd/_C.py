@@ -130,7 +130,9 @@ def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None, colors_out=None):
 
 
 def set_option(name, value):
-    """Process-wide tunables of libgsrast.so (include/gsrast.h gsr_set_option); none changes a result bit."""
+    """Process-wide tunables of libgsrast.so (include/gsrast.h gsr_set_option).  Only `fast_exp` (the process default of the
+    compositing kernels' exp: 1 = v_exp_f32, the default; 0 = the reproducible polynomial, bit-identical to the CPU oracle)
+    changes a result bit; the autograd Functions resolve it at forward time and keep it with the graph (options.resolved)."""
     L = lib()
     rc = L.gsr_set_option(name.encode(), ctypes.c_int(int(value)))
     if rc < 0:

@@ -141,7 +141,36 @@ std::atomic<int> g_opt_fwd_variant{env_int("GSR_FWD_VARIANT", 0)}; // 0: per-qua
 std::atomic<int> g_opt_bwd_variant{env_int("GSR_BWD_VARIANT", -1)};   // -1: from gsr_selftest; bit 0: select on T
 std::atomic<int> g_opt_speculative{env_int("GSR_SPECULATIVE", 1)}; // launch binning + compositing before R is known
 std::atomic<int> g_opt_band_lo{0}, g_opt_band_hi{0};               // tile rows [lo, hi) this process renders (hi <= 0: all)
-std::atomic<int> g_opt_fast_exp{env_int("GSR_FAST_EXP", 0)};       // exp on the transcendental unit in both compositing kernels
+// exp on the transcendental unit (v_exp_f32) in both compositing kernels.  DEFAULT ON since round 4: pinned directly against the
+// reference's kernels and the CPU oracle (tests/test_gpu_ref.py, tests/test_gpu_fastexp_oracle.py), it differs from the
+// reference at no more pixels than two builds of the reference differ from each other (profiles/r04_parity.json).
+// GSR_FAST_EXP=0 / gsr_set_option("fast_exp", 0) / gsr_options.fast_exp = 0: the reproducible polynomial exp, bit-identical
+// to the CPU oracle (the test suite's mode).
+std::atomic<int> g_opt_fast_exp{env_int("GSR_FAST_EXP", 1)};
+
+// The exp mode the most recent forwards ran with, by image buffer: a backward handed buffers of a forward in the OTHER mode
+// would take other alpha >= 1/255 decisions than its forward (silently inconsistent gradients).  The device-side record
+// (GsCtl::opts) needs a read-back to check (debug mode does); this host-side memory makes the check free for the common
+// case of a backward that follows its forward in the same process.  An entry overwritten by newer forwards is simply not checked.
+struct FwdMode { const void* img; int fast_exp; };
+constexpr int kFwdModes = 64;
+FwdMode g_fwd_modes[kFwdModes] = {};
+unsigned g_fwd_modes_next = 0;
+std::mutex g_fwd_modes_mutex;
+void remember_forward_mode(const void* img, int fast_exp)
+{
+	std::lock_guard<std::mutex> lock(g_fwd_modes_mutex);
+	for (auto& e : g_fwd_modes)
+		if (e.img == img) { e.fast_exp = fast_exp; return; }
+	g_fwd_modes[g_fwd_modes_next++ % kFwdModes] = FwdMode{img, fast_exp};
+}
+int recall_forward_mode(const void* img)    // -1: unknown
+{
+	std::lock_guard<std::mutex> lock(g_fwd_modes_mutex);
+	for (const auto& e : g_fwd_modes)
+		if (e.img == img) return e.fast_exp;
+	return -1;
+}
 
 // options of ONE call: the caller's gsr_options where given (>= 0), the process defaults elsewhere
 struct Resolved {
@@ -451,6 +480,8 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	char* img = image_alloc(image_ctx, il.total + (lds_bin ? align_up(bin_hist_bytes(P, il.T)) : 0));
 	if (!geom || !img) return fail(GSR_ERR_ALLOC, "gsr_forward: allocator returned NULL", __FILE__, __LINE__);
 
+	remember_forward_mode(img, ro.fast_exp != 0);
+
 	GsCam* cam = reinterpret_cast<GsCam*>(geom + gl.cam);
 	GsRec* recs = reinterpret_cast<GsRec*>(geom + gl.recs);
 	GsCtl* ctl = reinterpret_cast<GsCtl*>(img + il.ctl);
@@ -743,6 +774,11 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	tm.mark();
 	if (R > 0) {
 		const Resolved ro = resolve_options(opt);
+		{
+			const int fwd_mode = recall_forward_mode(image_buffer);
+			if (fwd_mode >= 0 && fwd_mode != (ro.fast_exp != 0))
+				return fail(GSR_ERR_ARG, "gsr_backward: fast_exp differs from the forward that produced these buffers", __FILE__, __LINE__);
+		}
 		if (debug) {
 			// the forward recorded what it ran with: a backward in another exp mode would take other alpha >= 1/255 decisions
 			GsCtl c;

@@ -167,8 +167,12 @@ __global__ __launch_bounds__(NT) void tsdf_integrate_kernel(const float* __restr
 		// degenerate / non-finite point.  A point AT the sensor origin is what depth2point makes of a masked pixel (depth 0):
 		// a whole depth map can be integrated without compacting the valid pixels first.  "At" = within a thousandth of a
 		// voxel: the unprojection's camera centre and the caller's `origin` agree to rounding only, and a ray of 1e-7
-		// units would otherwise carve +-sdf_trunc around the sensor, hundreds of thousands of times into the same voxels
-		if (!(depth > 1.0e-3f * voxel_size) || !(depth < 3.0e38f)) active = false;
+		// units would otherwise carve +-sdf_trunc around the sensor, hundreds of thousands of times into the same voxels.
+		// That rounding scales with the COORDINATES (the unprojection inverts a view matrix: ~1e-6 of |origin|), not with
+		// the voxel: for a sensor at coordinates of a few hundred and 2-cm voxels it exceeds a thousandth of a voxel, so
+		// the threshold is also 1e-5 of the largest origin coordinate.  No real surface sample is that close.
+		const float at_origin = fmaxf(1.0e-3f * voxel_size, 1.0e-5f * fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz))));
+		if (!(depth > at_origin) || !(depth < 3.0e38f)) active = false;
 	}
 	__syncthreads();
 	// centre of the local window: the voxel of the workgroup's first ACTIVE point (anything nearby would do)

@@ -293,7 +293,11 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 		if (arena_matches(g_arena, P, M, fo, keys)) {   // one-shot, and only for the graph it was armed for
 			arena = std::move(g_arena);
 			g_arena = GradArena();
-			if (arena.sh_chunks > 1 && !arena.hook.is_none()) {
+			// "pending" only when this backward really reduces chunk by chunk (the condition of `chunked` below): without SH
+			// coefficients, with precomputed colours or with P = 0 the hook is never called, nothing is partly reduced and
+			// nothing would ever clear the flag
+			if (arena.sh_chunks > 1 && !arena.hook.is_none() && arena.outs.size() == 5 && !arena.colors_out.defined() && M > 0 &&
+			    sh.numel() != 0 && P != 0) {
 				std::copy(keys, keys + 4, g_pending_keys);
 				g_pending = true;
 			}

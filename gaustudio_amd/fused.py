@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .options import current as _current_options
+from .options import resolved as _current_options
 from .rasterizer import _dense_image_grads, _run_guarded
 
 ACT_OPACITY_SIGMOID = 1

@@ -54,3 +54,16 @@ class options:
     def __exit__(self, *exc):
         _tls.stack.pop()
         return False
+
+
+def resolved():
+    """current(), with `fast_exp` resolved against the process default NOW.  The autograd Functions store THIS with the graph:
+    the backward must evaluate exp() exactly as its forward did (the alpha >= 1/255 decisions depend on it), whatever a
+    `_C.set_option("fast_exp", ...)` -- or another thread -- does to the process default between the two calls.  The other
+    fields change no bit of the result and may stay deferred."""
+    cur = list(current())
+    i = FIELDS.index("fast_exp")
+    if cur[i] < 0:
+        from . import _C
+        cur[i] = int(_C.get_option("fast_exp"))
+    return tuple(cur)

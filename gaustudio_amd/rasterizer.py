@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .options import current as _current_options
+from .options import resolved as _current_options
 
 
 class GaussianRasterizationSettings(NamedTuple):

@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# The library's default compositing mode is fast_exp (v_exp_f32).  The test suite runs in the REPRODUCIBLE mode unless a test
+# asks otherwise (gaustudio_amd.options(fast_exp=True) / the fast_exp-parametrised tests): that is the mode the CPU oracle
+# pins to the bit.  Set through the environment, before libgsrast.so is loaded, so that spawned workers and the bench.py
+# subprocesses of the distributed tests inherit it.
+os.environ.setdefault("GSR_FAST_EXP", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

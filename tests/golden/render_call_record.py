@@ -109,5 +109,10 @@ def recording_module():
 def comparable(call):
     """The part of a recorded call that must be IDENTICAL between the reference's classes on the CPU box and a replay on the
     GPU box: everything except the two fields that describe the box."""
-    c = {k: v for k, v in call.items() if k not in ("_bg_obj", "torch_factory_calls_with_device_cuda", "returns", "bg_is_the_renderers_cpu_tensor")}
+    import copy
+    c = copy.deepcopy({k: v for k, v in call.items() if k not in ("_bg_obj", "torch_factory_calls_with_device_cuda", "returns", "bg_is_the_renderers_cpu_tensor")})
+    # camera_center is a 3-element SLICE of torch.inverse's result (datasets/__init__.py:182-183): non-contiguous where it was
+    # created (CPU), densified by Camera.to(device) (:197-205) on its way to a GPU -- its contiguity describes the box.  (The
+    # transposed-view world_view_transform keeps its strides through .to(): compared.)
+    c["settings"]["campos"]["tensor"].pop("contiguous", None)
     return c

@@ -167,6 +167,28 @@ def test_masked_pixels_at_the_sensor_origin_need_no_compaction():
 
 
 @pytest.mark.gpu
+def test_masked_pixels_far_from_the_world_origin_with_small_voxels():
+    """a sensor at coordinates of a few hundred units and 2-cm voxels -- the unprojected position of a masked pixel
+    differs from `origin` by the rounding of the coordinates (3e-5 here), far more than a thousandth of a voxel (2e-5); the
+    skip threshold also scales with |origin|, so such pixels still carve nothing."""
+    from gaustudio_amd.tsdf import TSDFVolume
+    rng = np.random.default_rng(11)
+    o = np.array([310.0, -120.0, 45.0], np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = (o + d * 2.0).astype(np.float32)
+    masked = (o + rng.uniform(-3e-5, 3e-5, (20000, 3))).astype(np.float32)          # ~1 ulp of 310 is 3e-5
+    vols = []
+    for cloud in (pts, np.concatenate([masked[:64], pts, masked[64:]])):
+        v = TSDFVolume(voxel_size=0.02, sdf_trunc=0.08, space_carving=False, device="cuda", capacity_blocks=1 << 16)
+        v.integrate(torch.from_numpy(cloud).cuda(), torch.from_numpy(o).cuda())
+        vols.append(v.export_voxels())
+    for x, y in zip(*vols):
+        assert torch.equal(x, y)
+    assert vols[0][0].shape[0] > 1000
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("H,W", [(64, 96), (37, 53), (32, 32), (1, 300), (200, 7), (270, 480)])
 def test_point_map_in_patches_gives_the_same_volume_as_the_flat_list(H, W):
     """integrate([H,W,3]) -- workgroups take 32 x 32 patches of the map (gsr_tsdf_integrate_map) -- against
