@@ -452,7 +452,7 @@ def main():
     bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()), roles=params)
     fx = None
     if factored:
-        fx = parallel.FactoredGradExchange(params, views_per_rank=V, sh_degree=D)
+        fx = parallel.FactoredGradExchange(params, views_per_rank=V)
         campos_all = torch.stack([c.campos for c in all_cams]).to(dev)
     state = {}
     comm_ev = []       # (backward enqueued, exchange finished) events of the timed steps, N > 1 only
@@ -480,7 +480,7 @@ def main():
         for v, r in enumerate(rasts):
             last = v == len(rasts) - 1
             if factored:
-                fx.arm(v)                                   # colour gradients of view v go to their all-gather slot
+                fx.arm(v, sh_degree=D)                      # colour gradients of view v go to their all-gather slot; the gather starts inside the backward
             elif multi and len(rasts) == 1:
                 # gradients are born in the flat all-reduce buffer; the SH ranges are reduced while the backward runs
                 bucket.arm(a.overlap_chunks)
@@ -491,7 +491,7 @@ def main():
         if multi and timed:
             e0 = torch.cuda.Event(enable_timing=True); e0.record()
         if factored:
-            fx.exchange(campos_all)
+            fx.exchange(campos_all, sh_degree=D)
         else:
             parallel.allreduce_gaussian_grads(bucket)      # the tail of the one logical reduction (no-op at N=1)
         if multi and timed:

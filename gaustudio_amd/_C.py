@@ -125,7 +125,10 @@ def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None, colors_out=None):
     (0 / empty = any); see gaustudio_amd/parallel.py.  With sh_chunks > 1 and a hook, the SH stage of that backward
     runs in Gaussian ranges and hook(c, g0, g1) is called after range c has been enqueued.  colors_out [P,3]: that
     backward runs its SH stage in the factored form -- the clamp-masked colour gradient goes there and the returned
-    dL_dsh is None (outs may then be [] or five tensors whose second is ignored).  [] without colors_out disarms."""
+    dL_dsh is None (outs may then be [] or five tensors whose second is ignored); a `hook` given together with colors_out is
+    called (no arguments) once the geometry stage -- which then already leaves the masked colour gradient in colors_out -- has
+    been enqueued and BEFORE the SH-direction stage: the caller starts the all-gather of the slot there.
+    [] without colors_out disarms."""
     native().set_grad_arena(list(outs), [int(k) for k in keys], int(sh_chunks), hook, colors_out)
 
 

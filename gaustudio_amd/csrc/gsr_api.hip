@@ -706,6 +706,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	if (!dL_dpix || !dL_dpix_depth || !dL_dpix_median_depth || !dL_dpix_final_opacity)
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL upstream gradient", __FILE__, __LINE__);
 	const bool sh_colors = (parts & GSR_BWD_PART_SH_COLORS) != 0;
+	const int colors_early = ((parts & GSR_BWD_PART_COLORS_EARLY) && sh_colors) ? GSR_PART_COLORS_EARLY : 0;
 	if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || (!dL_dcov3D && cov3D_precomp) || !dL_dscale || !dL_drot ||
 	    (M > 0 && !dL_dsh && !sh_colors))
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL output", __FILE__, __LINE__);
@@ -740,7 +741,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	if (!(parts & GSR_BWD_PART_MAIN)) {
 		// SH stage alone over a Gaussian range (the caller interleaves a collective per chunk, gaustudio_amd/parallel.py)
 		launch_preprocess_bwd(a, cam, recs, goff, rows, nullptr, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
-		                      dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_SH | (sh_colors ? GSR_PART_SH_COLORS : 0), sh_g0, sh_g1, s);
+		                      dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_SH | (sh_colors ? GSR_PART_SH_COLORS : 0) | colors_early, sh_g0, sh_g1, s);
 		STAGE_CHECK("preprocess_bwd_sh", debug, s);
 		return GSR_OK;
 	}
@@ -800,7 +801,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	tm.mark();
 	launch_preprocess_bwd(a, cam, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
 	                      dL_dsh_rest, dL_dscale, dL_drot,
-	                      GSR_PART_GEOM | ((parts & GSR_BWD_PART_SH) ? GSR_PART_SH : 0) | (sh_colors ? GSR_PART_SH_COLORS : 0),
+	                      GSR_PART_GEOM | ((parts & GSR_BWD_PART_SH) ? GSR_PART_SH : 0) | (sh_colors ? GSR_PART_SH_COLORS : 0) | colors_early,
 	                      sh_g0, sh_g1, s);
 	STAGE_CHECK("preprocess_bwd", debug, s);
 	tm.mark();

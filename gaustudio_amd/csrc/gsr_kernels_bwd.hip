@@ -933,7 +933,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const uint32_t* __restrict__ goff, const float* __restrict__ rows, const uint8_t* __restrict__ row_flags,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+    float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int mask_colors)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	float a_[GSR_ROW_STRIDE];
@@ -991,9 +991,19 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 	dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
 	// f1: d/d(raw opacity) = dL_dopacity * op * (1 - op), op = sigmoid(raw) kept in the record
 	dL_dopacity[idx] = (vis && (act & GSR_ACT_OPACITY_SIGMOID)) ? a_[5] * recs[idx].q1.y * (1.f - recs[idx].q1.y) : a_[5];
-	dL_dcolor[3 * (size_t)idx] = a_[6];
-	dL_dcolor[3 * (size_t)idx + 1] = a_[7];
-	dL_dcolor[3 * (size_t)idx + 2] = a_[8];
+	if (mask_colors && vis) {
+		// GSR_PART_COLORS_EARLY (factored multi-GPU exchange): leave dRGB -- the colour gradient with the clamped channels zeroed,
+		// the very product gs_sh_backward forms (backward.cu:35-40) -- here already, so that the all-gather of this view's colour
+		// slot can start before the SH-direction stage has read 192 B of coefficients per Gaussian
+		const uint32_t cl = recs[idx].q3.z;
+		dL_dcolor[3 * (size_t)idx] = a_[6] * ((cl & 1u) ? 0.f : 1.f);
+		dL_dcolor[3 * (size_t)idx + 1] = a_[7] * (((cl >> 1) & 1u) ? 0.f : 1.f);
+		dL_dcolor[3 * (size_t)idx + 2] = a_[8] * (((cl >> 2) & 1u) ? 0.f : 1.f);
+	} else {
+		dL_dcolor[3 * (size_t)idx] = a_[6];
+		dL_dcolor[3 * (size_t)idx + 1] = a_[7];
+		dL_dcolor[3 * (size_t)idx + 2] = a_[8];
+	}
 
 	float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float dscale[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1261,7 +1271,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
     int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, const GsRec* __restrict__ recs,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dsh_rest)
+    float* __restrict__ dL_dsh_rest, int write_colors)
 {
 	extern __shared__ __attribute__((aligned(16))) float sh_slab[];
 	constexpr int NC = (D + 1) * (D + 1);
@@ -1295,8 +1305,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
 #define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
 		if (COLORS) {
-			float* dcol = const_cast<float*>(dL_dcolor) + 3 * (size_t)idx;
-			dcol[0] = dRGB[0]; dcol[1] = dRGB[1]; dcol[2] = dRGB[2];
+			if (write_colors) {   // (0: the geometry stage left dRGB already and a collective may be reading the slot by now)
+				float* dcol = const_cast<float*>(dL_dcolor) + 3 * (size_t)idx;
+				dcol[0] = dRGB[0]; dcol[1] = dRGB[1]; dcol[2] = dRGB[2];
+			}
 		} else if (SPLIT) {
 			float* ddc = dL_dsh + 3 * (size_t)idx;
 			ddc[0] = OSH(0); ddc[1] = OSH(1); ddc[2] = OSH(2);
@@ -1378,7 +1390,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
     int g_base, int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dsh_rest)
+    float* __restrict__ dL_dsh_rest, int write_colors)
 {
 	const int idx = g_base + blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
@@ -1399,8 +1411,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 		}
 		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
 		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
-		float* dcol = const_cast<float*>(dL_dcolor) + 3 * (size_t)idx;
-		dcol[0] = dRGB[0]; dcol[1] = dRGB[1]; dcol[2] = dRGB[2];
+		if (write_colors) {
+			float* dcol = const_cast<float*>(dL_dcolor) + 3 * (size_t)idx;
+			dcol[0] = dRGB[0]; dcol[1] = dRGB[1]; dcol[2] = dRGB[2];
+		}
 	} else if (SPLIT) {
 		// split storage (f1): dL_dsh -> dL_df_dc [P,1,3], dL_dsh_rest -> dL_df_rest [P,M-1,3]
 		float* ddc = dL_dsh + 3 * (size_t)idx;
@@ -1474,7 +1488,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, FL>), grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, a.scales, \
 	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
 	                   h_y, sh_vec4, a.act, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
-	                   dL_drot)
+	                   dL_drot, (parts & GSR_PART_COLORS_EARLY) ? 1 : 0)
 	if (parts & GSR_PART_GEOM) {
 		if (row_flags != nullptr) { GSR_LAUNCH_PB(0, true); } else { GSR_LAUNCH_PB(0, false); }
 	}
@@ -1485,11 +1499,12 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	sh_g1 = min(a.P, sh_g1);
 	if (sh_g1 <= sh_g0) return;
 	const int sh_end = sh_g1;
+	const int write_colors = (parts & GSR_PART_COLORS_EARLY) ? 0 : 1;
 	grid = dim3((sh_g1 - sh_g0 + 255) / 256);
 	if (a.shs != nullptr) {
 #define GSR_LAUNCH_SH(DEG)                                                                                       \
 	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT, COLORS>), grid, block, 0, s, sh_g0, sh_end, a.M, a.means3D, a.radii, a.shs, \
-	                   a.shs_rest, cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
+	                   a.shs_rest, cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
 #define GSR_LAUNCH_SH_D()                        \
 		switch (a.D) {                            \
 			case 0: GSR_LAUNCH_SH(0); break;      \
@@ -1508,7 +1523,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 #define GSR_LAUNCH_SHC(DEG, SPL, COL)                                                                             \
 	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL, COL>), grid, block,                                  \
 	                   sizeof(float) * 256 * gs_row_stride<gs_sh_row_floats(DEG, SPL)>(), s, sh_g0, sh_end, \
-	                   a.means3D, a.radii, a.shs, a.shs_rest, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest)
+	                   a.means3D, a.radii, a.shs, a.shs_rest, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
 		// stored rows wider than the active degree ([P,16,3] storage while the degree is still being raised): the wide kernel
 		const bool wide = !colors && !split && a.M == 16 && NCd < 16 && (sh_g0 % 256 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
 #define GSR_LAUNCH_SHW(DEG)                                                                                            \

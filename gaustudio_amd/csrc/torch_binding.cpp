@@ -85,7 +85,9 @@ struct GradArena {
 	py::object hook;             // None or callable
 	// factored gradient exchange (gaustudio_amd/parallel.py FactoredGradExchange): when defined, that backward runs its
 	// SH stage in the GSR_BWD_PART_SH_COLORS form -- the clamp-masked colour gradient [P,3] is written HERE (a slot of
-	// the all-gather buffer) and no dL_dsh is produced (the binding returns None for it)
+	// the all-gather buffer) and no dL_dsh is produced (the binding returns None for it).  With a hook, the backward runs as
+	// two calls (GSR_BWD_PART_COLORS_EARLY): the geometry stage already leaves dRGB in the slot, `hook()` is called -- the
+	// caller starts the all-gather of this view's slot -- and only then the SH-direction stage is enqueued
 	torch::Tensor colors_out;
 };
 GradArena& g_arena = *new GradArena();   // never destroyed: holds a Python object, must not outlive the interpreter's teardown
@@ -333,7 +335,11 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 			if (rc < 0) fail(rc);
 		};
 		const bool chunked = in_arena && !factored && arena.sh_chunks > 1 && !arena.hook.is_none() && M > 0 && sh.numel() != 0;
-		if (factored) {
+		if (factored && !arena.hook.is_none()) {
+			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY, 0, 0);
+			arena.hook();
+			run(GSR_BWD_PART_SH | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY, 0, P);
+		} else if (factored) {
 			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH | GSR_BWD_PART_SH_COLORS, 0, P);
 		} else if (!chunked) {
 			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH, 0, P);

@@ -217,23 +217,34 @@ class FactoredGradExchange:
     the view's camera centre -- both known on every rank.  So instead of all-reducing (D+1)^2 x 12 B per Gaussian, every
     view's dRGB[P,3] is ALL-GATHERED (12 B per Gaussian and view) and each rank rebuilds
     sum_views basis (x) dRGB itself (`gsr_sh_grad_from_colors`, same arithmetic as the per-view SH backward, views added
-    in ascending order: bit-identical to accumulating the views on one device); only the geometry block
+    in a fixed order: bit-identical to accumulating the views on one device in that order); only the geometry block
     [means3D 3 | opacity 1 | scales 3 | rotations 4] = 44 B per Gaussian is all-reduced.  At 8 ranks x 1 view a rank
     moves 2 x 7/8 x 44 + 7 x 12 = 161 B per Gaussian instead of 2 x 7/8 x 236 = 413 B, independent of the SH degree.
 
-        fx = FactoredGradExchange(params_by_role, views_per_rank=V, sh_degree=D)
+        fx = FactoredGradExchange(params_by_role, views_per_rank=V)
         for v, cam in enumerate(my_views):
-            fx.arm(v); out = rasterizer_of(cam)(...); loss(out).backward()     # gradients accumulate as usual, no dL_dsh
-        fx.exchange(campos_of_all_views)      # [world * V, 3], global view order: rank-major
+            fx.arm(v, sh_degree=D); out = rasterizer_of(cam)(...); loss(out).backward()   # gradients accumulate as usual, no dL_dsh
+        fx.exchange(campos_of_all_views, sh_degree=D)      # [world * V, 3], global view order: rank-major
         # now p.grad of all five parameters holds the sum over all world * V views
 
+    EARLY, PER-VIEW all-gather (round 4).  The colour slots are laid out view-major, colors[V, world, P, 3], so that local
+    view v of all ranks is one contiguous all-gather.  The backward armed for view v calls back as soon as its geometry
+    stage is enqueued -- that stage already leaves dRGB in the slot (GSR_BWD_PART_COLORS_EARLY) -- and the all-gather of
+    view v starts THERE: before the SH-direction stage of that backward, and, at V > 1, while the later views of the step
+    are still being rendered ((V - 1) / V of the colour traffic is hidden behind them).  The order in which the views are
+    added is the memory order (local view index major, rank minor): `view_order()`.
+
+    `sh_degree` is the ACTIVE degree of the step's renders (it changes during training: the usual schedule raises it every
+    1000 iterations) -- given per step to arm() / exchange(); all views of a step must use the same one, and a mismatch
+    raises instead of silently rebuilding gradients for coefficients the renders did not use.
+
     `compact=True` additionally exchanges only the Gaussians that are visible (radii > 0 <=> a non-zero colour OR
-    geometry gradient row) in at least one view of the step: one bit-mask all-reduce, then compacted buffers; worth it
-    for real scenes where a view touches a fraction of the Gaussians (it costs a host synchronisation for the row count).
+    geometry gradient row) in at least one view of the step: one bit-mask all-reduce, then compacted buffers (it costs a
+    host synchronisation for the row count, and the mask must be agreed first: no early all-gather in this form).
     Runs on CPU tensors with the "gloo" backend when `sh_from_colors` is given (tests; the product kernel is HIP only)."""
 
-    def __init__(self, params_by_role: dict, views_per_rank: int = 1, sh_degree: int = 3, group=None, compact: bool = False,
-                 sh_from_colors=None):
+    def __init__(self, params_by_role: dict, views_per_rank: int = 1, sh_degree: Optional[int] = None, group=None, compact: bool = False,
+                 sh_from_colors=None, early: bool = True):
         if set(params_by_role) != set(ARENA_ROLES):
             raise ValueError(f"params_by_role must name exactly {ARENA_ROLES}")
         self.p = dict(params_by_role)
@@ -241,8 +252,9 @@ class FactoredGradExchange:
         self.world = dist.get_world_size(group) if _multi(group) else 1
         self.rank = dist.get_rank(group) if _multi(group) else 0
         self.V = int(views_per_rank)
-        self.D = int(sh_degree)
+        self.D = None if sh_degree is None else int(sh_degree)      # default for steps that do not name their degree
         self.compact = bool(compact)
+        self.early = bool(early) and not self.compact
         self._sh_from_colors = sh_from_colors
         means = self.p["means3D"]
         dev, self.P = means.device, means.shape[0]
@@ -252,9 +264,12 @@ class FactoredGradExchange:
         self.M = self.p["shs"].shape[1]
         self._geo_sizes = [self.p[r].numel() for r in GEOMETRY_ROLES]
         self.geo = torch.zeros(sum(self._geo_sizes), dtype=torch.float32, device=dev)
-        self.colors = torch.zeros((self.world * self.V, self.P, 3), dtype=torch.float32, device=dev)
+        self.colors = torch.zeros((self.V, self.world, self.P, 3), dtype=torch.float32, device=dev)     # view-major
         self.sh_grad = torch.empty((self.P, self.M, 3), dtype=torch.float32, device=dev)
-        self.stats = {"steps": 0, "rows_exchanged": 0}
+        self.stats = {"steps": 0, "rows_exchanged": 0, "early_allgathers": 0}
+        self._works = {}          # local view -> work handle of its early all-gather
+        self._step_degrees = []   # degrees the step's armed backwards were rendered with
+        self._order = torch.tensor(self.view_order(), dtype=torch.long, device=dev)
 
     def geo_views(self):
         out, o = {}, 0
@@ -262,6 +277,10 @@ class FactoredGradExchange:
             out[r] = self.geo[o:o + n].view_as(self.p[r])
             o += n
         return out
+
+    def view_order(self):
+        """Global view ids (rank * V + local view) in the order the rebuilt SH gradient adds them = memory order of `colors`."""
+        return [r * self.V + v for v in range(self.V) for r in range(self.world)]
 
     # wire sizes of one step (per rank): what goes out and what comes in
     @property
@@ -279,26 +298,59 @@ class FactoredGradExchange:
         return {"payload_bytes_per_rank": int(sent), "allreduce_bytes": int(rows * 44), "allgather_bytes_sent": int(rows * 12 * self.V),
                 "allgather_bytes_received": int(rows * 12 * self.V * (self.world - 1)),
                 "dense_payload_bytes_per_rank": self.P * (self.M * 3 + 11) * 4, "rows_per_step": rows, "rows_total": self.P,
-                "compacted": self.compact}
+                "compacted": self.compact, "early_allgathers_per_step": self.stats["early_allgathers"] / n}
 
-    def arm(self, v: int):
-        """Before the forward + backward of this rank's local view v: its colour gradients go to slot rank * V + v of the
+    def arm(self, v: int, sh_degree: Optional[int] = None):
+        """Before the forward + backward of this rank's local view v: its colour gradients go to slot [v, rank] of the
         all-gather buffer.  The first view's geometry gradients are born in the all-reduce buffer when no p.grad exists
-        yet; later views accumulate into them through autograd as usual."""
+        yet; later views accumulate into them through autograd as usual.  sh_degree: the settings' sh_degree of this view's
+        render (checked against the step's other views and against exchange())."""
         from . import _C
-        slot = self.colors[self.rank * self.V + v]
+        if sh_degree is not None:
+            self._step_degrees.append(int(sh_degree))
+        slot = self.colors[v, self.rank]
         fresh = all(self.p[r].grad is None for r in ARENA_ROLES)
         outs = []
         if v == 0 and fresh and self.geo.is_cuda:
             g = self.geo_views()
             outs = [g["means3D"], self.sh_grad, g["opacities"], g["scales"], g["rotations"]]     # slot 1 (dL_dsh) is ignored
         keys = [int(self.p[r].data_ptr()) for r in _KEY_ROLES]
-        _C.set_grad_arena(outs, keys, 1, None, colors_out=slot)
+        hook = None
+        if self.early and _multi(self.group):
+            hook = lambda v=v: self._on_colors_ready(v)
+        _C.set_grad_arena(outs, keys, 1, hook, colors_out=slot)
 
-    def exchange(self, campos_all: torch.Tensor):
-        """campos_all [world * V, 3]: the camera centres of ALL views of this step in global order (rank-major) -- every
-        rank knows the step's camera list.  Afterwards p.grad of all five parameters is the sum over all views."""
+    def _on_colors_ready(self, v: int):
+        """Called by the backward armed for local view v (csrc/torch_binding.cpp) right after its geometry stage has been
+        enqueued: slot [v, rank] holds the view's final dRGB.  The all-gather of view v over all ranks is stream-ordered
+        behind that kernel and runs on the communicator's stream while the backward's SH-direction stage -- and the
+        step's remaining views -- compute."""
+        if v in self._works:
+            return
+        self._works[v] = _all_gather_in_place(self.colors[v], self.rank, 1, self.group)
+        self.stats["early_allgathers"] += 1
+
+    def _step_degree(self, sh_degree):
+        degs = set(self._step_degrees)
+        self._step_degrees = []
+        if len(degs) > 1:
+            raise ValueError(f"FactoredGradExchange: the views of one step were rendered with different SH degrees {sorted(degs)}")
+        if sh_degree is not None and degs and int(sh_degree) not in degs:
+            raise ValueError(f"FactoredGradExchange.exchange(sh_degree={sh_degree}) but the step's backwards were armed with degree {sorted(degs)[0]}")
+        D = int(sh_degree) if sh_degree is not None else (degs.pop() if degs else self.D)
+        if D is None:
+            raise ValueError("FactoredGradExchange: the active SH degree of the step is unknown -- pass sh_degree to arm() / exchange() "
+                             "(or a default to the constructor)")
+        if (D + 1) ** 2 > self.M:
+            raise ValueError(f"SH degree {D} does not fit the {self.M} stored coefficients")
+        return D
+
+    def exchange(self, campos_all: torch.Tensor, sh_degree: Optional[int] = None):
+        """campos_all [world * V, 3]: the camera centres of ALL views of this step in global order (rank-major: view v of
+        rank r is row r * V + v) -- every rank knows the step's camera list.  Afterwards p.grad of all five parameters is
+        the sum over all views.  sh_degree: the active degree the step's views were rendered with (see the class docstring)."""
         P, V, W = self.P, self.V, self.world
+        D = self._step_degree(sh_degree)
         views = self.geo_views()
         for r in GEOMETRY_ROLES:                              # pack what autograd did not put there itself
             p, v = self.p[r], views[r]
@@ -307,9 +359,10 @@ class FactoredGradExchange:
             elif not (p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape and p.grad.is_contiguous()):
                 v.copy_(p.grad)
         multi = _multi(self.group)
-        mine = self.colors[self.rank * V:(self.rank + 1) * V]
         rows = None
+        w2 = None
         if multi and self.compact:
+            mine = self.colors[:, self.rank]                  # [V, P, 3]
             # rows with a non-zero gradient in ANY view of ANY rank (a culled Gaussian's rows are exactly zero): every one of
             # the 11 geometry floats and the colour slots counts, so that no partial row is left out of the sum
             live = mine.abs().amax(dim=(0, 2)) > 0
@@ -320,14 +373,16 @@ class FactoredGradExchange:
             rows = torch.nonzero(mask, as_tuple=False).flatten()
             K = rows.numel()                                  # host synchronisation: the buffers below are sized by it
             geo_rows = torch.cat([views[r].reshape(P, -1)[rows] for r in GEOMETRY_ROLES], dim=1).contiguous()       # [K,11]
-            col = torch.zeros((W * V, K, 3), dtype=torch.float32, device=self.geo.device)
-            col[self.rank * V:(self.rank + 1) * V] = mine[:, rows]
-            w1 = _all_gather_in_place(col, self.rank, V, self.group)
+            col = torch.zeros((V, W, K, 3), dtype=torch.float32, device=self.geo.device)
+            col[:, self.rank] = mine[:, rows]
+            w1s = [_all_gather_in_place(col[v], self.rank, 1, self.group) for v in range(V)]
             w2 = dist.all_reduce(geo_rows, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            w1.wait()
+            for w in w1s:
+                w.wait()
             self.colors.zero_()
-            self.colors[:, rows] = col
+            self.colors[:, :, rows] = col
             w2.wait()
+            w2 = None
             o = 0
             for r in GEOMETRY_ROLES:
                 n = views[r].reshape(P, -1).shape[1]
@@ -335,16 +390,23 @@ class FactoredGradExchange:
                 o += n
             self.stats["rows_exchanged"] += K
         elif multi:
-            w1 = _all_gather_in_place(self.colors, self.rank, V, self.group)
+            # views whose all-gather did not start from inside their backward (early=False, a CPU run, an arena that autograd
+            # did not consume) start now; then the geometry all-reduce; the colour works are waited for in view order
+            for v in range(V):
+                if v not in self._works:
+                    self._works[v] = _all_gather_in_place(self.colors[v], self.rank, 1, self.group)
             w2 = dist.all_reduce(self.geo, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            w1.wait()
+            for v in range(V):
+                self._works[v].wait()
+        self._works = {}
         # the SH gradient of the whole step from every view's colour gradient (runs while the geometry all-reduce is in flight)
         fn = self._sh_from_colors
         if fn is None:
             from . import _C
             fn = _C.sh_grad_from_colors
-        fn(self.p["means3D"].detach(), campos_all.to(self.geo.device, torch.float32).contiguous(), self.colors, self.D, self.sh_grad)
-        if multi and not self.compact:
+        campos = campos_all.detach().to(self.geo.device, torch.float32)[self._order].contiguous()      # (no host round trip)
+        fn(self.p["means3D"].detach(), campos, self.colors.view(V * W, P, 3), D, self.sh_grad)
+        if w2 is not None:
             w2.wait()
         for r in GEOMETRY_ROLES:
             self.p[r].grad = views[r]

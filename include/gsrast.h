@@ -161,6 +161,12 @@ int gsr_backward(int P, int D, int M, int R,
  * in place with dRGB, the clamp-masked colour gradient the SH basis is multiplied with (backward.cu:35-40); dL_dmean3D
  * gets its SH term as usual.  SH colours in one [P,M,3] tensor only. */
 #define GSR_BWD_PART_SH_COLORS 4
+/* with GSR_BWD_PART_SH_COLORS, on every call of one backward (gsr_backward_ex only): the GEOMETRY stage of GSR_BWD_PART_MAIN
+ * already leaves dRGB in dL_dcolor (the clamp mask is in the forward's record: it needs no SH coefficients), and the SH stage
+ * does not write dL_dcolor again.  A caller that runs MAIN and SH as two calls can start the all-gather of this view's colour
+ * gradients between them -- before the SH-direction stage has read 192 B of coefficients per Gaussian -- without a race on
+ * the slot.  Same bits as the one-call form. */
+#define GSR_BWD_PART_COLORS_EARLY 8
 int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int R, const float* background, int width,
                        int height, const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                        float scale_modifier, const float* rotations, const float* cov3D_precomp, float tan_fovx,

@@ -178,16 +178,31 @@ def _worker_factored(rank, world, port, out_dir, V, compact):
         views, means, campos, (P, M) = _factored_inputs(world, V)
         shapes = dict(means3D=(P, 3), shs=(P, M, 3), opacities=(P, 1), scales=(P, 3), rotations=(P, 4))
         params = {k: (means.clone() if k == "means3D" else torch.zeros(shp)).requires_grad_(True) for k, shp in shapes.items()}
-        fx = parallel.FactoredGradExchange(params, views_per_rank=V, sh_degree=3, compact=compact, sh_from_colors=_sh_from_colors_torch)
-        assert fx.world == world and fx.colors.shape == (world * V, P, 3)
+        fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact, sh_from_colors=_sh_from_colors_torch)
+        assert fx.world == world and fx.colors.shape == (V, world, P, 3)
+        assert fx.view_order() == [r * V + v for v in range(V) for r in range(world)]
         # what the armed backwards of this rank's V views leave behind: colour gradients in their slots, geometry
-        # gradients accumulated in p.grad
+        # gradients accumulated in p.grad; the early hook (called by the real backward right after its geometry stage,
+        # csrc/torch_binding.cpp) is driven by hand here: view v's all-gather starts before view v + 1 is "rendered"
         for v in range(V):
             gv = views[rank * V + v]
-            fx.colors[rank * V + v].copy_(gv["colors"])
+            fx.colors[v, rank].copy_(gv["colors"])
+            if not compact:
+                fx._on_colors_ready(v)
             for k in parallel.GEOMETRY_ROLES:
                 params[k].grad = gv[k].clone() if params[k].grad is None else params[k].grad + gv[k]
-        fx.exchange(campos)
+        if not compact:
+            assert fx.stats["early_allgathers"] == V and sorted(fx._works) == list(range(V))
+        if rank == 0:          # a step armed with one degree and exchanged with another is refused
+            fx._step_degrees = [2]
+            with pytest.raises(ValueError, match="armed with degree 2"):
+                fx._step_degree(3)
+            fx._step_degrees = [1, 3]
+            with pytest.raises(ValueError, match="different SH degrees"):
+                fx._step_degree(None)
+            with pytest.raises(ValueError, match="unknown"):
+                fx._step_degree(None)
+        fx.exchange(campos, sh_degree=3)
         pay = fx.payload()
         assert pay["dense_payload_bytes_per_rank"] == P * 59 * 4
         if not compact:
@@ -208,7 +223,8 @@ def test_factored_exchange_equals_dense_accumulation(tmp_path, V, compact):
     mp.spawn(_worker_factored, args=(world, _free_port(), str(tmp_path), V, compact), nprocs=world, join=True)
     views, means, campos, (P, M) = _factored_inputs(world, V)
     want = {k: sum(v[k] for v in views) for k in parallel.GEOMETRY_ROLES}
-    want["shs"] = _sh_from_colors_torch(means, campos, torch.stack([v["colors"] for v in views]), 3, torch.zeros(P, M, 3))
+    order = [r * V + v for v in range(V) for r in range(world)]          # FactoredGradExchange.view_order(): local view major, rank minor
+    want["shs"] = _sh_from_colors_torch(means, campos[order], torch.stack([views[g]["colors"] for g in order]), 3, torch.zeros(P, M, 3))
     got = [torch.load(os.path.join(tmp_path, f"fx_rank{r}.pt")) for r in range(world)]
     for k in want:
         assert torch.equal(got[0][k], got[1][k]), k                           # replicated result
@@ -314,12 +330,12 @@ def _accumulate_views_dense(sc, cams, dev, D=3):
 def _factored_step(sc, my_cams, all_cams, dev, V, D=3, compact=False):
     from gaustudio_amd import GaussianRasterizationSettings, GaussianRasterizer
     params = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in KEYS}
-    fx = parallel.FactoredGradExchange(params, views_per_rank=V, sh_degree=D, compact=compact)
+    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact)
     m2 = torch.zeros_like(params["means3D"])
     for v, cam in enumerate(my_cams):
         rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
                                            cam.viewmatrix.to(dev), cam.projmatrix.to(dev), D, cam.campos.to(dev), False, False)
-        fx.arm(v)
+        fx.arm(v, sh_degree=D)
         out = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=m2, opacities=params["opacities"], shs=params["shs"],
                                      scales=params["scales"], rotations=params["rotations"])
         g = [t.to(dev) for t in scenes.make_output_grads(cam, seed=5)]
@@ -328,7 +344,9 @@ def _factored_step(sc, my_cams, all_cams, dev, V, D=3, compact=False):
     if V >= 1 and fx.geo.is_cuda:
         gv = fx.geo_views()
         assert all(params[r].grad.data_ptr() == gv[r].data_ptr() for r in parallel.GEOMETRY_ROLES)   # born in the all-reduce buffer
-    fx.exchange(torch.stack([c.campos for c in all_cams]).to(dev))
+    if parallel._multi(None) and not compact:
+        assert fx.stats["early_allgathers"] == V       # every view's all-gather started from inside its backward
+    fx.exchange(torch.stack([c.campos for c in all_cams]).to(dev), sh_degree=D)
     return {k: p.grad.cpu() for k, p in params.items()}, fx
 
 
