@@ -456,7 +456,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 #define GSR_BWQ_BATCH 128    // instances staged per round (64 or 128): the four waves and their quarters re-synchronise
                              // once per round -- census at C3: 30.1 k workgroup steps at 64, 28.3 k at 128 (20.9 k ideal)
 #endif
-#define GSR_BWQ_HALVES (GSR_BWQ_BATCH / 64)
+#define GSR_BWQ_HALVES ((GSR_BWQ_BATCH + 63) / 64)
 #define GSR_BWQ_LIST (GSR_BWQ_BATCH + 8)   // bytes per quarter list: the entries + 8 sentinels
 #define GSR_BWQ_SENT GSR_BWQ_BATCH         // batch index of the sentinel record (opacity 0)
 #define GSR_BWQ_QSTRIDE 66   // float2 per quarter in the slab: 4 steps x 16 pixels + 2 pad (16-B aligned, banks shifted)
@@ -481,8 +481,11 @@ __device__ unsigned long long g_bwd_phase_ticks[GSR_TM_SLOTS * 12];
 #define TM(k)
 #define TM_END
 #endif
+#ifndef GSR_BWQ_WAVES
+#define GSR_BWQ_WAVES 4      // waves per SIMD the register allocation is held to (experiment: 5 with GSR_BWQ_BATCH=96)
+#endif
 template <bool FLAGS, bool TSEL, bool FX>
-__global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void composite_bwd_quarter_kernel(
+__global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_BWQ_WAVES, GSR_BWQ_WAVES))) void composite_bwd_quarter_kernel(
     int T, int chunk, int gx, int W, int H, const GsBg bgv, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ med_pos,
@@ -698,6 +701,31 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			GSR_APPEND(2, c2)
 			GSR_APPEND(3, c3)
 		}
+#ifdef GSR_BWQ_LIST_TWICE   // sensitivity experiment: the list building once more (same lists again) = its cost in situ
+		c0 = c1 = c2 = c3 = 0;
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int h = 0; h < GSR_BWQ_HALVES; h++) {
+			const int jl = lane + 64 * h;
+			if (64 * h >= cnt) break;
+			uint32_t mk = 0;
+			if (jl < cnt) {
+				if (have_qmask) {
+					const uint32_t m16 = (uint32_t)__builtin_nontemporal_load(&s_qmask[jl]) >> (8 * (wv >> 1) + 2 * (wv & 1));
+					mk = (m16 & 3u) | ((m16 >> 2) & 12u);
+				} else {
+					mk = gs_quarter_mask<2>(sA[jl], sB[jl], fbx, fby, 0xfu);
+				}
+				const int pos = top - 1 - jl;
+				mk &= (pos < qm0 ? 1u : 0u) | (pos < qm1 ? 2u : 0u) | (pos < qm2 ? 4u : 0u) | (pos < qm3 ? 8u : 0u);
+			}
+			asm volatile("" : "+v"(mk));
+			GSR_APPEND(0, c0)
+			GSR_APPEND(1, c1)
+			GSR_APPEND(2, c2)
+			GSR_APPEND(3, c3)
+		}
+#endif
 #undef GSR_APPEND
 		__builtin_amdgcn_wave_barrier();
 		TM(8)
