@@ -51,7 +51,12 @@ WORKLOADS = {
     # per-GPU shares of the multi-GPU configurations (one view per GPU)
     "C4": (5_000_000, 1297, 840, 3, "C4 share: 5M synthetic Gaussians (garden stand-in), one 1297x840 view, SH degree 3, fwd+bwd"),
     "C5": (2_500_000, 3840, 2160, 3, "C5 share: 2.5M synthetic Gaussians (Truck stand-in), one 3840x2160 view, SH degree 3, fwd+bwd"),
+    # a NON-UNIFORM scene: C2's size, the structure of a trained capture -- clustered Gaussians in a ball seen by
+    # an inward ring camera, > 20 % empty tiles, a 1 % tail of 50-60 px splats; per-tile lists p50 ~ 10, p99 ~ 11 k, max ~ 58 k
+    "C2-clustered": (300_000, 800, 800, 3, "C2-clustered: 300k Gaussians in 48 clusters inside a ball (Zipf populations, 1 % of the splats with sigma "
+                                           "50-60 px), inward ring camera at 11 units, 800x800, SH degree 3, fwd+bwd"),
 }
+CLUSTERED = {"C2-clustered": dict(cam_distance=11.0, ring=5, view=1)}
 
 
 def rank_camera(scenes, W, H, rank, world):
@@ -159,7 +164,7 @@ def list_histogram(ranges):
     n = (ranges[:, 1] - ranges[:, 0]).float()
     q = torch.quantile(n, torch.tensor([0.5, 0.9, 0.99], device=n.device)).tolist()
     return {"mean": round(float(n.mean()), 1), "p50": int(q[0]), "p90": int(q[1]), "p99": int(q[2]), "max": int(n.max()),
-            "empty_tiles": int((n == 0).sum())}
+            "empty_tiles": int((n == 0).sum()), "max_over_mean": round(float(n.max() / n.mean().clamp(min=1e-9)), 2)}
 
 
 def reference_ab(sc, cam, D, grads_cpu, dev, steps=5):
@@ -429,10 +434,16 @@ def main():
 
     P, W, H, D, desc = WORKLOADS[a.workload]
     V = max(1, a.views_per_rank)
-    cam0 = scenes.make_camera(W, H)
-    sc = scenes.make_scene(P, cam0, seed=0)                 # identical on every rank (replicated parameters)
-    # this rank's V cameras of the world * V views of a step (view v of rank r = global view r * V + v)
-    all_cams = [rank_camera(scenes, W, H, g, world * V) for g in range(world * V)]
+    if a.workload in CLUSTERED:
+        c = CLUSTERED[a.workload]
+        sc = scenes.make_clustered_scene(P, W, cam_distance=c["cam_distance"], seed=0)
+        ring = scenes.ring_cameras(max(c["ring"], world * V + c["view"]), W, H, radius=c["cam_distance"])
+        all_cams = [ring[(c["view"] + g) % len(ring)] for g in range(world * V)]
+    else:
+        cam0 = scenes.make_camera(W, H)
+        sc = scenes.make_scene(P, cam0, seed=0)                 # identical on every rank (replicated parameters)
+        # this rank's V cameras of the world * V views of a step (view v of rank r = global view r * V + v)
+        all_cams = [rank_camera(scenes, W, H, g, world * V) for g in range(world * V)]
     cams = all_cams[rank * V:(rank + 1) * V]
     cam = cams[0]
     grads_cpu = scenes.make_output_grads(cam, seed=1)

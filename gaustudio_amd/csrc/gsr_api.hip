@@ -552,8 +552,9 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	DevState& ds = dev_state();
 	const bool nocull = ro.cull == 0;
 	const bool wave_lists = ro.fwd_variant == 1;
-	auto launch_rest = [&](uint32_t cap, bool with_long) -> int {
-		const BinLayout bl((size_t)cap, with_long);
+	auto launch_rest = [&](uint32_t cap, int long_level) -> int {
+		const bool with_long = long_level > 0;
+		const BinLayout bl((size_t)cap, with_long, il.T);
 		char* bin = binning_alloc(binning_ctx, bl.total);
 		if (!bin) return fail(GSR_ERR_ALLOC, "gsr_forward: binning allocator returned NULL", __FILE__, __LINE__);
 		uint64_t* keys = reinterpret_cast<uint64_t*>(bin + bl.keys);
@@ -575,19 +576,20 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		}
 		tm.mark();
 		if (cap > 0) {
-			launch_tile_sort(il.T, true, with_long, ranges, keys, keys2, point_list, ctl, cap, s);
+			launch_tile_sort(il.T, true, long_level, ranges, keys, keys2, point_list, bin + bl.queue, (size_t)cap, ctl, cap, s);
 			STAGE_CHECK("tile_sort", debug, s);
 		}
 		tm.mark();
 		launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
-		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap, with_long ? 0xffffffffu : GSR_SORT_LDS_MAX, nocull, wave_lists, ro.fast_exp != 0, s);
+		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap,
+		                     long_level >= 2 ? 0xffffffffu : (long_level == 1 ? GSR_SORT_GIANT : GSR_SORT_LDS_MAX), nocull, wave_lists, ro.fast_exp != 0, s);
 		STAGE_CHECK("composite_fwd", debug, s);
 		tm.mark();
 		return 0;
 	};
 
 	const uint32_t cap0 = ds.cap.load();
-	const bool long0 = ds.long_lists.load() != 0;
+	const int long0 = ds.long_lists.load();   // sort regime of the previous frame: 0 / 1 (lists > 1024 keys) / 2 (> GSR_SORT_GIANT keys)
 	const bool speculate = !debug && ro.speculative != 0 && cap0 > 0;
 	if (speculate) {
 		const int rc = launch_rest(cap0, long0);
@@ -601,8 +603,8 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		            __FILE__, __LINE__);
 	if (host->err_overflow || host->ref_rendered > 0x7fffffffu || Rb > 0x7fffffffu)
 		return fail(GSR_ERR_ARG, "gsr_forward: more than 2^31 - 1 (tile, Gaussian) instances", __FILE__, __LINE__);
-	const bool need_long = max_tile > GSR_SORT_LDS_MAX;
-	if (!speculate || Rb > cap0 || (need_long && !long0)) {
+	const int need_long = max_tile > GSR_SORT_GIANT ? 2 : (max_tile > GSR_SORT_LDS_MAX ? 1 : 0);
+	if (!speculate || Rb > cap0 || need_long > long0) {
 		// first call on this device, debug mode, or the speculation missed: exact size, launched now
 		const int rc = launch_rest(Rb, need_long);
 		if (rc < 0) return rc;
@@ -616,7 +618,7 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		const uint32_t next = cur < want ? want : (cur - (cur - want) / 8 > want + 4096u ? cur - (cur - want) / 8 : want);
 		if (next == cur || ds.cap.compare_exchange_weak(cur, next)) break;
 	}
-	ds.long_lists.store(need_long ? 1 : 0);
+	ds.long_lists.store(need_long);
 	return (int)host->ref_rendered;
 }
 

@@ -58,14 +58,16 @@ struct ImgLayout {
 // binning buffer: [point_list u32 x R][keys u64 x R][keys2 u64 x R, only when a tile list is long enough for
 // the radix path]   (replaces BinningState, rasterizer_impl.h:59-68: 2x u64 keys + 2x u32 values + CUB temp =
 // 24 B/instance + temp; here 12 B/instance, 20 B with the radix ping-pong buffer).  Backward reads point_list only.
+size_t sort_queue_bytes(size_t R, int T);   // work queue of the long-list sort (gsr_kernels_fwd.hip)
 struct BinLayout {
-	size_t point_list, keys, keys2, total;
-	explicit BinLayout(size_t R, bool with_tmp = false)
+	size_t point_list, keys, keys2, queue, total;
+	explicit BinLayout(size_t R, bool with_tmp = false, int T = 0)
 	{
 		point_list = 0;
 		keys = align_up(sizeof(uint32_t) * R);
 		keys2 = keys + align_up(sizeof(uint64_t) * R);
-		total = with_tmp ? keys2 + align_up(sizeof(uint64_t) * R) : keys2;
+		queue = keys2 + align_up(sizeof(uint64_t) * R);
+		total = with_tmp ? queue + align_up(sort_queue_bytes(R, T)) : keys2;
 		if (total == 0) total = 256;
 	}
 };
@@ -112,9 +114,10 @@ void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const 
                      uint32_t* tile_count, hipStream_t s);
 void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
                          const uint2* ranges, uint64_t* keys, const uint32_t* bsums, uint32_t* goff, const GsCtl* ctl, uint32_t cap, hipStream_t s);
-// with_long: also launch the long-list (> GSR_SORT_LDS_MAX keys) kernel, which needs the keys2 buffer
-void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
-                      uint32_t* point_list, const GsCtl* ctl, uint32_t cap, hipStream_t s);
+// long_level: 0 = no list beyond GSR_SORT_LDS_MAX, 1 = lists up to GSR_SORT_GIANT keys (one workgroup per tile), 2 = longer ones too
+#define GSR_SORT_GIANT 8192u
+void launch_tile_sort(int T, bool with_short, int long_level, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
+                      uint32_t* point_list, char* queue, size_t R, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
                           float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp, hipStream_t s);

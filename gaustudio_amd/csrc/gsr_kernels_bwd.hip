@@ -46,25 +46,52 @@ __device__ __forceinline__ float row_swap_sum(float p, float q)
 	return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
-// Sum of the per-instance rows of Gaussian idx in ascending tile order (fixed order: the result does
-// not depend on scheduling).  Used by preprocess_bwd and by the test-only inspection kernel.
-__device__ __forceinline__ void gs_sum_rows(bool vis, int idx, const GsRec* __restrict__ recs,
-                                            const uint32_t* __restrict__ goff, const float* __restrict__ rows,
-                                            const uint8_t* __restrict__ row_flags, float* a_)
+// Gaussians with MORE than GSR_SUM_LONG instance rows (a splat tens of pixels wide sits in hundreds of tile lists) are not
+// summed by their own lane -- one lane adding 400 rows while 63 wait made preprocess_bwd 4x slower on a scene with 1 % of
+// such splats (bench.py --workload C2-clustered: 0.199 ms against 0.05) -- but by the whole WAVE: lane l adds the rows
+// b + l, b + l + 64, ... (coalesced 3-KiB reads), and six xor-butterfly steps add the 64 partial sums.  A fixed order
+// again (the butterfly is symmetric: every lane ends with the same bits), used by preprocess_bwd and by the inspection
+// kernel alike, so the result stays independent of scheduling and the two agree bit for bit.
+#define GSR_SUM_LONG 96
+__device__ __forceinline__ void gs_sum_rows_wave(uint32_t b, uint32_t e, const float* __restrict__ rows,
+                                                 const uint8_t* __restrict__ row_flags, int lane, float* acc)
 {
 #pragma unroll
-	for (int i = 0; i < GSR_ROW_STRIDE; i++) a_[i] = 0.f;
-	if (!vis) return;
-	const uint32_t b = goff[idx], e = goff[idx + 1];
-	for (uint32_t r = b; r < e; r++) {
-		if (row_flags != nullptr && !row_flags[r]) continue;   // flags mode: not written (never reached by the walk)
+	for (int i = 0; i < 10; i++) acc[i] = 0.f;
+	for (uint32_t r = b + (uint32_t)lane; r < e; r += 64) {
+		if (row_flags != nullptr && !row_flags[r]) continue;
 		const float4* ar = reinterpret_cast<const float4*>(rows + (size_t)r * GSR_ROW_STRIDE);
-		const float4 v0 = ar[0], v1 = ar[1], v2 = ar[2];
-		a_[0] += v0.x; a_[1] += v0.y; a_[2] += v0.z; a_[3] += v0.w; a_[4] += v1.x; a_[5] += v1.y;
-		a_[6] += v1.z; a_[7] += v1.w; a_[8] += v2.x; a_[9] += v2.y;
+		const float4 v0 = gs_ld_stream(ar), v1 = gs_ld_stream(ar + 1), v2 = gs_ld_stream(ar + 2);
+		acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w; acc[4] += v1.x; acc[5] += v1.y;
+		acc[6] += v1.z; acc[7] += v1.w; acc[8] += v2.x; acc[9] += v2.y;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+		for (int i = 0; i < 10; i++) acc[i] += __shfl_xor(acc[i], o, 64);
+	}
+}
+// the long Gaussians of a wave, one after the other (all 64 lanes must call; `b`, `e` = the lane's own row span or b == e)
+__device__ __forceinline__ void gs_sum_long_rows(uint32_t b, uint32_t e, const float* __restrict__ rows,
+                                                 const uint8_t* __restrict__ row_flags, int lane, float* a_)
+{
+	unsigned long long longs = __ballot(e - b > (uint32_t)GSR_SUM_LONG);
+	while (longs) {
+		const int l = __builtin_ctzll(longs);
+		longs &= longs - 1;
+		const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)b, l), el = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
+		float acc[10];
+		gs_sum_rows_wave(bl, el, rows, row_flags, lane, acc);
+		if (lane == l) {
+#pragma unroll
+			for (int i = 0; i < 10; i++) a_[i] = acc[i];
+		}
 	}
 }
 
+// Sum of the per-instance rows of Gaussian idx in ascending tile order (fixed order: the result does
+// not depend on scheduling); spans longer than GSR_SUM_LONG by the whole wave (above).  Test-only inspection kernel;
+// preprocess_bwd forms the same sums in the same order from its LDS slabs.
 __global__ __launch_bounds__(256) void inspect_sums_kernel(int P, const int* __restrict__ radii,
                                                            const GsRec* __restrict__ recs,
                                                            const uint32_t* __restrict__ goff,
@@ -72,9 +99,23 @@ __global__ __launch_bounds__(256) void inspect_sums_kernel(int P, const int* __r
                                                            const uint8_t* __restrict__ row_flags, float* __restrict__ out)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
-	if (idx >= P) return;
+	const int lane = threadIdx.x & 63;
+	const bool vis = idx < P && radii[idx] > 0;
 	float a_[GSR_ROW_STRIDE];
-	gs_sum_rows(radii[idx] > 0, idx, recs, goff, rows, row_flags, a_);
+#pragma unroll
+	for (int i = 0; i < GSR_ROW_STRIDE; i++) a_[i] = 0.f;
+	const uint32_t b = vis ? goff[idx] : 0u, e = vis ? goff[idx + 1] : 0u;
+	if (e - b <= (uint32_t)GSR_SUM_LONG) {
+		for (uint32_t r = b; r < e; r++) {
+			if (row_flags != nullptr && !row_flags[r]) continue;   // flags mode: not written (never reached by the walk)
+			const float4* ar = reinterpret_cast<const float4*>(rows + (size_t)r * GSR_ROW_STRIDE);
+			const float4 v0 = ar[0], v1 = ar[1], v2 = ar[2];
+			a_[0] += v0.x; a_[1] += v0.y; a_[2] += v0.z; a_[3] += v0.w; a_[4] += v1.x; a_[5] += v1.y;
+			a_[6] += v1.z; a_[7] += v1.w; a_[8] += v2.x; a_[9] += v2.y;
+		}
+	}
+	gs_sum_long_rows(b, e, rows, row_flags, lane, a_);
+	if (idx >= P) return;
 #pragma unroll
 	for (int i = 0; i < 10; i++) out[10 * (size_t)idx + i] = a_[i];
 }
@@ -978,6 +1019,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 		if (g0 >= P) return;   // wave-uniform
 		const uint32_t b = goff[min(idx, P)], e = idx < P ? goff[idx + 1] : b;   // goff has P + 1 entries
 		const uint32_t wb = goff[g0], we = goff[min(g0 + 64, P)];
+		const bool is_long = e - b > (uint32_t)GSR_SUM_LONG;
 #pragma unroll
 		for (int i = 0; i < GSR_ROW_STRIDE; i++) a_[i] = 0.f;
 		float4* slab = s_rows[wv];
@@ -1000,7 +1042,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 				if (j < cnt * 3 && (!flagged || fl[j / 3])) slab[j] = gs_ld_stream(src + j);   // unwritten rows are not fetched; read once
 			}
 			__builtin_amdgcn_wave_barrier();
-			const uint32_t lo = max(b, base), hi = min(e, base + cnt);
+			const uint32_t lo = max(b, base), hi = is_long ? lo : min(e, base + cnt);   // long spans: by the whole wave, below
 			for (uint32_t r = lo; r < hi; r++) {
 				if (flagged && !fl[r - base]) continue;
 				const float4* ar = slab + (r - base) * 3;
@@ -1010,6 +1052,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 			}
 			__builtin_amdgcn_wave_barrier();
 		}
+		gs_sum_long_rows(b, e, rows, FLAGS ? row_flags : nullptr, lane, a_);   // spans > GSR_SUM_LONG rows: the whole wave per Gaussian
 	}
 	if (idx >= P) return;
 	const bool vis = radii[idx] > 0;

@@ -842,9 +842,168 @@ __device__ __forceinline__ void tile_radix_pass(const uint64_t* __restrict__ src
 	__syncthreads();
 }
 
+// ---- long lists, round 4: partition by key range, then sort the buckets ALL OVER THE CHIP -------------------------
+// Until round 3 one workgroup did everything for its tile: cut the list into <= 1024 equal-width depth buckets, sort the
+// buckets with its four waves -- and, when one bucket overflowed (depths piled up: the surface a tile looks at), fall back
+// to four counting passes over the whole list.  On a clustered scene (bench.py --workload C2-clustered: per-tile lists
+// p50 10 / p99 11 k / max 58 k) that kernel was 55 % of the step: 0.98 ms for the workgroup that owned the 58 k list.
+// Now the stage is a small pipeline over a WORK QUEUE in the binning buffer (GsSortQ + item arrays):
+//   tile_partition     one 1024-thread workgroup per long tile: min / max of the 64-bit keys (depth << 32 | id), B = 2^k
+//                      buckets of equal KEY width (~128 keys on average, <= 4096 buckets), histogram + scatter into
+//                      `keys2`; every non-empty bucket becomes a queue item: <= 1024 keys -> sort item, more -> a
+//                      segment for the next round.  (64-bit keys: a pile of equal depths spreads over the id bits.)
+//   segment_partition  the same cut applied to the oversized buckets, each by its own key range, into the other key buffer
+//                      (two more levels; also takes the <= 8192-key lists whose one-workgroup cut overflowed, see
+//                      tile_radix_sort_kernel); what is STILL oversized after three levels goes to
+//   segment_fallback   the counting sort that used to take the whole tile (tile_radix_pass), one workgroup per segment.
+//   bucket_sort        every wave of the chip sorts buckets from the queue in registers (gs_wave_sort_tile) -> point_list.
+// The order is (depth, id) as before; point_list is bit-identical to the oracle's.
+struct GsSortQ {
+	uint32_t n_sort, n_seg, n_seg2, n_fall, err, pad[3];
+};
+#define GSR_Q_IN_KEYS 0x80000000u    // item flag (in .y): the bucket's keys are in `keys` (second round), else in `keys2`
+#define GSR_PART_THREADS 1024
+#define GSR_PART_BMAX 4096u
+#define GSR_PART_AVG 128u            // target keys per bucket
+#define GSR_PART_REGS 8192u          // lists up to this many keys are read once and held in registers (NT threads x 8192 / NT keys)
+
+// One workgroup (GSR_PART_THREADS threads) cuts the n keys at src into buckets written to dst (same offsets); items are
+// positions relative to the binning arrays (`abs0` = index of src[0] in them).  item_flag marks where the buckets live.
+template <int NT>
+__device__ __forceinline__ void gs_partition_segment(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t abs0,
+                                                     uint32_t n, uint32_t item_flag, GsSortQ* __restrict__ q,
+                                                     uint2* __restrict__ sort_items, uint32_t sort_cap,
+                                                     uint2* __restrict__ over_items, uint32_t over_cap, uint32_t* over_count,
+                                                     uint32_t* s_off, uint32_t* s_cur, uint32_t* s_misc, unsigned long long* s_mm,
+                                                     uint32_t* __restrict__ fused_out)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	constexpr int NW = NT / 64, RK = (int)(GSR_PART_REGS / NT);
+	if (tid == 0) { s_mm[0] = ~0ull; s_mm[1] = 0ull; s_misc[0] = 0u; s_misc[1] = 0u; }
+	__syncthreads();
+	const bool in_regs = n <= (uint32_t)NT * RK;
+	uint64_t kreg[RK];
+	unsigned long long mn = ~0ull, mx = 0ull;
+	if (in_regs) {
+#pragma unroll
+		for (int r = 0; r < RK; r++) {
+			const uint32_t i = (uint32_t)tid + (uint32_t)NT * r;
+			kreg[r] = i < n ? src[i] : ~0ull;
+			if (i < n) { mn = min(mn, (unsigned long long)kreg[r]); mx = max(mx, (unsigned long long)kreg[r]); }
+		}
+	} else {
+		for (uint32_t i = tid; i < n; i += NT) {
+			const unsigned long long k = src[i];
+			mn = min(mn, k); mx = max(mx, k);
+		}
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		mn = min(mn, (unsigned long long)__shfl_xor((long long)mn, o, 64));
+		mx = max(mx, (unsigned long long)__shfl_xor((long long)mx, o, 64));
+	}
+	if (lane == 0) { atomicMin(&s_mm[0], mn); atomicMax(&s_mm[1], mx); }
+	__syncthreads();
+	const unsigned long long kmin = s_mm[0], span = s_mm[1] - s_mm[0];   // span > 0: the keys are distinct and n > 1
+	uint32_t B = 2;
+	while (B < GSR_PART_BMAX && B < 4u * NT && B * GSR_PART_AVG < n) B <<= 1;
+	const int span_bits = 64 - __builtin_clzll(span | 1ull), logB = 31 - __clz((int)B);
+	const int shift = max(0, span_bits - logB);            // (k - kmin) >> shift < B
+	for (uint32_t b = tid; b <= B; b += NT) s_off[b] = 0u;
+	__syncthreads();
+	if (in_regs) {
+#pragma unroll
+		for (int r = 0; r < RK; r++)
+			if ((uint32_t)tid + (uint32_t)NT * r < n) atomicAdd(&s_off[(uint32_t)((kreg[r] - kmin) >> shift)], 1u);
+	} else {
+		for (uint32_t i = tid; i < n; i += NT) atomicAdd(&s_off[(uint32_t)((src[i] - kmin) >> shift)], 1u);
+	}
+	__syncthreads();
+	// exclusive scan of the B counts (4 per thread); how many sort / oversized items this cut produces
+	{
+		uint32_t c[4], sum = 0, n_s = 0, n_o = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint32_t b = 4 * tid + k;
+			c[k] = b < B ? s_off[b] : 0u;
+			sum += c[k];
+			n_s += (c[k] > 0u && c[k] <= GSR_SORT_LDS_MAX) ? 1u : 0u;
+			n_o += c[k] > GSR_SORT_LDS_MAX ? 1u : 0u;
+		}
+		uint32_t incl = sum;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		__shared__ uint32_t s_wtot[NW];
+		if (lane == 63) s_wtot[wv] = incl;
+		// local item slots (order irrelevant)
+		uint32_t ls = 0, lo_ = 0;
+		if (n_s) ls = atomicAdd(&s_misc[0], n_s);
+		if (n_o) lo_ = atomicAdd(&s_misc[1], n_o);
+		__syncthreads();
+		uint32_t run = incl - sum;
+		for (int w = 0; w < wv; w++) run += s_wtot[w];
+		// a list held in registers whose buckets all fit the register sort is finished right here by this workgroup's own
+		// waves (the C4 regime: every tile ~3.7 k keys) -- no queue round trip; only longer lists and overflowing cuts
+		// hand their buckets to bucket_sort_kernel
+		const bool fused = fused_out != nullptr && in_regs && s_misc[1] == 0u;
+		if (tid == 0) {   // one reservation per workgroup and queue
+			const uint32_t ts = fused ? 0u : s_misc[0], to = s_misc[1];
+			s_misc[2] = ts ? atomicAdd(&q->n_sort, ts) : 0u;
+			s_misc[3] = to ? atomicAdd(over_count, to) : 0u;
+		}
+		__syncthreads();
+		const uint32_t gs = s_misc[2], go = s_misc[3];
+		if ((!fused && gs + s_misc[0] > sort_cap) || go + s_misc[1] > over_cap) { if (tid == 0) q->err = 1u; }
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint32_t b = 4 * tid + k;
+			if (b < B) { s_off[b] = run; s_cur[b] = run; }
+			if (b == B - 1) s_off[B] = run + c[k];
+			if (c[k] > 0u && c[k] <= GSR_SORT_LDS_MAX) { if (!fused && gs + ls < sort_cap) sort_items[gs + ls] = make_uint2(abs0 + run, c[k] | item_flag); ls++; }
+			else if (c[k] > GSR_SORT_LDS_MAX) { if (go + lo_ < over_cap) over_items[go + lo_] = make_uint2(abs0 + run, c[k] | item_flag); lo_++; }
+			run += c[k];
+		}
+	}
+	__syncthreads();
+	if (in_regs) {
+#pragma unroll
+		for (int r = 0; r < RK; r++) {
+			if ((uint32_t)tid + (uint32_t)NT * r < n) {
+				const uint64_t k = kreg[r];
+				dst[atomicAdd(&s_cur[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
+			}
+		}
+	} else {
+		for (uint32_t i = tid; i < n; i += NT) {
+			const uint64_t k = src[i];
+			dst[atomicAdd(&s_cur[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
+		}
+	}
+	if (fused_out != nullptr && in_regs && s_misc[1] == 0u) {
+		__threadfence_block();
+		__syncthreads();
+		for (uint32_t b = wv; b < B; b += NW) {
+			const uint32_t st = s_off[b], cnt = s_off[b + 1] - st;   // s_off[B] = n was left by the scan below
+			const uint64_t* bs = dst + st;
+			uint32_t* bo = fused_out + st;
+			if (cnt == 0) continue;
+			if (cnt <= 64) gs_wave_sort_tile<1>(bs, bo, cnt, lane);
+			else if (cnt <= 128) gs_wave_sort_tile<2>(bs, bo, cnt, lane);
+			else if (cnt <= 256) gs_wave_sort_tile<4>(bs, bo, cnt, lane);
+			else if (cnt <= 512) gs_wave_sort_tile<8>(bs, bo, cnt, lane);
+			else gs_wave_sort_tile<16>(bs, bo, cnt, lane);
+		}
+	}
+	__syncthreads();
+}
+
 __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __restrict__ ranges,
                                                               uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
                                                               uint32_t* __restrict__ point_list, uint32_t lo,
+                                                              GsSortQ* __restrict__ q, uint2* __restrict__ seg_items, uint32_t seg_cap,
                                                               const GsCtl* __restrict__ ctl, uint32_t cap)
 {
 	__shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave running offsets
@@ -854,6 +1013,8 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 	const uint2 range = ranges[blockIdx.x];
 	const uint32_t n = range.y - range.x;
 	if (n <= lo) return;
+	if (q != nullptr && n > GSR_PART_REGS) return;   // the queue pipeline's (tile_partition_kernel), when it is launched
+	if (q == nullptr && ctl->max_tile_count > GSR_SORT_GIANT) return;   // launched for the wrong regime: the host re-launches with the pipeline
 	const int tid = threadIdx.x, wv = tid >> 6;
 	uint64_t* src = keys + range.x;
 	uint64_t* dst = keys2 + range.x;
@@ -984,6 +1145,17 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 		}
 		__syncthreads();
 	}
+	if (q != nullptr) {
+		// an overflowing cut while the queue pipeline runs anyway (a list > GSR_PART_REGS keys exists in this frame): the
+		// list becomes a segment of its second stage (64-bit key ranges, buckets sorted all over the chip) -- its keys are
+		// still where the scatter left them, in `keys`
+		if (tid == 0) {
+			const uint32_t at = atomicAdd(&q->n_seg, 1u);
+			if (at < seg_cap) seg_items[at] = make_uint2(range.x, n | GSR_Q_IN_KEYS);
+			else q->err = 1u;
+		}
+		return;
+	}
 	// wave w owns [wb, we): quarters rounded to multiples of 64 so that groups never straddle waves
 	const uint32_t per = ((n + 3) / 4 + 63) / 64 * 64;
 	const uint32_t wb = min(n, (uint32_t)wv * per), we = min(n, wb + per);
@@ -1034,15 +1206,189 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 	for (uint32_t i = tid; i < n; i += 256) point_list[range.x + i] = (uint32_t)src[i];
 }
 
-void launch_tile_sort(int T, bool with_short, bool with_long, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
-                      uint32_t* point_list, const GsCtl* ctl, uint32_t cap, hipStream_t s)
+
+// (NT = 256 for the lists of 1025 .. 8192 keys was measured: slower than 1024 threads -- C4 sort 0.240 against 0.216 ms)
+template <int NT>
+__global__ __launch_bounds__(NT) void tile_partition_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
+                                                                         uint64_t* __restrict__ keys2, uint32_t* __restrict__ point_list, GsSortQ* __restrict__ q,
+                                                                         uint2* __restrict__ sort_items, uint32_t sort_cap,
+                                                                         uint2* __restrict__ seg_items, uint32_t seg_cap,
+                                                                         const GsCtl* __restrict__ ctl, uint32_t cap)
 {
-	// <= GSR_SORT_LDS_MAX keys: register bitonic network, one wave per tile; longer: radix path (needs keys2)
+	constexpr uint32_t BM = 4u * NT < GSR_PART_BMAX ? 4u * NT : GSR_PART_BMAX;
+	__shared__ uint32_t s_off[BM + 1], s_cur[BM], s_misc[4];
+	__shared__ unsigned long long s_mm[2];
+	if (ctl->num_binned > cap || ctl->max_tile_count <= GSR_SORT_LDS_MAX) return;   // see bin_scatter_kernel; no long list at all
+	const uint2 range = ranges[blockIdx.x];
+	const uint32_t n = range.y - range.x;
+	if (n <= GSR_SORT_LDS_MAX) return;   // tile_sort_kernel's
+	gs_partition_segment<NT>(keys + range.x, keys2 + range.x, range.x, n, 0u, q, sort_items, sort_cap, seg_items, seg_cap, &q->n_seg,
+	                         s_off, s_cur, s_misc, s_mm, nullptr);
+}
+
+// further levels: the oversized buckets of the level before (and the overflowing lists tile_radix_sort_kernel hands over) cut
+// again, each by its OWN key range, into the other key buffer; workgroups stride over the segment queue `in_items`, what is
+// still oversized goes to `out_items` (the next level's queue, or the fallback's)
+__global__ __launch_bounds__(GSR_PART_THREADS) void segment_partition_kernel(uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
+                                                                            GsSortQ* __restrict__ q, uint2* __restrict__ sort_items,
+                                                                            uint32_t sort_cap, const uint2* __restrict__ in_items,
+                                                                            const uint32_t* __restrict__ in_count, uint32_t seg_cap,
+                                                                            uint2* __restrict__ out_items, uint32_t* __restrict__ out_count,
+                                                                            const GsCtl* __restrict__ ctl, uint32_t cap)
+{
+	__shared__ uint32_t s_off[GSR_PART_BMAX + 1], s_cur[GSR_PART_BMAX], s_misc[4];
+	__shared__ unsigned long long s_mm[2];
+	if (ctl->num_binned > cap || ctl->max_tile_count <= GSR_SORT_LDS_MAX) return;
+	const uint32_t nseg = min(*in_count, seg_cap);
+	for (uint32_t it = blockIdx.x; it < nseg; it += gridDim.x) {
+		const uint2 sg = in_items[it];
+		const bool in_keys = (sg.y & GSR_Q_IN_KEYS) != 0u;     // where the segment's keys are; its buckets go to the other buffer
+		const uint32_t cnt = sg.y & ~GSR_Q_IN_KEYS;
+		gs_partition_segment<GSR_PART_THREADS>((in_keys ? keys : keys2) + sg.x, (in_keys ? keys2 : keys) + sg.x, sg.x, cnt,
+		                                       in_keys ? 0u : GSR_Q_IN_KEYS, q, sort_items, sort_cap, out_items, seg_cap,
+		                                       out_count, s_off, s_cur, s_misc, s_mm, nullptr);
+	}
+}
+
+// every wave of the launch sorts buckets (<= 1024 keys each) from the queue in registers
+__global__ __launch_bounds__(256) void bucket_sort_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys2,
+                                                          uint32_t* __restrict__ point_list, const GsSortQ* __restrict__ q,
+                                                          const uint2* __restrict__ sort_items, uint32_t sort_cap,
+                                                          const GsCtl* __restrict__ ctl, uint32_t cap)
+{
+	if (ctl->num_binned > cap || ctl->max_tile_count <= GSR_SORT_LDS_MAX) return;
+	const int lane = threadIdx.x & 63;
+	const uint32_t nitems = min(q->n_sort, sort_cap);
+	const uint32_t nwaves = gridDim.x * 4u;
+	for (uint32_t it = blockIdx.x * 4u + (threadIdx.x >> 6); it < nitems; it += nwaves) {
+		const uint2 item = sort_items[it];
+		const uint32_t cnt = item.y & ~GSR_Q_IN_KEYS;
+		const uint64_t* bs = ((item.y & GSR_Q_IN_KEYS) ? keys : keys2) + item.x;
+		uint32_t* bo = point_list + item.x;
+		if (cnt <= 64) gs_wave_sort_tile<1>(bs, bo, cnt, lane);
+		else if (cnt <= 128) gs_wave_sort_tile<2>(bs, bo, cnt, lane);
+		else if (cnt <= 256) gs_wave_sort_tile<4>(bs, bo, cnt, lane);
+		else if (cnt <= 512) gs_wave_sort_tile<8>(bs, bo, cnt, lane);
+		else gs_wave_sort_tile<16>(bs, bo, cnt, lane);
+	}
+}
+
+// last resort for a segment that two levels of key-range cuts could not break up: stable LSD counting sort on the 32
+// depth bits (ping-pong src <-> tmp, data ends in src), runs of equal depth put in id order afterwards; one workgroup
+// (256 threads) per segment.
+__device__ __forceinline__ void gs_radix_sort_segment(uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t* __restrict__ out,
+                                                      uint32_t n, uint32_t (*whist)[256], uint32_t* s_tot, uint32_t* s_maxrun)
+{
+	const int tid = threadIdx.x, wv = tid >> 6;
+	// wave w owns [wb, we): quarters rounded to multiples of 64 so that groups never straddle waves
+	const uint32_t per = ((n + 3) / 4 + 63) / 64 * 64;
+	const uint32_t wb = min(n, (uint32_t)wv * per), we = min(n, wb + per);
+	if (tid == 0) *s_maxrun = 0;
+	for (int pass = 0; pass < 4; pass += 2) {   // an even number of passes leaves the data in `src`
+		tile_radix_pass(src, dst, 32 + 8 * pass, wb, we, whist, s_tot);
+		tile_radix_pass(dst, src, 40 + 8 * pass, wb, we, whist, s_tot);
+	}
+	// Runs of equal depth are in scatter order.  Measure the longest one (capped): short runs (the normal case:
+	// isolated float ties) are put in id order by one thread each; long runs (a fronto-parallel sheet of Gaussians
+	// all at one depth) would make that quadratic in one thread, so the whole list is re-sorted as a full 64-bit
+	// stable LSD sort instead: four passes on the id bits, then the four depth passes again.
+	const uint32_t RUN_CAP = 32;
+	uint32_t myrun = 0;
+	for (uint32_t i = tid; i < n; i += 256) {
+		const uint32_t dep = (uint32_t)(src[i] >> 32);
+		if (i == 0 || (uint32_t)(src[i - 1] >> 32) != dep) {
+			uint32_t e = i + 1;
+			while (e < n && e - i <= RUN_CAP && (uint32_t)(src[e] >> 32) == dep) e++;
+			myrun = max(myrun, e - i);
+		}
+	}
+	if (myrun > 1) atomicMax(s_maxrun, myrun);
+	__syncthreads();
+	const uint32_t maxrun = *s_maxrun;
+	if (maxrun > RUN_CAP) {
+		for (int pass = 0; pass < 8; pass += 2) {
+			tile_radix_pass(src, dst, 8 * pass, wb, we, whist, s_tot);
+			tile_radix_pass(dst, src, 8 * pass + 8, wb, we, whist, s_tot);
+		}
+	} else if (maxrun > 1) {
+		for (uint32_t i = tid; i < n; i += 256) {
+			const uint32_t dep = (uint32_t)(src[i] >> 32);
+			const bool starts = (i == 0 || (uint32_t)(src[i - 1] >> 32) != dep) && (i + 1 < n) && (uint32_t)(src[i + 1] >> 32) == dep;
+			if (starts) {
+				uint32_t e = i + 1;
+				while (e < n && (uint32_t)(src[e] >> 32) == dep) e++;
+				for (uint32_t a = i + 1; a < e; a++) {   // insertion sort of the run [i, e) by full key (= by id)
+					const uint64_t v = src[a];
+					uint32_t b = a;
+					while (b > i && src[b - 1] > v) { src[b] = src[b - 1]; b--; }
+					src[b] = v;
+				}
+			}
+		}
+		__syncthreads();
+	}
+	for (uint32_t i = tid; i < n; i += 256) out[i] = (uint32_t)src[i];
+	__syncthreads();
+}
+
+__global__ __launch_bounds__(256) void segment_fallback_kernel(uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
+                                                               uint32_t* __restrict__ point_list, const GsSortQ* __restrict__ q,
+                                                               const uint2* __restrict__ fall_items, uint32_t fall_cap,
+                                                               const GsCtl* __restrict__ ctl, uint32_t cap)
+{
+	__shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave running offsets
+	__shared__ uint32_t s_tot[4];
+	__shared__ uint32_t s_maxrun;
+	if (ctl->num_binned > cap || ctl->max_tile_count <= GSR_SORT_LDS_MAX) return;
+	const uint32_t nf = min(q->n_fall, fall_cap);
+	for (uint32_t it = blockIdx.x; it < nf; it += gridDim.x) {
+		const uint2 sg = fall_items[it];
+		const bool in_keys = (sg.y & GSR_Q_IN_KEYS) != 0u;
+		gs_radix_sort_segment((in_keys ? keys : keys2) + sg.x, (in_keys ? keys2 : keys) + sg.x, point_list + sg.x, sg.y & ~GSR_Q_IN_KEYS,
+		                      whist, s_tot, &s_maxrun);
+	}
+}
+
+// queue storage behind keys2 (BinLayout::queue): [GsSortQ][sort items][segment items][fallback items]
+size_t sort_queue_bytes(size_t R, int T)
+{
+	const size_t sort_cap = R / 16 + 4 * (size_t)T + 4096, seg_cap = R / 512 + (size_t)T + 64;
+	return 256 + sizeof(uint2) * (sort_cap + 3 * seg_cap) + 256;
+}
+
+void launch_tile_sort(int T, bool with_short, int long_level, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
+                      uint32_t* point_list, char* queue, size_t R, const GsCtl* ctl, uint32_t cap, hipStream_t s)
+{
+	// <= GSR_SORT_LDS_MAX keys: register bitonic network, one wave per tile (tile_sort_kernel).
+	// long_level 1 (lists up to GSR_SORT_GIANT keys, e.g. the C4 regime: every tile ~3.7 k): one 256-thread workgroup per tile
+	// cuts and sorts its list (tile_radix_sort_kernel, the round-2/3 kernel: 0.19 ms at C4 against 0.216 for the pipeline).
+	// long_level 2 (a longer list exists in the frame): the queue pipeline for every long list -- cut by 1024-thread
+	// workgroups, every overflowing cut cut again (two more levels), the buckets sorted by all waves of the chip.
 	if (with_short)
 		hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list, ctl, cap);
-	if (with_long)
-		hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list,
-		                   GSR_SORT_LDS_MAX, ctl, cap);
+	if (long_level <= 0) return;
+	const uint32_t sort_cap = (uint32_t)(R / 16 + 4 * (size_t)T + 4096), seg_cap = (uint32_t)(R / 512 + (size_t)T + 64);
+	if (long_level == 1) {
+		hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, GSR_SORT_LDS_MAX, (GsSortQ*)nullptr,
+		                   (uint2*)nullptr, 0u, ctl, cap);
+		return;
+	}
+	// (measured on the clustered scene: sending the 1025 .. 8192-key lists of such a frame through tile_radix_sort_kernel
+	// first costs 42 us in front of the pipeline -- 0.177 against 0.123 ms for the stage; the pipeline takes every long list)
+	GsSortQ* q = reinterpret_cast<GsSortQ*>(queue);
+	uint2* sort_items = reinterpret_cast<uint2*>(queue + 256);
+	uint2* seg_items = sort_items + sort_cap;
+	uint2* seg2_items = seg_items + seg_cap;
+	uint2* fall_items = seg2_items + seg_cap;
+	(void)hipMemsetAsync(q, 0, sizeof(GsSortQ), s);
+	hipLaunchKernelGGL(tile_partition_kernel<GSR_PART_THREADS>, dim3(T), dim3(GSR_PART_THREADS), 0, s, ranges, keys, keys2, point_list, q,
+	                   sort_items, sort_cap, seg_items, seg_cap, ctl, cap);
+	hipLaunchKernelGGL(segment_partition_kernel, dim3(256), dim3(GSR_PART_THREADS), 0, s, keys, keys2, q, sort_items, sort_cap,
+	                   seg_items, &q->n_seg, seg_cap, seg2_items, &q->n_seg2, ctl, cap);
+	hipLaunchKernelGGL(segment_partition_kernel, dim3(256), dim3(GSR_PART_THREADS), 0, s, keys, keys2, q, sort_items, sort_cap,
+	                   seg2_items, &q->n_seg2, seg_cap, fall_items, &q->n_fall, ctl, cap);
+	hipLaunchKernelGGL(segment_fallback_kernel, dim3(256), dim3(256), 0, s, keys, keys2, point_list, q, fall_items, seg_cap, ctl, cap);
+	hipLaunchKernelGGL(bucket_sort_kernel, dim3(2048), dim3(256), 0, s, keys, keys2, point_list, q, sort_items, sort_cap, ctl, cap);
 }
 
 

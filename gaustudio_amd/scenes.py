@@ -113,6 +113,42 @@ def make_ball_scene(P, radius=4.0, seed=0, sigma=0.02) -> Scene:
                  opac.float().contiguous(), shs.float().contiguous())
 
 
+def make_clustered_scene(P, width, cam_distance=11.0, fovx_deg=60.0, radius=3.0, clusters=48, seed=0, sigma_px_median=1.5,
+                         sigma_px_logstd=0.7, big_fraction=0.01, big_px=(50.0, 60.0)) -> Scene:
+    """A NON-UNIFORM scene for inward-looking ring cameras at `cam_distance` (the structure of a trained capture rather than
+    of SURVEY.md s8d's uniform cloud): Gaussians in `clusters` blobs inside a ball of `radius` -- blob sizes log-uniform over
+    1.5 decades, populations Zipf-like, so a few screen regions hold most of the instances --, nothing outside the ball (a
+    ring camera sees well over 20 % empty tiles), footprints log-normal with a `big_fraction` tail of splats whose sigma
+    is `big_px` pixels at the ball's distance (the floaters / background blobs of real scenes: every one of them sits in
+    hundreds of tile lists)."""
+    g = torch.Generator().manual_seed(seed)
+    cdir = torch.randn(clusters, 3, generator=g)
+    cdir = cdir / cdir.norm(dim=1, keepdim=True)
+    ccen = cdir * (radius * 0.85 * torch.rand(clusters, 1, generator=g) ** (1.0 / 3.0))
+    crad = radius * 10 ** (-1.7 + 1.5 * torch.rand(clusters, generator=g))             # 0.02 .. 0.63 of the ball
+    w = 1.0 / torch.arange(1, clusters + 1, dtype=torch.float32) ** 0.9                   # Zipf-like populations
+    which = torch.multinomial(w / w.sum(), P, replacement=True, generator=g)
+    means = ccen[which] + torch.randn(P, 3, generator=g) * (crad[which][:, None] * 0.5)
+    far = means.norm(dim=1) > radius
+    means[far] = means[far] / means[far].norm(dim=1, keepdim=True) * radius
+    px_to_world = cam_distance * 2 * math.tan(math.radians(fovx_deg) / 2) / width          # one pixel at the ball's distance
+    sigma_px = torch.exp(torch.randn(P, generator=g) * sigma_px_logstd + math.log(sigma_px_median))
+    big = torch.rand(P, generator=g) < big_fraction
+    sigma_px[big] = big_px[0] + (big_px[1] - big_px[0]) * torch.rand(int(big.sum()), generator=g)
+    jitter = torch.rand(P, 3, generator=g) * 1.5 + 0.5
+    jitter[big] = jitter[big] / 2.0                  # big splats: `big_px` is the sigma of their LARGEST axis (0.25 .. 1 of it on the others)
+    jitter[big, 0] = 1.0
+    scales = (sigma_px * px_to_world)[:, None] * jitter
+    rot = torch.randn(P, 4, generator=g)
+    rot = rot / rot.norm(dim=1, keepdim=True)
+    opac = torch.sigmoid(torch.randn(P, 1, generator=g) * 2)
+    opac[big] = opac[big] * 0.3                                                            # large splats are faint in trained scenes
+    shs = torch.randn(P, 16, 3, generator=g) * 0.1
+    shs[:, 0, :] = (torch.rand(P, 3, generator=g) * 2 - 1) / 0.28209479177387814
+    return Scene(means.float().contiguous(), scales.float().contiguous(), rot.float().contiguous(),
+                 opac.float().contiguous(), shs.float().contiguous())
+
+
 def ring_cameras(n, width, height, radius=10.0, fovx_deg=60.0, elevation=0.2):
     cams = []
     for k in range(n):
