@@ -140,6 +140,7 @@ std::atomic<int> g_opt_cull{env_int("GSR_CULL", 1)};               // composite_
 std::atomic<int> g_opt_fwd_variant{env_int("GSR_FWD_VARIANT", 0)}; // 0: per-quarter (4x4) instance lists, 1: per-wave (8x8)
 std::atomic<int> g_opt_bwd_variant{env_int("GSR_BWD_VARIANT", -1)};   // -1: from gsr_selftest; bit 0: select on T
 std::atomic<int> g_opt_speculative{env_int("GSR_SPECULATIVE", 1)}; // launch binning + compositing before R is known
+std::atomic<int> g_opt_tile_order{env_int("GSR_TILE_ORDER", 1)};   // backward of a skewed frame: tiles longest walk first (0: always XCD-banded)
 std::atomic<int> g_opt_band_lo{0}, g_opt_band_hi{0};               // tile rows [lo, hi) this process renders (hi <= 0: all)
 // exp on the transcendental unit (v_exp_f32) in both compositing kernels.  DEFAULT ON since round 4: pinned directly against the
 // reference's kernels and the CPU oracle (tests/test_gpu_ref.py, tests/test_gpu_fastexp_oracle.py), it differs from the
@@ -152,7 +153,7 @@ std::atomic<int> g_opt_fast_exp{env_int("GSR_FAST_EXP", 1)};
 // would take other alpha >= 1/255 decisions than its forward (silently inconsistent gradients).  The device-side record
 // (GsCtl::opts) needs a read-back to check (debug mode does); this host-side memory makes the check free for the common
 // case of a backward that follows its forward in the same process.  An entry overwritten by newer forwards is simply not checked.
-struct FwdMode { const void* img; int fast_exp; };
+struct FwdMode { const void* img; int fast_exp; int skew; };
 constexpr int kFwdModes = 64;
 FwdMode g_fwd_modes[kFwdModes] = {};
 unsigned g_fwd_modes_next = 0;
@@ -161,8 +162,22 @@ void remember_forward_mode(const void* img, int fast_exp)
 {
 	std::lock_guard<std::mutex> lock(g_fwd_modes_mutex);
 	for (auto& e : g_fwd_modes)
-		if (e.img == img) { e.fast_exp = fast_exp; return; }
-	g_fwd_modes[g_fwd_modes_next++ % kFwdModes] = FwdMode{img, fast_exp};
+		if (e.img == img) { e.fast_exp = fast_exp; e.skew = 0; return; }
+	g_fwd_modes[g_fwd_modes_next++ % kFwdModes] = FwdMode{img, fast_exp, 0};
+}
+// skew: the frame has a tile list many times longer than the mean -- its backward orders the tiles longest walk first
+void remember_forward_skew(const void* img, int skew)
+{
+	std::lock_guard<std::mutex> lock(g_fwd_modes_mutex);
+	for (auto& e : g_fwd_modes)
+		if (e.img == img) { e.skew = skew; return; }
+}
+int recall_forward_skew(const void* img)
+{
+	std::lock_guard<std::mutex> lock(g_fwd_modes_mutex);
+	for (const auto& e : g_fwd_modes)
+		if (e.img == img) return e.skew;
+	return 0;
 }
 int recall_forward_mode(const void* img)    // -1: unknown
 {
@@ -201,6 +216,7 @@ Resolved resolve_options(const gsr_options* o)
 struct DevState {
 	std::atomic<uint32_t> cap{0};
 	std::atomic<int> long_lists{0};
+	std::atomic<int> skew{0};        // the last frame was skewed (a tile list > 4x the mean): composite_fwd runs the tiles longest list first
 	std::atomic<int> selftest{-1};
 };
 DevState g_dev[16];
@@ -552,6 +568,7 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	DevState& ds = dev_state();
 	const bool nocull = ro.cull == 0;
 	const bool wave_lists = ro.fwd_variant == 1;
+	bool skew_now = g_opt_tile_order.load() != 0 && ds.skew.load() != 0;
 	auto launch_rest = [&](uint32_t cap, int long_level) -> int {
 		const bool with_long = long_level > 0;
 		const BinLayout bl((size_t)cap, with_long, il.T);
@@ -580,9 +597,15 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 			STAGE_CHECK("tile_sort", debug, s);
 		}
 		tm.mark();
+		const uint32_t* order = nullptr;
+		if (skew_now && cap > 0) {   // (any permutation of the tiles is valid: a wrong guess of the regime costs or wastes two small launches, nothing else)
+			uint32_t* o = reinterpret_cast<uint32_t*>(img + il.tile_order);
+			launch_tile_order_fwd(il.T, ranges, o, ctl, cap, s);
+			order = o;
+		}
 		launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
 		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap,
-		                     long_level >= 2 ? 0xffffffffu : (long_level == 1 ? GSR_SORT_GIANT : GSR_SORT_LDS_MAX), nocull, wave_lists, ro.fast_exp != 0, s);
+		                     long_level >= 2 ? 0xffffffffu : (long_level == 1 ? GSR_SORT_GIANT : GSR_SORT_LDS_MAX), nocull, wave_lists, ro.fast_exp != 0, order, s);
 		STAGE_CHECK("composite_fwd", debug, s);
 		tm.mark();
 		return 0;
@@ -619,6 +642,10 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		if (next == cur || ds.cap.compare_exchange_weak(cur, next)) break;
 	}
 	ds.long_lists.store(need_long);
+	// a skewed frame (longest list > 1024 keys and > 4x the mean): its backward runs the tiles longest walk first
+	const int skew = (g_opt_tile_order.load() != 0 && max_tile > GSR_SORT_LDS_MAX && (uint64_t)max_tile * (uint64_t)il.T > 4ull * Rb) ? 1 : 0;
+	remember_forward_skew(img, skew);
+	ds.skew.store(skew);
 	return (int)host->ref_rendered;
 }
 
@@ -763,6 +790,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	for (int i = 0; i < 3; i++) bgv.host[i] = (background != nullptr && bgv.dptr == nullptr) ? background[i] : 0.f;
 	bgv.flag_dst = reinterpret_cast<uint32_t*>(bg_dev + 8);
 	bgv.flag = flagged ? 1u : 0u;
+	bgv.tile_order = nullptr;
 	if (R <= 0) {
 		const float* const src[4] = {nullptr, nullptr, nullptr, nullptr};
 		float* const dst[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -794,6 +822,12 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 		if (ro.fast_exp) {
 			if (variant & 2) return fail(GSR_ERR_ARG, "gsr_backward: fast_exp needs the per-quarter kernel (bwd_variant bit 1 clear)", __FILE__, __LINE__);
 			variant |= 8;   // bit 3: the forward used the hardware exp -- the backward takes the same decisions with it
+		}
+		if (recall_forward_skew(image_buffer)) {
+			uint32_t* tw = reinterpret_cast<uint32_t*>(const_cast<char*>(image_buffer) + il.tile_work);
+			uint32_t* to = reinterpret_cast<uint32_t*>(const_cast<char*>(image_buffer) + il.tile_order);
+			launch_tile_order(il.T, n_contrib, tw, to, s);
+			bgv.tile_order = to;
 		}
 		launch_composite_bwd(il, width, height, bgv, ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix,
 		                     dL_dpix_depth, dL_dpix_median_depth, dL_dpix_final_opacity, rows, row_flags,
@@ -895,6 +929,7 @@ int gsr_set_option(const char* name, int value)
 	else if (n == "bwd_variant") g_opt_bwd_variant.store(value);
 	else if (n == "speculative") g_opt_speculative.store(value);
 	else if (n == "fast_exp") g_opt_fast_exp.store(value != 0);
+	else if (n == "tile_order") g_opt_tile_order.store(value != 0);
 	else if (n == "roctx") g_opt_roctx.store(value != 0);
 	else if (n == "tile_row_lo") g_opt_band_lo.store(value > 0 ? value : 0);
 	else if (n == "tile_row_hi") g_opt_band_hi.store(value);
@@ -916,6 +951,7 @@ int gsr_get_option(const char* name)
 	if (n == "bwd_variant") return g_opt_bwd_variant.load();
 	if (n == "speculative") return g_opt_speculative.load();
 	if (n == "fast_exp") return g_opt_fast_exp.load();
+	if (n == "tile_order") return g_opt_tile_order.load();
 	if (n == "roctx") return g_opt_roctx.load() != 0 && roctx().push != nullptr;
 	if (n == "tile_row_lo") return g_opt_band_lo.load();
 	if (n == "tile_row_hi") return g_opt_band_hi.load();

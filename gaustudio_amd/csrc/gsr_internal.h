@@ -38,7 +38,7 @@ struct GeomLayout {
 // the tile's list of the Gaussian at which the pixel's transmittance crossed 0.5 (0 = none): the forward's own
 // median decision (forward.cu:368-373), which the backward uses for the median-depth gradient.
 struct ImgLayout {
-	size_t ctl, ranges, tile_count, final_T, n_contrib, med_pos, total;
+	size_t ctl, ranges, tile_count, final_T, n_contrib, med_pos, tile_work, tile_order, total;
 	int gx, gy, T;
 	ImgLayout(int W, int H)
 	{
@@ -51,7 +51,9 @@ struct ImgLayout {
 		final_T = tile_count + align_up(sizeof(uint32_t) * (size_t)T);
 		n_contrib = final_T + align_up(sizeof(float) * (size_t)T * GSR_TILE_PIX);
 		med_pos = n_contrib + align_up(sizeof(uint32_t) * (size_t)T * GSR_TILE_PIX);
-		total = med_pos + align_up(sizeof(uint32_t) * (size_t)T * GSR_TILE_PIX);
+		tile_work = med_pos + align_up(sizeof(uint32_t) * (size_t)T * GSR_TILE_PIX);     // backward only, skewed frames (launch_tile_order)
+		tile_order = tile_work + align_up(sizeof(uint32_t) * (size_t)T);
+		total = tile_order + align_up(sizeof(uint32_t) * (size_t)T);
 	}
 };
 
@@ -120,7 +122,9 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
                       uint32_t* point_list, char* queue, size_t R, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
-                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp, hipStream_t s);
+                          float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp,
+                          const uint32_t* tile_order, hipStream_t s);
+void launch_tile_order_fwd(int T, const uint2* ranges, uint32_t* order, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 
 // --- launchers (gsr_kernels_bwd.hip) ---
 struct BwdArgs {
@@ -166,7 +170,12 @@ struct GsBg {
 	float host[3];         // the values when dptr == nullptr (absent background: zeros)
 	uint32_t* flag_dst;    // word 8 of the scratch's background block
 	uint32_t flag;
+	const uint32_t* tile_order;   // nullptr: workgroup b -> tile by XCD band; else workgroup b -> tile_order[b] (longest walk first)
 };
+// Longest-first tile order for composite_bwd on SKEWED frames (a few tiles with walks many times the mean: a workgroup that
+// starts such a tile late is the kernel's tail): work[t] = the tile's longest walk (max n_contrib), tiles ordered by
+// descending work class (counting sort, 4 classes per octave).  Two small launches, only when the forward saw skew.
+void launch_tile_order(int T, const uint32_t* n_contrib, uint32_t* tile_work, uint32_t* tile_order, hipStream_t s);
 // variant: 0 = default; other values select A/B variants of the kernel (gsr_set_option("bwd_variant", v))
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, const uint2* ranges,
                           const uint32_t* point_list, const GsRec* recs, const uint32_t* goff, const float* final_T,

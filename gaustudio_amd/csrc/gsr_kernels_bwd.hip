@@ -246,8 +246,9 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	__shared__ float4 s_tab[4][8 * GSR_TAB_ROW];            // per-pixel constants of phase 2
 	__shared__ int s_max[4];
 	if (blockIdx.x == 0 && threadIdx.x == 0 && bgv.flag_dst != nullptr) *bgv.flag_dst = bgv.flag;   // regime word (GsBg)
-	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+	// XCD-banded static order, or (skewed frames) longest walk first: launch_tile_order
+	const int tile = bgv.tile_order ? ((int)blockIdx.x < T ? (int)bgv.tile_order[blockIdx.x] : T) : (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((!bgv.tile_order && (int)(blockIdx.x >> 3) >= chunk) || tile >= T) return;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
 	const int tx = tile % gx, ty = tile / gx;
@@ -544,8 +545,9 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	__shared__ __attribute__((aligned(16))) uint8_t s_list[4][4][GSR_BWQ_LIST];
 	__shared__ int s_max[4];
 	if (blockIdx.x == 0 && threadIdx.x == 0 && bgv.flag_dst != nullptr) *bgv.flag_dst = bgv.flag;   // regime word (GsBg)
-	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+	// XCD-banded static order, or (skewed frames) longest walk first: launch_tile_order
+	const int tile = bgv.tile_order ? ((int)blockIdx.x < T ? (int)bgv.tile_order[blockIdx.x] : T) : (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((!bgv.tile_order && (int)(blockIdx.x >> 3) >= chunk) || tile >= T) return;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6, qd = lane >> 4;
 	TM_DECL
@@ -963,6 +965,44 @@ __global__ void bwd_selftest_kernel(const float* __restrict__ in, uint32_t* __re
 void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s)
 {
 	hipLaunchKernelGGL(bwd_selftest_kernel, dim3(1), dim3(1), 0, s, in, out);
+}
+
+// ---- longest-first tile order (skewed frames) ----
+__device__ __forceinline__ uint32_t gs_work_class(uint32_t m)   // 4 classes per octave, monotone in m; < 128
+{
+	if (m < 4u) return m;
+	const int e = 31 - __clz((int)m);
+	return (uint32_t)(4 * (e - 1)) + ((m >> (e - 2)) & 3u);
+}
+__global__ __launch_bounds__(256) void tile_work_kernel(int T, const uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ work)
+{
+	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (tile >= T) return;
+	const uint4 v = reinterpret_cast<const uint4*>(n_contrib + (size_t)tile * GSR_TILE_PIX)[lane];
+	uint32_t m = max(max(v.x, v.y), max(v.z, v.w));
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+	if (lane == 0) work[tile] = m;
+}
+__global__ __launch_bounds__(1024) void tile_order_kernel(int T, const uint32_t* __restrict__ work, uint32_t* __restrict__ order)
+{
+	__shared__ uint32_t s_cnt[128], s_cur[128];
+	const int tid = threadIdx.x;
+	if (tid < 128) s_cnt[tid] = 0u;
+	__syncthreads();
+	for (int t = tid; t < T; t += 1024) atomicAdd(&s_cnt[gs_work_class(work[t])], 1u);
+	__syncthreads();
+	if (tid == 0) {   // descending classes: the longest walks get the first workgroups
+		uint32_t run = 0;
+		for (int c = 127; c >= 0; c--) { s_cur[c] = run; run += s_cnt[c]; }
+	}
+	__syncthreads();
+	for (int t = tid; t < T; t += 1024) order[atomicAdd(&s_cur[gs_work_class(work[t])], 1u)] = (uint32_t)t;
+}
+void launch_tile_order(int T, const uint32_t* n_contrib, uint32_t* tile_work, uint32_t* tile_order, hipStream_t s)
+{
+	hipLaunchKernelGGL(tile_work_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, n_contrib, tile_work);
+	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, T, tile_work, tile_order);
 }
 
 void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, const uint2* ranges,

@@ -884,6 +884,7 @@ __device__ __forceinline__ void gs_partition_segment(const uint64_t* __restrict_
 	const bool in_regs = n <= (uint32_t)NT * RK;
 	uint64_t kreg[RK];
 	unsigned long long mn = ~0ull, mx = 0ull;
+	const unsigned long long kmax_init = 0ull;
 	if (in_regs) {
 #pragma unroll
 		for (int r = 0; r < RK; r++) {
@@ -892,9 +893,14 @@ __device__ __forceinline__ void gs_partition_segment(const uint64_t* __restrict_
 			if (i < n) { mn = min(mn, (unsigned long long)kreg[r]); mx = max(mx, (unsigned long long)kreg[r]); }
 		}
 	} else {
-		for (uint32_t i = tid; i < n; i += NT) {
-			const unsigned long long k = src[i];
-			mn = min(mn, k); mx = max(mx, k);
+		// long lists: eight independent loads in flight per thread and sweep (one load at a time made the 58 k-key list of
+		// the clustered scene take 58 us here: three sweeps of 57 dependent round trips)
+		for (uint32_t i0 = tid; i0 < n; i0 += 8u * NT) {
+			unsigned long long k8[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)u * NT; k8[u] = i < n ? src[i] : kmax_init; }
+#pragma unroll
+			for (int u = 0; u < 8; u++) if (i0 + (uint32_t)u * NT < n) { mn = min(mn, k8[u]); mx = max(mx, k8[u]); }
 		}
 	}
 #pragma unroll
@@ -916,7 +922,13 @@ __device__ __forceinline__ void gs_partition_segment(const uint64_t* __restrict_
 		for (int r = 0; r < RK; r++)
 			if ((uint32_t)tid + (uint32_t)NT * r < n) atomicAdd(&s_off[(uint32_t)((kreg[r] - kmin) >> shift)], 1u);
 	} else {
-		for (uint32_t i = tid; i < n; i += NT) atomicAdd(&s_off[(uint32_t)((src[i] - kmin) >> shift)], 1u);
+		for (uint32_t i0 = tid; i0 < n; i0 += 8u * NT) {
+			unsigned long long k8[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)u * NT; k8[u] = i < n ? src[i] : kmin; }
+#pragma unroll
+			for (int u = 0; u < 8; u++) if (i0 + (uint32_t)u * NT < n) atomicAdd(&s_off[(uint32_t)((k8[u] - kmin) >> shift)], 1u);
+		}
 	}
 	__syncthreads();
 	// exclusive scan of the B counts (4 per thread); how many sort / oversized items this cut produces
@@ -977,9 +989,13 @@ __device__ __forceinline__ void gs_partition_segment(const uint64_t* __restrict_
 			}
 		}
 	} else {
-		for (uint32_t i = tid; i < n; i += NT) {
-			const uint64_t k = src[i];
-			dst[atomicAdd(&s_cur[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
+		for (uint32_t i0 = tid; i0 < n; i0 += 8u * NT) {
+			unsigned long long k8[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)u * NT; k8[u] = i < n ? src[i] : kmin; }
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				if (i0 + (uint32_t)u * NT < n) dst[atomicAdd(&s_cur[(uint32_t)((k8[u] - kmin) >> shift)], 1u)] = k8[u];
 		}
 	}
 	if (fused_out != nullptr && in_regs && s_misc[1] == 0u) {
@@ -1412,7 +1428,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ med_pos_out,
-    const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted)
+    const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted, const uint32_t* __restrict__ tile_order)
 {
 	__shared__ float4 sA[256];
 	__shared__ float4 sB[256];
@@ -1420,8 +1436,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 	// launched ahead of the host's read-back (see bin_scatter_kernel): leave when the binning buffer was too small or
 	// a list is longer than what the sort kernels launched with this call handle (its point_list is not written)
 	if (ctl->num_binned > cap || ctl->max_tile_count > max_sorted) return;
-	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+	// XCD-banded static order, or (skewed frames) longest list first: launch_tile_order_fwd
+	const int tile = tile_order ? ((int)blockIdx.x < T ? (int)tile_order[blockIdx.x] : T) : (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((!tile_order && (int)(blockIdx.x >> 3) >= chunk) || tile >= T) return;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int tx = tile % gx, ty = tile / gx;
@@ -1562,7 +1579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ med_pos_out,
-    GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted)
+    GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted, const uint32_t* __restrict__ tile_order)
 {
 	__shared__ float4 sRec[3 * GSR_FWD_PLANE];   // planes A, B, C (as above), slot 256 of each = the sentinel
 	__shared__ uint16_t sMask[256];
@@ -1573,8 +1590,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 	uint16_t* __restrict__ qmask = gs_qmask_ptr(point_list, num_binned);
 	if (!NOCULL && blockIdx.x == 0 && threadIdx.x == 0) ctl->has_qmask = 1u;
 	if (FX && blockIdx.x == 0 && threadIdx.x == 0) ctl->opts |= GSR_CTL_OPT_FAST_EXP;
-	const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-	if ((int)(blockIdx.x >> 3) >= chunk || tile >= T) return;
+	// XCD-banded static order, or (skewed frames) longest list first: launch_tile_order_fwd
+	const int tile = tile_order ? ((int)blockIdx.x < T ? (int)tile_order[blockIdx.x] : T) : (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((!tile_order && (int)(blockIdx.x >> 3) >= chunk) || tile >= T) return;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, w = tid >> 6, q = lane >> 4;
 	const int tx = tile % gx, ty = tile / gx;
@@ -1719,15 +1737,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 	med_pos_out[(size_t)tile * GSR_TILE_PIX + slot] = med_final;
 }
 
+// Longest-first tile order for composite_fwd on skewed frames (see launch_tile_order in gsr_kernels_bwd.hip for the
+// backward's, which knows the true walk lengths): tiles by descending list-length class, one small workgroup.
+__device__ __forceinline__ uint32_t gs_len_class(uint32_t m)   // 4 classes per octave, monotone; < 128
+{
+	if (m < 4u) return m;
+	const int e = 31 - __clz((int)m);
+	return (uint32_t)(4 * (e - 1)) + ((m >> (e - 2)) & 3u);
+}
+__global__ __launch_bounds__(1024) void tile_order_fwd_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                             const GsCtl* __restrict__ ctl, uint32_t cap)
+{
+	__shared__ uint32_t s_cnt[128], s_cur[128];
+	if (ctl->num_binned > cap) return;
+	const int tid = threadIdx.x;
+	if (tid < 128) s_cnt[tid] = 0u;
+	__syncthreads();
+	for (int t = tid; t < T; t += 1024) atomicAdd(&s_cnt[gs_len_class(ranges[t].y - ranges[t].x)], 1u);
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t run = 0;
+		for (int c = 127; c >= 0; c--) { s_cur[c] = run; run += s_cnt[c]; }
+	}
+	__syncthreads();
+	for (int t = tid; t < T; t += 1024) order[atomicAdd(&s_cur[gs_len_class(ranges[t].y - ranges[t].x)], 1u)] = (uint32_t)t;
+}
+void launch_tile_order_fwd(int T, const uint2* ranges, uint32_t* order, const GsCtl* ctl, uint32_t cap, hipStream_t s)
+{
+	hipLaunchKernelGGL(tile_order_fwd_kernel, dim3(1), dim3(1024), 0, s, T, ranges, order, ctl, cap);
+}
+
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
                           float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos,
-                          GsCtl* ctl_, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp, hipStream_t s)
+                          GsCtl* ctl_, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp,
+                          const uint32_t* tile_order, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
 #define GSR_LAUNCH_FWD(K)                                                                                              \
 	hipLaunchKernelGGL(K, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges, point_list, recs, out_color, \
-	                   out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted)
+	                   out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted, tile_order)
 	if (wave_lists) {
 		const GsCtl* ctl = ctl_;
 		if (nocull) GSR_LAUNCH_FWD(composite_fwd_kernel<true>);

@@ -195,6 +195,8 @@ int gsr_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, co
  *   "bwd_variant"   -1 = auto (gsr_selftest), bit 0 = keep the select on T in composite_bwd, bit 1 = the per-wave
  *                        (8x8) kernel instead of the per-quarter one;
  *   "fast_exp"      0|1  process default of gsr_options.fast_exp (below);
+ *   "tile_order"    1|0  (GSR_TILE_ORDER) backward of a SKEWED frame (longest tile list > 1024 entries and > 4x the mean): run
+ *                        the tiles longest walk first instead of in XCD bands (two small extra launches; changes no result bit);
  *   "roctx"         0|1  (GSR_ROCTX) wrap every stage of gsr_forward / gsr_backward in a roctx range ("gsr.preprocess_fwd",
  *                        "gsr.scan", ... ) for rocprofv3 --marker-trace timelines; the marker library is dlopen()ed, get
  *                        returns 1 only if it was found;

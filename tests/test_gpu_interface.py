@@ -235,3 +235,32 @@ def test_tile_band_sharding_of_one_view():
     for k, v in gfull.items():
         scale = float(v.abs().max())
         assert float((acc[k] - v).abs().max()) <= 1e-5 * scale, k       # two partial sums instead of one: fp32 re-association only
+
+
+def test_longest_first_tile_order_changes_no_bit():
+    """Skewed frames (a tile list > 1024 entries and > 4x the mean; here the clustered bench scene: lists p50 ~ 10, max ~ 58 k) run
+    their tiles longest-first in composite_fwd (by list length, from the SECOND such frame on: the regime is remembered per
+    device) and in composite_bwd (by the forward's walk lengths) instead of in XCD bands -- gsr_set_option("tile_order").  Which
+    workgroup takes which tile changes no output, no per-pixel state and no gradient bit."""
+    from gaustudio_amd import _C
+    from util import hip_backward_raw
+    W = H = 800
+    sc = scenes.make_clustered_scene(300_000, W, cam_distance=11.0, seed=0)
+    cam = scenes.ring_cameras(5, W, H, radius=11.0)[1]
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam, seed=3)
+    res = {}
+    for order in (0, 1):
+        _C.set_option("tile_order", order)
+        try:
+            hip_forward(sc, cam, 3, kw)                       # first frame of the regime: remembers "skewed"
+            hs = hip_forward(sc, cam, 3, kw)                  # second: composite_fwd runs ordered (when enabled)
+            hb = hip_backward_raw(hs, sc, cam, 3, kw, grads)
+        finally:
+            _C.set_option("tile_order", 1)
+        res[order] = (hs, hb)
+    for k in ("color", "depth", "median", "opacity", "radii", "final_T", "n_contrib", "point_list", "ranges"):
+        assert torch.equal(res[0][0][k], res[1][0][k]), k
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "acc"):
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    assert _C.get_option("tile_order") == 1
