@@ -375,6 +375,10 @@ def main():
                     help="N > 1: dense = ONE all-reduce of the flat 236 B/Gaussian gradient buffer; factored = all-gather of the "
                          "per-view colour gradients (12 B/Gaussian/view) + all-reduce of the 44 B/Gaussian geometry block, the SH "
                          "gradient rebuilt locally (gaustudio_amd/parallel.py)")
+    ap.add_argument("--compact", default="none", choices=["none", "view", "view+geometry", "union"],
+                    help="N > 1, --exchange factored: none = dense 12 B/Gaussian colour slots; view = per-view packed messages (header + "
+                         "12 B per VISIBLE Gaussian, counts agreed off the critical path); view+geometry = also the geometry all-reduce "
+                         "on the union of the step's views; union = the round-3 form (mask all-reduce + compacted buffers)")
     ap.add_argument("--epilogue-separate", action="store_true", help="C3-extract: mask, depth_to_points and depth_to_normals as separate steps (torch ops + two kernels) instead of the fused gsr_depth_epilogue")
     ap.add_argument("--tsdf-linear", action="store_true", help="C3-extract: integrate the point map as a flat list (256 consecutive points per workgroup) instead of 32x32 patches")
     ap.add_argument("--views-per-rank", type=int, default=1, help="cameras rendered (and accumulated) per rank and step")
@@ -463,7 +467,7 @@ def main():
     bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()), roles=params)
     fx = None
     if factored:
-        fx = parallel.FactoredGradExchange(params, views_per_rank=V)
+        fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact={"none": False, "union": True}.get(a.compact, a.compact))
         campos_all = torch.stack([c.campos for c in all_cams]).to(dev)
     state = {}
     comm_ev = []       # (backward enqueued, exchange finished) events of the timed steps, N > 1 only
@@ -496,6 +500,8 @@ def main():
                 # gradients are born in the flat all-reduce buffer; the SH ranges are reduced while the backward runs
                 bucket.arm(a.overlap_chunks)
             color, radii, depth, median, opac = render(v, r)
+            if factored:
+                fx.visible(v, radii)                        # --compact view: header + count gather right after the forward (no-op otherwise)
             torch.autograd.backward([color, depth, median, opac], grads)
             if last:
                 state["out"] = (color, radii, depth, median, opac)

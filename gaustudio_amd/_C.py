@@ -119,6 +119,63 @@ def sh_grad_from_colors(means3D, campos, colors, degree, out):
     return out
 
 
+# ---- compacted rows for the multi-GPU exchange (include/gsrast.h; csrc/gsr_comm.hip) ------------------------------------
+def msg_header_words(P):
+    L = lib()
+    L.gsr_msg_header_words.restype = ctypes.c_size_t
+    return int(L.gsr_msg_header_words(ctypes.c_int(int(P))))
+
+
+def _rc(L, rc):
+    if rc < 0:
+        raise _err(L, rc)
+
+
+def visible_index(radii, msg, counts):
+    """Header (K, block bases, mask) of the Gaussians with radii > 0 into the int32 tensor `msg`; counts: int32 scratch [ceil(P/256)]."""
+    L = lib()
+    with torch.cuda.device(radii.device):
+        _rc(L, L.gsr_visible_index(ctypes.c_int(radii.numel()), _ptr(radii), _ptr(msg), _ptr(counts), _stream(radii.device)))
+
+
+def union_index(P, msgs, offsets, out_hdr, counts):
+    """Header of the OR of the N = offsets.numel() messages' masks; message r starts at word offsets[r] (int64, device) of the
+    int32 tensor msgs."""
+    L = lib()
+    with torch.cuda.device(msgs.device):
+        _rc(L, L.gsr_union_index(ctypes.c_int(int(P)), ctypes.c_int(int(offsets.numel())), _ptr(msgs), _ptr(offsets),
+                                 _ptr(out_hdr), _ptr(counts), _stream(msgs.device)))
+
+
+def pack_rows(hdr, src, dst, dst_stride, col0=0):
+    """dst[row * dst_stride + col0 + c] = src[g, c] for the header's Gaussians g (src float32 [P, C], dst float32 flat)."""
+    L = lib()
+    P, C = src.shape[0], src.numel() // max(src.shape[0], 1)
+    with torch.cuda.device(src.device):
+        _rc(L, L.gsr_pack_rows(ctypes.c_int(P), ctypes.c_int(C), _ptr(hdr), _ptr(src), _ptr(dst), ctypes.c_int(int(dst_stride)),
+                               ctypes.c_int(int(col0)), _stream(src.device)))
+
+
+def unpack_rows(hdr, src, src_stride, col0, dst):
+    """dst[g, c] = src[row * src_stride + col0 + c] for the header's Gaussians g; the other rows of dst stay as they are."""
+    L = lib()
+    P, C = dst.shape[0], dst.numel() // max(dst.shape[0], 1)
+    with torch.cuda.device(dst.device):
+        _rc(L, L.gsr_unpack_rows(ctypes.c_int(P), ctypes.c_int(C), _ptr(hdr), _ptr(src), ctypes.c_int(int(src_stride)),
+                                 ctypes.c_int(int(col0)), _ptr(dst), _stream(dst.device)))
+
+
+def sh_grad_from_packed(means3D, campos, msgs, offsets, degree, out):
+    """sh_grad_from_colors reading N = offsets.numel() packed messages (header + rows of 3 floats, message r at word offsets[r] of the
+    int32 tensor msgs) instead of dense colours."""
+    L = lib()
+    P, M = out.shape[0], out.shape[1]
+    with torch.cuda.device(out.device):
+        _rc(L, L.gsr_sh_grad_from_packed(ctypes.c_int(P), ctypes.c_int(int(degree)), ctypes.c_int(M), ctypes.c_int(int(offsets.numel())),
+                                         _ptr(means3D), _ptr(campos), _ptr(msgs), _ptr(offsets), _ptr(out), _stream(out.device)))
+    return out
+
+
 def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None, colors_out=None):
     """One-shot destination tensors [dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations] for the next
     rasterize_gaussians_backward whose inputs [means3D, sh, scales, rotations] have the data pointers `keys`

@@ -913,8 +913,24 @@ int gsr_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, co
 	if (!means3D || !dL_dsh || (N > 0 && (!campos || !colors)))
 		return fail(GSR_ERR_ARG, "gsr_sh_grad_from_colors: NULL argument", __FILE__, __LINE__);
 	if (!is_device_ptr(campos)) return fail(GSR_ERR_ARG, "gsr_sh_grad_from_colors: campos must be device memory", __FILE__, __LINE__);
-	launch_sh_grad_from_colors(P, D, M, N, means3D, campos, colors, dL_dsh, (hipStream_t)stream);
+	launch_sh_grad_from_colors(P, D, M, N, means3D, campos, colors, nullptr, nullptr, 0u, dL_dsh, (hipStream_t)stream);
 	STAGE_CHECK("sh_grad_from_colors", 0, (hipStream_t)stream);
+	return GSR_OK;
+}
+
+int gsr_sh_grad_from_packed(int P, int D, int M, int N, const float* means3D, const float* campos, const uint32_t* msgs,
+                            const unsigned long long* msg_offsets, float* dL_dsh, void* stream)
+{
+	g_err.clear();
+	if (P <= 0 || M <= 0) return GSR_OK;
+	if (N < 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M)
+		return fail(GSR_ERR_ARG, "gsr_sh_grad_from_packed: bad N / SH degree", __FILE__, __LINE__);
+	if (!means3D || !dL_dsh || (N > 0 && (!campos || !msgs || !msg_offsets)))
+		return fail(GSR_ERR_ARG, "gsr_sh_grad_from_packed: NULL argument", __FILE__, __LINE__);
+	if (!is_device_ptr(campos)) return fail(GSR_ERR_ARG, "gsr_sh_grad_from_packed: campos must be device memory", __FILE__, __LINE__);
+	launch_sh_grad_from_colors(P, D, M, N, means3D, campos, nullptr, msgs, msg_offsets, (uint32_t)gsr_msg_header_words(P), dL_dsh,
+	                           (hipStream_t)stream);
+	STAGE_CHECK("sh_grad_from_packed", 0, (hipStream_t)stream);
 	return GSR_OK;
 }
 

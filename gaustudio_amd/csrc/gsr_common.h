@@ -546,3 +546,19 @@ __device__ __forceinline__ void gs_row_from_lds(const float* __restrict__ row, f
 		for (int i = 0; i < RF; i++) out[i] = row[i];
 	}
 }
+
+// ---- packed row messages of the multi-GPU exchange (layout: gsr_comm.hip) ----
+__device__ __forceinline__ uint32_t gs_msg_nb(int P) { return (uint32_t)((P + 255) / 256); }
+__device__ __forceinline__ uint32_t gs_msg_nw(int P) { return (uint32_t)((P + 31) / 32); }
+// row of Gaussian idx in the message `msg` (false: not visible in that view, it has no row)
+__device__ __forceinline__ bool gs_msg_lookup(const uint32_t* __restrict__ msg, int P, int idx, uint32_t& row)
+{
+	const uint32_t nb = gs_msg_nb(P);
+	const uint32_t* mask = msg + 4 + nb;
+	const uint32_t w = (uint32_t)idx >> 5, word = mask[w];
+	if (!((word >> (idx & 31)) & 1u)) return false;
+	uint32_t r = msg[4 + ((uint32_t)idx >> 8)];
+	for (uint32_t k = ((uint32_t)idx >> 8) * 8; k < w; k++) r += (uint32_t)__popc(mask[k]);
+	row = r + (uint32_t)__popc(word & ((1u << (idx & 31)) - 1u));
+	return true;
+}

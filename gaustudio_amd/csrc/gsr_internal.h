@@ -195,7 +195,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s);
 // dL_dsh[P,M,3] = sum over N views of basis(dir) (x) colors[r][g] (gaustudio_amd/parallel.py FactoredGradExchange)
 void launch_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, const float* campos, const float* colors,
-                                float* dL_dsh, hipStream_t s);
+                                const uint32_t* msgs, const unsigned long long* msg_off, uint32_t hdr_words, float* dL_dsh, hipStream_t s);
 void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint32_t* goff, const float* rows,
                          const uint8_t* row_flags,
                          float* sums10, hipStream_t s);

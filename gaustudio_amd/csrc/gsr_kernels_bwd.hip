@@ -1697,7 +1697,10 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 template <int D, bool COOP>
 __global__ __launch_bounds__(256) void sh_grad_from_colors_kernel(int P, int M, int N, const float* __restrict__ means3D,
                                                                   const float* __restrict__ campos,   // [N,3]
-                                                                  const float* __restrict__ colors,   // [N,P,3]
+                                                                  const float* __restrict__ colors,   // [N,P,3], or nullptr:
+                                                                  const uint32_t* __restrict__ msgs,  // N packed messages (gsr_comm.hip) at
+                                                                  const unsigned long long* __restrict__ msg_off,   // word offsets msg_off[r]
+                                                                  uint32_t hdr_words,
                                                                   float* __restrict__ dL_dsh)
 {
 	extern __shared__ __attribute__((aligned(16))) float sh_slab[];
@@ -1716,7 +1719,15 @@ __global__ __launch_bounds__(256) void sh_grad_from_colors_kernel(int P, int M, 
 		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
 		bool first = true;
 		for (int r = 0; r < N; r++) {
-			const float* c = colors + ((size_t)r * P + idx) * 3;
+			const float* c;
+			if (msgs != nullptr) {   // compacted view: the Gaussian has a row only where it was visible
+				const uint32_t* m = msgs + msg_off[r];
+				uint32_t row;
+				if (!gs_msg_lookup(m, P, idx, row)) continue;
+				c = reinterpret_cast<const float*>(m + hdr_words) + (size_t)row * 3;
+			} else {
+				c = colors + ((size_t)r * P + idx) * 3;
+			}
 			const float c0 = c[0], c1 = c[1], c2 = c[2];
 			if (c0 == 0.f && c1 == 0.f && c2 == 0.f) continue;   // culled in view r (or no gradient): contributes +0
 			const float3 d = {m.x - campos[3 * r], m.y - campos[3 * r + 1], m.z - campos[3 * r + 2]};
@@ -1756,14 +1767,14 @@ __global__ __launch_bounds__(256) void sh_grad_from_colors_kernel(int P, int M, 
 }
 
 void launch_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, const float* campos, const float* colors,
-                                float* dL_dsh, hipStream_t s)
+                                const uint32_t* msgs, const unsigned long long* msg_off, uint32_t hdr_words, float* dL_dsh, hipStream_t s)
 {
 	const dim3 grid((P + 255) / 256), block(256);
 	const bool coop = M == (D + 1) * (D + 1) && ((uintptr_t)dL_dsh % 16 == 0);
 #define GSR_LAUNCH_SGC(DEG, CO)                                                                                    \
 	hipLaunchKernelGGL((sh_grad_from_colors_kernel<DEG, CO>), grid, block,                                             \
 	                   (CO) ? sizeof(float) * 256 * gs_row_stride<(DEG + 1) * (DEG + 1) * 3>() : 0, s, P, M, N, means3D, campos, \
-	                   colors, dL_dsh)
+	                   colors, msgs, msg_off, hdr_words, dL_dsh)
 	switch (D) {
 		case 0: if (coop) GSR_LAUNCH_SGC(0, true); else GSR_LAUNCH_SGC(0, false); break;
 		case 1: if (coop) GSR_LAUNCH_SGC(1, true); else GSR_LAUNCH_SGC(1, false); break;

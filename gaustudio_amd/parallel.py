@@ -209,6 +209,41 @@ def allreduce_gaussian_grads(bucket: FlatGradBucket, group: Optional[dist.Proces
 GEOMETRY_ROLES = ("means3D", "opacities", "scales", "rotations")     # 3 + 1 + 3 + 4 = 11 floats per Gaussian
 
 
+class _HipPacked:
+    """The packed-message primitives of csrc/gsr_comm.hip (include/gsrast.h) on device tensors; tests substitute a torch
+    restatement on CPU tensors (tests/packed_ref.py) through FactoredGradExchange(packed=...)."""
+
+    @staticmethod
+    def header_words(P):
+        from . import _C
+        return _C.msg_header_words(P)
+
+    @staticmethod
+    def visible_index(radii, hdr, scratch):
+        from . import _C
+        _C.visible_index(radii, hdr, scratch)
+
+    @staticmethod
+    def union_index(P, msgs, offsets, out_hdr, scratch):
+        from . import _C
+        _C.union_index(P, msgs, offsets, out_hdr, scratch)
+
+    @staticmethod
+    def pack_rows(hdr, src, dst, dst_stride, col0=0):
+        from . import _C
+        _C.pack_rows(hdr, src, dst, dst_stride, col0)
+
+    @staticmethod
+    def unpack_rows(hdr, src, src_stride, col0, dst):
+        from . import _C
+        _C.unpack_rows(hdr, src, src_stride, col0, dst)
+
+    @staticmethod
+    def sh_from_packed(means3D, campos, msgs, offsets, D, out):
+        from . import _C
+        _C.sh_grad_from_packed(means3D, campos, msgs, offsets, D, out)
+
+
 class FactoredGradExchange:
     """The gradient exchange of a multi-GPU step in FACTORED form (new design).
 
@@ -238,13 +273,22 @@ class FactoredGradExchange:
     1000 iterations) -- given per step to arm() / exchange(); all views of a step must use the same one, and a mismatch
     raises instead of silently rebuilding gradients for coefficients the renders did not use.
 
-    `compact=True` additionally exchanges only the Gaussians that are visible (radii > 0 <=> a non-zero colour OR
+    `compact="view"` (round 4): PER-VIEW compaction of the colour slots.  A view of a real capture sees a fraction of the
+    scene (cameras inside a 360-degree scene: 14-19 % of the Gaussians per view, tools/comm_model.py), and dRGB of a Gaussian
+    culled in a view is exactly zero.  After the forward of view v the caller hands over its `radii`
+    (`fx.visible(v, radii)`): the visibility header (count, block bases, bit mask: P / 8 bytes) is built and the counts
+    of all ranks gathered right there, off the critical path; when the backward calls back, the view's K visible rows are
+    packed behind the header and ONE all-gather moves `header + 12 B x max-over-ranks K` per rank instead of 12 B x P; the
+    SH gradient is rebuilt straight from the packed messages (gsr_sh_grad_from_packed: same arithmetic, same order, same
+    bits).  `compact="view+geometry"` also cuts the geometry all-reduce down to the UNION of the step's views (the OR of the
+    gathered masks -- every rank already holds them, no mask all-reduce; one host synchronisation for the row count).
+    `compact=True` (round 3; kept): exchanges only the Gaussians that are visible (radii > 0 <=> a non-zero colour OR
     geometry gradient row) in at least one view of the step: one bit-mask all-reduce, then compacted buffers (it costs a
     host synchronisation for the row count, and the mask must be agreed first: no early all-gather in this form).
     Runs on CPU tensors with the "gloo" backend when `sh_from_colors` is given (tests; the product kernel is HIP only)."""
 
-    def __init__(self, params_by_role: dict, views_per_rank: int = 1, sh_degree: Optional[int] = None, group=None, compact: bool = False,
-                 sh_from_colors=None, early: bool = True):
+    def __init__(self, params_by_role: dict, views_per_rank: int = 1, sh_degree: Optional[int] = None, group=None, compact=False,
+                 sh_from_colors=None, early: bool = True, packed=None):
         if set(params_by_role) != set(ARENA_ROLES):
             raise ValueError(f"params_by_role must name exactly {ARENA_ROLES}")
         self.p = dict(params_by_role)
@@ -253,8 +297,13 @@ class FactoredGradExchange:
         self.rank = dist.get_rank(group) if _multi(group) else 0
         self.V = int(views_per_rank)
         self.D = None if sh_degree is None else int(sh_degree)      # default for steps that do not name their degree
-        self.compact = bool(compact)
+        if compact not in (False, True, "view", "view+geometry"):
+            raise ValueError('compact must be False, True, "view" or "view+geometry"')
+        self.by_view = compact in ("view", "view+geometry")      # per-view packed colour messages
+        self.union_geometry = compact == "view+geometry"
+        self.compact = compact is True                            # round-3 form: union mask agreed by an all-reduce
         self.early = bool(early) and not self.compact
+        self._pk = packed if packed is not None else _HipPacked
         self._sh_from_colors = sh_from_colors
         means = self.p["means3D"]
         dev, self.P = means.device, means.shape[0]
@@ -264,9 +313,22 @@ class FactoredGradExchange:
         self.M = self.p["shs"].shape[1]
         self._geo_sizes = [self.p[r].numel() for r in GEOMETRY_ROLES]
         self.geo = torch.zeros(sum(self._geo_sizes), dtype=torch.float32, device=dev)
-        self.colors = torch.zeros((self.V, self.world, self.P, 3), dtype=torch.float32, device=dev)     # view-major
+        if self.by_view:
+            self.Hw = int(self._pk.header_words(self.P))
+            self.Lmax = self.Hw + 3 * self.P                           # words of a message whose view sees everything
+            self.colors = torch.zeros((self.V, self.P, 3), dtype=torch.float32, device=dev)        # own views only, dense
+            self.hdr = torch.zeros((self.V, self.Hw), dtype=torch.int32, device=dev)
+            self.msgs = torch.zeros((self.V, self.world * self.Lmax), dtype=torch.int32, device=dev)
+            self.counts = torch.zeros((self.V, self.world), dtype=torch.int32, device=dev)
+            self._scratch = torch.zeros((self.P + 255) // 256, dtype=torch.int32, device=dev)
+            self.hdr_union = torch.zeros(self.Hw, dtype=torch.int32, device=dev)
+        else:
+            self.colors = torch.zeros((self.V, self.world, self.P, 3), dtype=torch.float32, device=dev)     # view-major
         self.sh_grad = torch.empty((self.P, self.M, 3), dtype=torch.float32, device=dev)
-        self.stats = {"steps": 0, "rows_exchanged": 0, "early_allgathers": 0}
+        self.stats = {"steps": 0, "rows_exchanged": 0, "early_allgathers": 0, "color_rows_sent": 0, "geometry_rows": 0}
+        self._count_works = {}    # local view -> work handle of the all-gather of its visible count
+        self._seen = set()        # local views whose radii arrived (visible())
+        self._L = {}              # local view -> message length (words) agreed for this step
         self._works = {}          # local view -> work handle of its early all-gather
         self._step_degrees = []   # degrees the step's armed backwards were rendered with
         self._order = torch.tensor(self.view_order(), dtype=torch.long, device=dev)
@@ -293,6 +355,15 @@ class FactoredGradExchange:
 
     def payload(self):
         n = max(1, self.stats["steps"])
+        if self.by_view:
+            crow = self.stats["color_rows_sent"] / n               # sum over this rank's views of the agreed row capacity
+            grow = self.stats["geometry_rows"] / n if self.union_geometry else self.P
+            hdrb = self.Hw * 4 * self.V
+            return {"payload_bytes_per_rank": int(crow * 12 + hdrb + grow * 44), "allreduce_bytes": int(grow * 44),
+                    "allgather_bytes_sent": int(crow * 12 + hdrb), "allgather_bytes_received": int((crow * 12 + hdrb) * (self.world - 1)),
+                    "dense_payload_bytes_per_rank": self.P * (self.M * 3 + 11) * 4, "color_rows_per_view": crow / self.V,
+                    "geometry_rows": grow, "rows_total": self.P, "compacted": "view+geometry" if self.union_geometry else "view",
+                    "early_allgathers_per_step": self.stats["early_allgathers"] / n}
         rows = self.stats["rows_exchanged"] / n if self.compact else self.P
         sent = rows * (44 + 12 * self.V)
         return {"payload_bytes_per_rank": int(sent), "allreduce_bytes": int(rows * 44), "allgather_bytes_sent": int(rows * 12 * self.V),
@@ -308,7 +379,7 @@ class FactoredGradExchange:
         from . import _C
         if sh_degree is not None:
             self._step_degrees.append(int(sh_degree))
-        slot = self.colors[v, self.rank]
+        slot = self.colors[v] if self.by_view else self.colors[v, self.rank]
         fresh = all(self.p[r].grad is None for r in ARENA_ROLES)
         outs = []
         if v == 0 and fresh and self.geo.is_cuda:
@@ -316,9 +387,45 @@ class FactoredGradExchange:
             outs = [g["means3D"], self.sh_grad, g["opacities"], g["scales"], g["rotations"]]     # slot 1 (dL_dsh) is ignored
         keys = [int(self.p[r].data_ptr()) for r in _KEY_ROLES]
         hook = None
-        if self.early and _multi(self.group):
+        if self.early and (_multi(self.group) or self.by_view):
             hook = lambda v=v: self._on_colors_ready(v)
         _C.set_grad_arena(outs, keys, 1, hook, colors_out=slot)
+
+    def visible(self, v: int, radii: torch.Tensor):
+        """compact="view": right after the FORWARD of local view v, with the `radii` it returned -- builds the view's
+        visibility header and gathers the visible counts of all ranks (asynchronously: nothing here waits)."""
+        if not self.by_view:
+            return
+        self._pk.visible_index(radii.detach().contiguous(), self.hdr[v], self._scratch)
+        if _multi(self.group):
+            self._count_works[v] = dist.all_gather_into_tensor(self.counts[v], self.hdr[v][0:1], group=self.group, async_op=True)
+        else:
+            self.counts[v, 0:1].copy_(self.hdr[v][0:1])
+        self._seen.add(v)
+
+    def _send_view(self, v: int):
+        """compact="view": packs view v's visible rows behind its header and starts the all-gather of the messages.  The
+        message length is the same on every rank: header + 3 floats x the LARGEST visible count of the view over the ranks
+        (known from the counts gathered after the forward; reading it is the only host synchronisation, and at that point
+        the device still has the rest of the backward queued)."""
+        if v not in self._seen:
+            raise RuntimeError(f'FactoredGradExchange(compact="view"): call visible({v}, radii) after the forward of local view {v}')
+        w = self._count_works.pop(v, None)
+        if w is not None:
+            w.wait()
+        kcap = int(self.counts[v].max().item())
+        L = self.Hw + 3 * kcap
+        buf = self.msgs[v][: self.world * L].view(self.world, L)
+        mine = buf[self.rank]
+        mine[: self.Hw].copy_(self.hdr[v])
+        if kcap > 0:
+            self._pk.pack_rows(self.hdr[v], self.colors[v], mine[self.Hw:].view(torch.float32), 3, 0)
+        self._L[v] = L
+        self.stats["color_rows_sent"] += kcap
+        if _multi(self.group):
+            self._works[v] = _all_gather_in_place(buf, self.rank, 1, self.group)
+        else:
+            self._works[v] = None
 
     def _on_colors_ready(self, v: int):
         """Called by the backward armed for local view v (csrc/torch_binding.cpp) right after its geometry stage has been
@@ -327,7 +434,10 @@ class FactoredGradExchange:
         step's remaining views -- compute."""
         if v in self._works:
             return
-        self._works[v] = _all_gather_in_place(self.colors[v], self.rank, 1, self.group)
+        if self.by_view:
+            self._send_view(v)
+        else:
+            self._works[v] = _all_gather_in_place(self.colors[v], self.rank, 1, self.group)
         self.stats["early_allgathers"] += 1
 
     def _step_degree(self, sh_degree):
@@ -361,6 +471,8 @@ class FactoredGradExchange:
         multi = _multi(self.group)
         rows = None
         w2 = None
+        if self.by_view:
+            return self._exchange_by_view(campos_all, D, views, multi)
         if multi and self.compact:
             mine = self.colors[:, self.rank]                  # [V, P, 3]
             # rows with a non-zero gradient in ANY view of ANY rank (a culled Gaussian's rows are exactly zero): every one of
@@ -412,6 +524,58 @@ class FactoredGradExchange:
             self.p[r].grad = views[r]
         self.p["shs"].grad = self.sh_grad
         self.stats["steps"] += 1
+
+
+def _exchange_by_view_impl(self, campos_all, D, views, multi):
+    """compact="view" / "view+geometry" (FactoredGradExchange._exchange_by_view)."""
+    P, V, W, dev = self.P, self.V, self.world, self.geo.device
+    for v in range(V):                               # views whose message did not leave from inside their backward
+        if v not in self._works:
+            self._send_view(v)
+    w2 = None
+    if multi and not self.union_geometry:
+        w2 = dist.all_reduce(self.geo, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    for v in range(V):
+        if self._works[v] is not None:
+            self._works[v].wait()
+    # word offset of every message in memory order (local view major, rank minor), computed on the device from the counts
+    Lv = self.Hw + 3 * self.counts.max(dim=1).values.to(torch.int64)                                        # [V]
+    offsets = (torch.arange(V, device=dev, dtype=torch.int64) * (W * self.Lmax))[:, None] + \
+        torch.arange(W, device=dev, dtype=torch.int64)[None, :] * Lv[:, None]
+    offsets = offsets.reshape(-1).contiguous()
+    msgs = self.msgs.view(-1)
+    campos = campos_all.detach().to(dev, torch.float32)[self._order].contiguous()
+    self._pk.sh_from_packed(self.p["means3D"].detach(), campos, msgs, offsets, D, self.sh_grad)
+    if self.union_geometry:
+        # rows with a non-zero geometry gradient anywhere in the step = the OR of the gathered masks (identical on every rank)
+        self._pk.union_index(P, msgs, offsets, self.hdr_union, self._scratch)
+        K = int(self.hdr_union[0].item())               # host synchronisation: the all-reduce below is sized by it
+        self.stats["geometry_rows"] += K
+        if K > 0:
+            rows = torch.empty((K, 11), dtype=torch.float32, device=dev)
+            col = 0
+            for r in GEOMETRY_ROLES:
+                n = views[r].reshape(P, -1).shape[1]
+                self._pk.pack_rows(self.hdr_union, views[r].reshape(P, -1), rows.view(-1), 11, col)
+                col += n
+            if multi:
+                dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
+            col = 0
+            for r in GEOMETRY_ROLES:
+                n = views[r].reshape(P, -1).shape[1]
+                self._pk.unpack_rows(self.hdr_union, rows.view(-1), 11, col, views[r].reshape(P, -1))
+                col += n
+    if w2 is not None:
+        w2.wait()
+    for r in GEOMETRY_ROLES:
+        self.p[r].grad = views[r]
+    self.p["shs"].grad = self.sh_grad
+    self._works, self._L = {}, {}
+    self._seen = set()
+    self.stats["steps"] += 1
+
+
+FactoredGradExchange._exchange_by_view = _exchange_by_view_impl
 
 
 def _all_gather_in_place(buf: torch.Tensor, rank: int, V: int, group):

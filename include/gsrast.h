@@ -185,6 +185,25 @@ int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int
 int gsr_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, const float* campos, const float* colors,
                             float* dL_dsh, void* stream);
 
+/* ---- compacted rows for the multi-GPU exchange (new; gaustudio_amd/parallel.py FactoredGradExchange(compact="view")) ----
+ * A view of a real capture sees a fraction of the scene and the gradient rows of a Gaussian culled in a view are exactly zero,
+ * so a view's colour gradients travel as a MESSAGE of 32-bit words:
+ *   [0] K = visible Gaussians (radii > 0), [1] P, [2..3] 0; ceil(P/256) block bases (visible Gaussians in front of each
+ *   256-Gaussian block); ceil(P/32) mask words (bit g & 31 of word g >> 5); padding to gsr_msg_header_words(P); then K rows.
+ * gsr_visible_index builds the header from `radii` (right after the forward, off the critical path; scratch_counts:
+ * ceil(P/256) words of device scratch), gsr_union_index the header of the OR of N messages' masks (message r starts at word
+ * msg_offsets[r] of msgs; offsets in device memory); gsr_pack_rows copies the rows in[P,C] of the header's Gaussians to out[row * out_stride + col0 ..], gsr_unpack_rows
+ * the other way (rows of other Gaussians are left untouched); gsr_sh_grad_from_packed is gsr_sh_grad_from_colors reading N
+ * messages (rows of 3 floats behind each header) instead of dense [N,P,3] colours: same arithmetic, same order, same bits. */
+size_t gsr_msg_header_words(int P);
+int gsr_visible_index(int P, const int* radii, uint32_t* msg, uint32_t* scratch_counts, void* stream);
+int gsr_union_index(int P, int N, const uint32_t* msgs, const unsigned long long* msg_offsets, uint32_t* out_hdr, uint32_t* scratch_counts,
+                    void* stream);
+int gsr_pack_rows(int P, int C, const uint32_t* hdr, const float* in, float* out, int out_stride, int col0, void* stream);
+int gsr_unpack_rows(int P, int C, const uint32_t* hdr, const float* in, int in_stride, int col0, float* out, void* stream);
+int gsr_sh_grad_from_packed(int P, int D, int M, int N, const float* means3D, const float* campos, const uint32_t* msgs,
+                            const unsigned long long* msg_offsets, float* dL_dsh, void* stream);
+
 /* Process-wide tunables (also read from the environment at load: GSR_TIGHT_BINNING, GSR_CULL, GSR_FWD_VARIANT,
  * GSR_BWD_VARIANT, GSR_SPECULATIVE).  The first five never change a bit of the forward (the backward variants add the
  * same terms in another order); they exist for A/B measurements and parity tests:

@@ -175,6 +175,8 @@ def _worker_factored(rank, world, port, out_dir, V, compact):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if isinstance(compact, str):
+            return _worker_factored_by_view(rank, world, out_dir, V, compact)
         views, means, campos, (P, M) = _factored_inputs(world, V)
         shapes = dict(means3D=(P, 3), shs=(P, M, 3), opacities=(P, 1), scales=(P, 3), rotations=(P, 4))
         params = {k: (means.clone() if k == "means3D" else torch.zeros(shp)).requires_grad_(True) for k, shp in shapes.items()}
@@ -214,7 +216,36 @@ def _worker_factored(rank, world, port, out_dir, V, compact):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("V,compact", [(1, False), (2, False), (1, True)])
+def _worker_factored_by_view(rank, world, out_dir, V, compact):
+    """compact="view" / "view+geometry" on CPU tensors: the packed-message primitives come from tests/packed_ref.py (the HIP
+    kernels are held against the same restatement on the GPU: test_packed_messages_hip_vs_torch)."""
+    from packed_ref import TorchPacked
+    TorchPacked.sh_from_colors = staticmethod(_sh_from_colors_torch)
+    views, means, campos, (P, M) = _factored_inputs(world, V)
+    shapes = dict(means3D=(P, 3), shs=(P, M, 3), opacities=(P, 1), scales=(P, 3), rotations=(P, 4))
+    params = {k: (means.clone() if k == "means3D" else torch.zeros(shp)).requires_grad_(True) for k, shp in shapes.items()}
+    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact, packed=TorchPacked)
+    assert fx.by_view and fx.colors.shape == (V, P, 3)
+    with pytest.raises(RuntimeError, match="call visible"):
+        fx._send_view(0)                                   # the radii of the view have not arrived
+    for v in range(V):
+        gv = views[rank * V + v]
+        radii = (gv["colors"].abs().amax(1) > 0).int() * 3          # culled rows of the inputs are all-zero rows
+        fx.visible(v, radii)                                         # right after the "forward"
+        fx.colors[v].copy_(gv["colors"])
+        fx._on_colors_ready(v)                                       # the backward's callback: pack + all-gather start
+        for k in parallel.GEOMETRY_ROLES:
+            params[k].grad = gv[k].clone() if params[k].grad is None else params[k].grad + gv[k]
+    assert fx.stats["early_allgathers"] == V
+    fx.exchange(campos, sh_degree=3)
+    pay = fx.payload()
+    assert pay["color_rows_per_view"] < 0.8 * P and pay["allgather_bytes_sent"] < 12 * P * V      # a third of the rows are culled per view
+    if compact == "view+geometry":
+        assert 0 < pay["geometry_rows"] <= P
+    torch.save({k: p.grad.clone() for k, p in params.items()}, os.path.join(out_dir, f"fx_rank{rank}.pt"))
+
+
+@pytest.mark.parametrize("V,compact", [(1, False), (2, False), (1, True), (1, "view"), (2, "view"), (2, "view+geometry")])
 def test_factored_exchange_equals_dense_accumulation(tmp_path, V, compact):
     """FactoredGradExchange (all-gather of per-view colour gradients + all-reduce of the geometry block + local rebuild of the
     SH gradient) == the sum over all world * V views of the dense per-view gradients, on every rank; with and without
@@ -228,7 +259,7 @@ def test_factored_exchange_equals_dense_accumulation(tmp_path, V, compact):
     got = [torch.load(os.path.join(tmp_path, f"fx_rank{r}.pt")) for r in range(world)]
     for k in want:
         assert torch.equal(got[0][k], got[1][k]), k                           # replicated result
-        tol = 0.0 if k == "shs" else 1e-6 * float(want[k].abs().max())         # geometry: (a + b) + c vs the ring's order
+        tol = 0.0 if k == "shs" else 1e-6 * float(want[k].abs().max())         # geometry: (a + b) + c vs the ring's order; dL_dsh BIT-equal
         assert float((got[0][k] - want[k]).abs().max()) <= tol, k
     assert float(want["shs"].abs().max()) > 0
 
@@ -338,13 +369,14 @@ def _factored_step(sc, my_cams, all_cams, dev, V, D=3, compact=False):
         fx.arm(v, sh_degree=D)
         out = GaussianRasterizer(rs)(means3D=params["means3D"], means2D=m2, opacities=params["opacities"], shs=params["shs"],
                                      scales=params["scales"], rotations=params["rotations"])
+        fx.visible(v, out[1])                                  # compact="view": the view's radii -> header + count gather (no-op otherwise)
         g = [t.to(dev) for t in scenes.make_output_grads(cam, seed=5)]
         torch.autograd.backward([out[0], out[2], out[3], out[4]], g)
         assert params["shs"].grad is None                      # the factored backward produces no dL_dsh
     if V >= 1 and fx.geo.is_cuda:
         gv = fx.geo_views()
         assert all(params[r].grad.data_ptr() == gv[r].data_ptr() for r in parallel.GEOMETRY_ROLES)   # born in the all-reduce buffer
-    if parallel._multi(None) and not compact:
+    if (parallel._multi(None) and not compact) or isinstance(compact, str):
         assert fx.stats["early_allgathers"] == V       # every view's all-gather started from inside its backward
     fx.exchange(torch.stack([c.campos for c in all_cams]).to(dev), sh_degree=D)
     return {k: p.grad.cpu() for k, p in params.items()}, fx
@@ -373,15 +405,17 @@ def _gpu_worker_factored(rank, world, port, out_dir, compact):
         dev = torch.device("cuda", 0)
         sc, cams = _scene_and_cams(world)
         got, fx = _factored_step(sc, parallel.shard_views(cams), cams, dev, V=1, compact=compact)
-        if compact:
+        if compact is True:
             assert fx.payload()["rows_per_step"] <= 1500
+        elif compact:
+            assert fx.payload()["color_rows_per_view"] <= 1500 and fx.payload()["compacted"] == compact
         torch.save(got, os.path.join(out_dir, f"fxgpu_rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("compact", [False, True, "view", "view+geometry"])
 def test_two_ranks_factored_exchange_real_kernels(tmp_path, compact):
     """Two ranks (gloo, one GPU), one camera each, the HIP kernels: after FactoredGradExchange every rank holds the gradients
     of both views -- dL_dsh bit-identical to single-process accumulation (same arithmetic, same view order), the geometry
@@ -437,12 +471,12 @@ def _nccl_world1_worker(rank, world, port, out_dir):
         torch.cuda.synchronize()
         report["dense2"] = {k: p.grad.cpu() for k, p in params.items()}
         # --- factored: colour all-gather (in place) + geometry all-reduce, with and without visible-row compaction
-        for compact in (False, True):
+        for compact, tag in ((False, "0"), (True, "1"), ("view", "view"), ("view+geometry", "viewgeo")):
             got, fx = _factored_step(sc, cams[:1], cams[:1], dev, V=1, compact=compact)
             assert fx.world == 1 and parallel._multi(None)
-            report[f"factored_compact{int(compact)}"] = got
+            report[f"factored_compact{tag}"] = got
             got2, _ = _factored_step(sc, cams, cams, dev, V=2, compact=compact)
-            report[f"factored2_compact{int(compact)}"] = got2
+            report[f"factored2_compact{tag}"] = got2
         torch.save(report, os.path.join(out_dir, "nccl1.pt"))
     finally:
         dist.destroy_process_group()
@@ -472,15 +506,16 @@ def test_nccl_world1_every_collective_call_of_the_step(tmp_path):
     want1 = _accumulate_views_dense(sc, cams[:1], dev)
     want2 = _accumulate_views_dense(sc, cams, dev)
     for name, want in (("dense", want1), ("dense2", want2), ("factored_compact0", want1), ("factored_compact1", want1),
-                       ("factored2_compact0", want2), ("factored2_compact1", want2)):
+                       ("factored2_compact0", want2), ("factored2_compact1", want2), ("factored_compactview", want1),
+                       ("factored2_compactview", want2), ("factored_compactviewgeo", want1), ("factored2_compactviewgeo", want2)):
         for k in KEYS:
             assert torch.equal(got[name][k], want[k]), (name, k)
     assert float(want1["shs"].abs().max()) > 0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["dense", "factored"])
-def test_nccl_world1_through_bench_py(tmp_path, exchange):
+@pytest.mark.parametrize("exchange,compact", [("dense", "none"), ("factored", "none"), ("factored", "view"), ("factored", "view+geometry")])
+def test_nccl_world1_through_bench_py(tmp_path, exchange, compact):
     """`bench.py --gpus 1` with GSR_BENCH_FORCE_PG=1: the exact code path of the driver's N > 1 runs (init_process_group("nccl",
     device_id=...), armed bucket / FactoredGradExchange, barrier + MAX all-reduce of the clock, comm block) on one GPU.
     The line must carry a `comm` block of the requested exchange WITHOUT a fallback."""
@@ -491,10 +526,75 @@ def test_nccl_world1_through_bench_py(tmp_path, exchange):
     env = dict(os.environ, GSR_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "C2", "--steps", "4", "--warmup", "2",
-                        "--exchange", exchange, "--no-cpu-baseline", "--no-ref-ab"], env=env, capture_output=True, text=True, timeout=300)
+                        "--exchange", exchange, "--compact", compact, "--no-cpu-baseline", "--no-ref-ab"], env=env, capture_output=True,
+                       text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["comm"]["exchange"] == exchange and line["comm"]["exchange_fallback"] is None, line["comm"]
     assert line["n_gpus"] == 1 and line["value"] > 0
     if exchange == "dense":
         assert line["comm"]["chunks_per_step"] == 4 and line["comm"]["tail_bytes_per_step"] > 0
+    elif compact != "none":
+        assert line["comm"]["compacted"] == compact and line["comm"]["color_rows_per_view"] < line["comm"]["rows_total"]
+        assert line["comm"]["early_allgathers_per_step"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 255, 256, 257, 5000, 100003])
+def test_packed_messages_hip_vs_torch(P):
+    """The packed row messages of compact="view" (csrc/gsr_comm.hip): header (count, block bases, mask), row packing /
+    unpacking, the union header and the SH-gradient rebuild from packed messages -- HIP kernels against the torch restatement
+    (tests/packed_ref.py) word for word, and the packed rebuild against the dense one bit for bit."""
+    from gaustudio_amd import _C
+    from packed_ref import TorchPacked as T
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(P)
+    Hw = _C.msg_header_words(P)
+    assert Hw == T.header_words(P)
+    N = 3
+    radii = [((torch.rand(P, generator=g) > f).int() * 7).to(dev) for f in (0.8, 0.3, 0.55)]
+    scratch = torch.zeros((P + 255) // 256, dtype=torch.int32, device=dev)
+    Lmax = Hw + 3 * P
+    msgs = torch.zeros(N * Lmax, dtype=torch.int32, device=dev)
+    offsets, cols = [], []
+    for r in range(N):
+        hdr, ref = torch.zeros(Hw, dtype=torch.int32, device=dev), torch.zeros(Hw, dtype=torch.int32, device=dev)
+        _C.visible_index(radii[r], hdr, scratch)
+        T.visible_index(radii[r], ref, None)
+        assert torch.equal(hdr, ref), r
+        K = int(hdr[0])
+        assert K == int((radii[r] > 0).sum())
+        col = (torch.randn(P, 3, generator=g).to(dev)) * (radii[r] > 0)[:, None]
+        cols.append(col)
+        off = r * Lmax
+        offsets.append(off)
+        msgs[off:off + Hw] = hdr
+        want_rows = torch.zeros(3 * K, device=dev)
+        T.pack_rows(hdr, col, want_rows, 3, 0)
+        _C.pack_rows(hdr, col, msgs[off + Hw:off + Hw + 3 * P].view(torch.float32), 3, 0)
+        assert torch.equal(msgs[off + Hw:off + Hw + 3 * K].view(torch.float32), want_rows)
+        back = torch.full((P, 3), 7.0, device=dev)
+        _C.unpack_rows(hdr, msgs[off + Hw:].view(torch.float32), 3, 0, back)
+        assert torch.equal(back[radii[r] > 0], col[radii[r] > 0]) and bool((back[radii[r] == 0] == 7.0).all())
+    off_t = torch.tensor(offsets, dtype=torch.int64, device=dev)
+    hu, hu_ref = torch.zeros(Hw, dtype=torch.int32, device=dev), torch.zeros(Hw, dtype=torch.int32, device=dev)
+    _C.union_index(P, msgs, off_t, hu, scratch)
+    T.union_index(P, msgs, off_t, hu_ref, None)
+    assert torch.equal(hu, hu_ref) and int(hu[0]) == int(((radii[0] > 0) | (radii[1] > 0) | (radii[2] > 0)).sum())
+    # geometry-style packing with a stride and a column offset
+    geo = torch.randn(P, 4, generator=g).to(dev)
+    K = int(hu[0])
+    if K > 0:
+        rows = torch.zeros((K, 11), device=dev)
+        _C.pack_rows(hu, geo, rows.view(-1), 11, 7)
+        assert torch.equal(rows[:, 7:11], geo[T._mask(hu, P)]) and float(rows[:, :7].abs().sum()) == 0.0
+    # rebuild: packed == dense, bit for bit, at every degree
+    means = torch.randn(P, 3, generator=g).to(dev)
+    campos = (torch.randn(N, 3, generator=g) * 4 + 15).to(dev)
+    for D in (0, 1, 2, 3):
+        for M in ((D + 1) ** 2, 16):
+            a = torch.full((P, M, 3), float("nan"), device=dev)
+            b = torch.full((P, M, 3), float("nan"), device=dev)
+            _C.sh_grad_from_colors(means, campos, torch.stack(cols).contiguous(), D, a)
+            _C.sh_grad_from_packed(means, campos, msgs, off_t, D, b)
+            assert torch.equal(a, b), (D, M)
