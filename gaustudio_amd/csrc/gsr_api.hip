@@ -153,17 +153,24 @@ std::atomic<int> g_opt_fast_exp{env_int("GSR_FAST_EXP", 1)};
 // would take other alpha >= 1/255 decisions than its forward (silently inconsistent gradients).  The device-side record
 // (GsCtl::opts) needs a read-back to check (debug mode does); this host-side memory makes the check free for the common
 // case of a backward that follows its forward in the same process.  An entry overwritten by newer forwards is simply not checked.
-struct FwdMode { const void* img; int fast_exp; int skew; };
+struct FwdMode { const void* img; int fast_exp; int skew; int forward_only; };
 constexpr int kFwdModes = 64;
 FwdMode g_fwd_modes[kFwdModes] = {};
 unsigned g_fwd_modes_next = 0;
 std::mutex g_fwd_modes_mutex;
-void remember_forward_mode(const void* img, int fast_exp)
+void remember_forward_mode(const void* img, int fast_exp, int forward_only)
 {
 	std::lock_guard<std::mutex> lock(g_fwd_modes_mutex);
 	for (auto& e : g_fwd_modes)
-		if (e.img == img) { e.fast_exp = fast_exp; e.skew = 0; return; }
-	g_fwd_modes[g_fwd_modes_next++ % kFwdModes] = FwdMode{img, fast_exp, 0};
+		if (e.img == img) { e.fast_exp = fast_exp; e.skew = 0; e.forward_only = forward_only; return; }
+	g_fwd_modes[g_fwd_modes_next++ % kFwdModes] = FwdMode{img, fast_exp, 0, forward_only};
+}
+int recall_forward_only(const void* img)
+{
+	std::lock_guard<std::mutex> lock(g_fwd_modes_mutex);
+	for (const auto& e : g_fwd_modes)
+		if (e.img == img) return e.forward_only;
+	return 0;
 }
 // skew: the frame has a tile list many times longer than the mean -- its backward orders the tiles longest walk first
 void remember_forward_skew(const void* img, int skew)
@@ -189,7 +196,7 @@ int recall_forward_mode(const void* img)    // -1: unknown
 
 // options of ONE call: the caller's gsr_options where given (>= 0), the process defaults elsewhere
 struct Resolved {
-	int tight, cull, fwd_variant, bwd_variant, speculative, band_lo, band_hi, fast_exp;
+	int tight, cull, fwd_variant, bwd_variant, speculative, band_lo, band_hi, fast_exp, forward_only;
 };
 Resolved resolve_options(const gsr_options* o)
 {
@@ -208,6 +215,7 @@ Resolved resolve_options(const gsr_options* o)
 	if (v.tile_row_lo >= 0) { r.band_lo = v.tile_row_lo; r.band_hi = v.tile_row_hi; }
 	else { r.band_lo = g_opt_band_lo.load(); r.band_hi = g_opt_band_hi.load(); }
 	r.fast_exp = v.fast_exp >= 0 ? v.fast_exp : g_opt_fast_exp.load();
+	r.forward_only = v.forward_only > 0 ? 1 : 0;
 	return r;
 }
 
@@ -405,6 +413,7 @@ void gsr_options_init(gsr_options* opt)
 	opt->tight_binning = opt->cull = opt->fwd_variant = opt->bwd_variant = opt->speculative = -1;
 	opt->tile_row_lo = opt->tile_row_hi = -1;
 	opt->fast_exp = -1;
+	opt->forward_only = -1;
 }
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
@@ -496,7 +505,7 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	char* img = image_alloc(image_ctx, il.total + (lds_bin ? align_up(bin_hist_bytes(P, il.T)) : 0));
 	if (!geom || !img) return fail(GSR_ERR_ALLOC, "gsr_forward: allocator returned NULL", __FILE__, __LINE__);
 
-	remember_forward_mode(img, ro.fast_exp != 0);
+	remember_forward_mode(img, ro.fast_exp != 0, ro.forward_only);
 
 	GsCam* cam = reinterpret_cast<GsCam*>(geom + gl.cam);
 	GsRec* recs = reinterpret_cast<GsRec*>(geom + gl.recs);
@@ -539,7 +548,8 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	uint32_t* bsums = reinterpret_cast<uint32_t*>(geom + gl.bsums);
 	uint32_t* refsums = reinterpret_cast<uint32_t*>(geom + gl.refsums);
 	uint32_t* Hm = reinterpret_cast<uint32_t*>(img + hm_off);
-	launch_preprocess_fwd(a, cam, il, radii, recs, tiles_touched, bsums, refsums, lds_bin ? nullptr : tile_count, ctl, s);
+	launch_preprocess_fwd(a, cam, il, radii, recs, ro.forward_only ? nullptr : reinterpret_cast<float*>(geom + gl.shjac), tiles_touched, bsums, refsums,
+	                      lds_bin ? nullptr : tile_count, ctl, s);
 	STAGE_CHECK("preprocess_fwd", debug, s);
 	tm.mark();
 	if (lds_bin) {
@@ -769,7 +779,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 
 	if (!(parts & GSR_BWD_PART_MAIN)) {
 		// SH stage alone over a Gaussian range (the caller interleaves a collective per chunk, gaustudio_amd/parallel.py)
-		launch_preprocess_bwd(a, cam, recs, goff, rows, nullptr, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+		launch_preprocess_bwd(a, cam, recs, reinterpret_cast<const float*>(geom_buffer + gl.shjac), goff, rows, nullptr, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
 		                      dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_SH | (sh_colors ? GSR_PART_SH_COLORS : 0) | colors_early, sh_g0, sh_g1, s);
 		STAGE_CHECK("preprocess_bwd_sh", debug, s);
 		return GSR_OK;
@@ -809,6 +819,8 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 			const int fwd_mode = recall_forward_mode(image_buffer);
 			if (fwd_mode >= 0 && fwd_mode != (ro.fast_exp != 0))
 				return fail(GSR_ERR_ARG, "gsr_backward: fast_exp differs from the forward that produced these buffers", __FILE__, __LINE__);
+			if (recall_forward_only(image_buffer))
+				return fail(GSR_ERR_ARG, "gsr_backward: these buffers come from a forward_only forward (gsr_options.forward_only): it kept nothing for a backward", __FILE__, __LINE__);
 		}
 		if (debug) {
 			// the forward recorded what it ran with: a backward in another exp mode would take other alpha >= 1/255 decisions
@@ -835,7 +847,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 		STAGE_CHECK("composite_bwd", debug, s);
 	}
 	tm.mark();
-	launch_preprocess_bwd(a, cam, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+	launch_preprocess_bwd(a, cam, recs, reinterpret_cast<const float*>(geom_buffer + gl.shjac), goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
 	                      dL_dsh_rest, dL_dscale, dL_drot,
 	                      GSR_PART_GEOM | ((parts & GSR_BWD_PART_SH) ? GSR_PART_SH : 0) | (sh_colors ? GSR_PART_SH_COLORS : 0) | colors_early,
 	                      sh_g0, sh_g1, s);

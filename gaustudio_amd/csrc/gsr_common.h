@@ -547,6 +547,79 @@ __device__ __forceinline__ void gs_row_from_lds(const float* __restrict__ row, f
 	}
 }
 
+// ---- d(rgb) / d(unit view direction) of the SH colour (backward.cu:60-123: dRGBdx, dRGBdy, dRGBdz) ----
+// The one part of the SH backward that needs the SH COEFFICIENTS.  Round 4: preprocess_fwd, which holds the 48 coefficients
+// in registers anyway, evaluates these nine numbers and leaves them in the geometry buffer (36 B per Gaussian); the SH
+// backward reads them instead of the 192-B coefficient row -- 128 MB less to read at C3, 0.65 GB at 5 M Gaussians -- and
+// contracts them with dRGB as before.  Same expressions, same order as the reference-following backward used to evaluate
+// them: bit-identical gradients (tests: the per-Gaussian stage against the CPU oracle, bit for bit).
+// J = {dRGBdx[0..2], dRGBdy[0..2], dRGBdz[0..2]}; sh[(k) * 3 + ch]; C1, C2[5], C3[7] = the SH constants of auxiliary.h:22-38.
+#define GSR_SHJAC_STREAM_P 2000000   // above this many Gaussians the nine floats bypass the caches (fwd store, bwd load)
+// the backward's read of the nine floats of Gaussian idx
+__device__ __forceinline__ void gs_load_shjac(const float* __restrict__ shjac, int P, int idx, float* J)
+{
+	if (P > GSR_SHJAC_STREAM_P) {
+		asm volatile("" ::: "memory");   // (keeps the optimiser from merging the two arms into plain loads)
+#pragma unroll
+		for (int k = 0; k < 9; k++) J[k] = __builtin_nontemporal_load(shjac + 9 * (size_t)idx + k);
+		asm volatile("" ::: "memory");
+	} else {
+#pragma unroll
+		for (int k = 0; k < 9; k++) J[k] = shjac[9 * (size_t)idx + k];
+	}
+}
+template <int D>
+__device__ __forceinline__ void gs_sh_dir_jacobian(const float C1, const float* __restrict__ C2, const float* __restrict__ C3,
+                                                   const float* sh, const float x, const float y, const float z, float* J)
+{
+	float* dRGBdx = J;
+	float* dRGBdy = J + 3;
+	float* dRGBdz = J + 6;
+#pragma unroll
+	for (int k = 0; k < 9; k++) J[k] = 0.f;
+#define SH(k) sh[(k) * 3 + ch]
+	if (D > 0) {
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) {
+			dRGBdx[ch] = -C1 * SH(3);
+			dRGBdy[ch] = -C1 * SH(1);
+			dRGBdz[ch] = C1 * SH(2);
+		}
+		if (D > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z;
+			const float xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) {
+				dRGBdx[ch] += __builtin_fmaf(C2[4] * 2.f * x, SH(8), __builtin_fmaf(C2[3] * z, SH(7), __builtin_fmaf(C2[2] * 2.f * -x, SH(6), C2[0] * y * SH(4))));
+				dRGBdy[ch] += __builtin_fmaf(C2[4] * 2.f * -y, SH(8), __builtin_fmaf(C2[2] * 2.f * -y, SH(6), __builtin_fmaf(C2[1] * z, SH(5), C2[0] * x * SH(4))));
+				dRGBdz[ch] += __builtin_fmaf(C2[3] * x, SH(7), __builtin_fmaf(C2[2] * 2.f * 2.f * z, SH(6), C2[1] * y * SH(5)));
+			}
+			if (D > 2) {
+#pragma unroll
+				for (int ch = 0; ch < 3; ch++) {
+					dRGBdx[ch] += __builtin_fmaf(C3[6] * SH(15) * 3.f, xx - yy,
+					              __builtin_fmaf(C3[5] * SH(14) * 2.f, xz,
+					              __builtin_fmaf(C3[4] * SH(13), __builtin_fmaf(4.f, zz, -3.f * xx) - yy,
+					              __builtin_fmaf(C3[3] * SH(12) * -3.f * 2.f, xz,
+					              __builtin_fmaf(C3[2] * SH(11) * -2.f, xy,
+					              __builtin_fmaf(C3[1] * SH(10), yz, C3[0] * SH(9) * 3.f * 2.f * xy))))));
+					dRGBdy[ch] += __builtin_fmaf(C3[6] * SH(15) * -3.f * 2.f, xy,
+					              __builtin_fmaf(C3[5] * SH(14) * -2.f, yz,
+					              __builtin_fmaf(C3[4] * SH(13) * -2.f, xy,
+					              __builtin_fmaf(C3[3] * SH(12) * -3.f * 2.f, yz,
+					              __builtin_fmaf(C3[2] * SH(11), __builtin_fmaf(4.f, zz, -3.f * yy) - xx,
+					              __builtin_fmaf(C3[1] * SH(10), xz, C3[0] * SH(9) * 3.f * (xx - yy)))))));
+					dRGBdz[ch] += __builtin_fmaf(C3[5] * SH(14), xx - yy,
+					              __builtin_fmaf(C3[4] * SH(13) * 4.f * 2.f, xz,
+					              __builtin_fmaf(C3[3] * SH(12) * 3.f, __builtin_fmaf(2.f, zz, -xx) - yy,
+					              __builtin_fmaf(C3[2] * SH(11) * 4.f * 2.f, yz, C3[1] * SH(10) * xy))));
+				}
+			}
+		}
+	}
+#undef SH
+}
+
 // ---- packed row messages of the multi-GPU exchange (layout: gsr_comm.hip) ----
 __device__ __forceinline__ uint32_t gs_msg_nb(int P) { return (uint32_t)((P + 255) / 256); }
 __device__ __forceinline__ uint32_t gs_msg_nw(int P) { return (uint32_t)((P + 31) / 32); }

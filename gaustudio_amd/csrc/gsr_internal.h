@@ -16,7 +16,7 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // goff_apply finishes the scan inside each block -- no separate multi-kernel scan.
 #define GSR_PRE_BLOCK 256
 struct GeomLayout {
-	size_t cam, recs, tiles_touched, goff, bsums, refsums, total;
+	size_t cam, recs, tiles_touched, goff, bsums, refsums, shjac, total;
 	size_t nblk;
 	explicit GeomLayout(size_t P)
 	{
@@ -27,7 +27,10 @@ struct GeomLayout {
 		goff = tiles_touched + align_up(sizeof(uint32_t) * P);
 		bsums = goff + align_up(sizeof(uint32_t) * (P + 1));
 		refsums = bsums + align_up(sizeof(uint32_t) * (nblk + 1));
-		total = refsums + align_up(sizeof(uint32_t) * (nblk + 1));
+		// d(rgb) / d(view direction) of every visible Gaussian's SH colour, 9 floats: left by preprocess_fwd for the SH
+		// backward (gs_sh_dir_jacobian), which then does not read the 192-B coefficient rows again
+		shjac = refsums + align_up(sizeof(uint32_t) * (nblk + 1));
+		total = shjac + align_up(sizeof(float) * 9 * P);
 	}
 };
 
@@ -99,7 +102,7 @@ struct FwdArgs {
 // host knows the instance count and leave without touching memory when ctl->num_binned exceeds it (the host then
 // re-allocates and re-launches; gsr_api.hip forward_impl).
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
-void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs,
+void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs, float* shjac,
                            uint32_t* tiles_touched, uint32_t* bsums, uint32_t* refsums, uint32_t* tile_count,
                            GsCtl* ctl, hipStream_t s);
 void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, int nblk, uint32_t* bsums, const uint32_t* refsums,
@@ -188,7 +191,7 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, con
 #define GSR_PART_SH 2
 #define GSR_PART_SH_COLORS 4   // with GSR_PART_SH: the factored form (dRGB into dL_dcolor in place, dL_dsh untouched)
 #define GSR_PART_COLORS_EARLY 8   // the GEOMETRY kernel leaves dRGB (clamp-masked) in dL_dcolor; the COLORS SH kernel then does not write it
-void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
+void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const float* shjac, const uint32_t* goff,
                            const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
                            float* dL_drot, int parts, int sh_g0, int sh_g1, hipStream_t s);

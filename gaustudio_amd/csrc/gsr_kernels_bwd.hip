@@ -1265,7 +1265,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 // fused into preprocess_bwd it pushed that kernel to 146 VGPRs (3 waves/SIMD) for work that lives on
 // memory-level parallelism.  Runs after preprocess_bwd: reads dL_dcolor, adds its mean gradient to dL_dmeans.
 //
-// gs_sh_backward: from the SH coefficients `sh` (active degree D) returns dc[k] = d(rgb)/d(sh_k) (so that
+// gs_sh_backward: from J = d(rgb)/d(direction) of the Gaussian (9 floats the forward left, gs_sh_dir_jacobian; all zero at
+// degree 0) returns dc[k] = d(rgb)/d(sh_k) (so that
 // dL_dsh[k][ch] = dc[k] * dRGB[ch]), dRGB = dL_dcolor with the clamped channels zeroed (Q12), and dmean_sh, the
 // gradient reaching the mean through the view direction (backward.cu:126-138).
 // dc[k] = d(rgb) / d(sh_k) for the unit view direction (x, y, z): the SH basis of the active degree (forward.cu:20-71,
@@ -1298,7 +1299,7 @@ __device__ __forceinline__ void gs_sh_basis(const float x, const float y, const 
 
 template <int D>
 __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __restrict__ cam, uint32_t clamped,
-                                               const float* __restrict__ dLc, const float* sh, float* dc, float* dRGB,
+                                               const float* __restrict__ dLc, const float* J, float* dc, float* dRGB,
                                                float* dmean_sh)
 {
 		const float3 dir_orig = {m.x - cam->campos[0], m.y - cam->campos[1], m.z - cam->campos[2]};
@@ -1306,49 +1307,11 @@ __device__ __forceinline__ void gs_sh_backward(const float3 m, const GsCam* __re
 		const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
 #pragma unroll
 		for (int ch = 0; ch < 3; ch++) dRGB[ch] = dLc[ch] * (((clamped >> ch) & 1u) ? 0.f : 1.f);
-		float dRGBdx[3] = {0.f, 0.f, 0.f}, dRGBdy[3] = {0.f, 0.f, 0.f}, dRGBdz[3] = {0.f, 0.f, 0.f};
-#define SH(k) sh[(k) * 3 + ch]
+		// d(rgb) / d(direction): evaluated by preprocess_fwd from the coefficients it held (gs_sh_dir_jacobian, gsr_common.h)
+		const float* dRGBdx = J;
+		const float* dRGBdy = J + 3;
+		const float* dRGBdz = J + 6;
 		gs_sh_basis<D>(x, y, z, dc);
-		if (D > 0) {
-#pragma unroll
-			for (int ch = 0; ch < 3; ch++) {
-				dRGBdx[ch] = -bSH_C1 * SH(3);
-				dRGBdy[ch] = -bSH_C1 * SH(1);
-				dRGBdz[ch] = bSH_C1 * SH(2);
-			}
-			if (D > 1) {
-				const float xx = x * x, yy = y * y, zz = z * z;
-				const float xy = x * y, yz = y * z, xz = x * z;
-#pragma unroll
-				for (int ch = 0; ch < 3; ch++) {
-					dRGBdx[ch] += FMA(bSH_C2[4] * 2.f * x, SH(8), FMA(bSH_C2[3] * z, SH(7), FMA(bSH_C2[2] * 2.f * -x, SH(6), bSH_C2[0] * y * SH(4))));
-					dRGBdy[ch] += FMA(bSH_C2[4] * 2.f * -y, SH(8), FMA(bSH_C2[2] * 2.f * -y, SH(6), FMA(bSH_C2[1] * z, SH(5), bSH_C2[0] * x * SH(4))));
-					dRGBdz[ch] += FMA(bSH_C2[3] * x, SH(7), FMA(bSH_C2[2] * 2.f * 2.f * z, SH(6), bSH_C2[1] * y * SH(5)));
-				}
-				if (D > 2) {
-#pragma unroll
-					for (int ch = 0; ch < 3; ch++) {
-						dRGBdx[ch] += FMA(bSH_C3[6] * SH(15) * 3.f, xx - yy,
-						              FMA(bSH_C3[5] * SH(14) * 2.f, xz,
-						              FMA(bSH_C3[4] * SH(13), FMA(4.f, zz, -3.f * xx) - yy,
-						              FMA(bSH_C3[3] * SH(12) * -3.f * 2.f, xz,
-						              FMA(bSH_C3[2] * SH(11) * -2.f, xy,
-						              FMA(bSH_C3[1] * SH(10), yz, bSH_C3[0] * SH(9) * 3.f * 2.f * xy))))));
-						dRGBdy[ch] += FMA(bSH_C3[6] * SH(15) * -3.f * 2.f, xy,
-						              FMA(bSH_C3[5] * SH(14) * -2.f, yz,
-						              FMA(bSH_C3[4] * SH(13) * -2.f, xy,
-						              FMA(bSH_C3[3] * SH(12) * -3.f * 2.f, yz,
-						              FMA(bSH_C3[2] * SH(11), FMA(4.f, zz, -3.f * yy) - xx,
-						              FMA(bSH_C3[1] * SH(10), xz, bSH_C3[0] * SH(9) * 3.f * (xx - yy)))))));
-						dRGBdz[ch] += FMA(bSH_C3[5] * SH(14), xx - yy,
-						              FMA(bSH_C3[4] * SH(13) * 4.f * 2.f, xz,
-						              FMA(bSH_C3[3] * SH(12) * 3.f, FMA(2.f, zz, -xx) - yy,
-						              FMA(bSH_C3[2] * SH(11) * 4.f * 2.f, yz, bSH_C3[1] * SH(10) * xy))));
-					}
-				}
-			}
-		}
-#undef SH
 		const float ddx = FMA(dRGBdx[2], dRGB[2], FMA(dRGBdx[1], dRGB[1], dRGBdx[0] * dRGB[0]));
 		const float ddy = FMA(dRGBdy[2], dRGB[2], FMA(dRGBdy[1], dRGB[1], dRGBdy[0] * dRGB[0]));
 		const float ddz = FMA(dRGBdz[2], dRGB[2], FMA(dRGBdz[1], dRGB[1], dRGBdz[0] * dRGB[0]));
@@ -1379,8 +1342,8 @@ constexpr int gs_sh_row_floats(int deg, bool split)
 // as usual.
 template <int D, bool SPLIT, bool COLORS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
-    int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
-    const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, const GsRec* __restrict__ recs,
+    int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shjac,
+    const GsCam* __restrict__ cam, const GsRec* __restrict__ recs,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_rest, int write_colors)
 {
@@ -1395,25 +1358,19 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 	const int nrows = min(64, P - g0);
 	if (nrows <= 0) return;   // wave-uniform
 	const bool vis = idx < P && radii[idx] > 0;
-	const unsigned long long vm = __ballot(vis);
 	constexpr int RFP = gs_row_stride<RFA>();   // padded row stride in the slab (bank conflicts)
 	float* slab = sh_slab + wv * 64 * RFP;
 	float* row = slab + lane * RFP;
-	if (RF > 0) {
-		const float* src = (SPLIT ? shs_rest : shs) + (size_t)g0 * RF;
-		if (vm) gs_wave_rows_to_lds<RFA>(src, nrows, vm, slab, lane);
-		__builtin_amdgcn_wave_barrier();
-	}
 	if (vis) {
-		float sh[NC * 3], dc[NC], dRGB[3], dmean_sh[3];
-		if (SPLIT) {
-			sh[0] = shs[3 * (size_t)idx]; sh[1] = shs[3 * (size_t)idx + 1]; sh[2] = shs[3 * (size_t)idx + 2];
-			if (RF > 0) gs_row_from_lds<RFA>(row, sh + 3);
+		float J[9], dc[NC], dRGB[3], dmean_sh[3];
+		if (D > 0) {
+			gs_load_shjac(shjac, P, idx, J);
 		} else {
-			gs_row_from_lds<RFA>(row, sh);
+#pragma unroll
+			for (int k = 0; k < 9; k++) J[k] = 0.f;
 		}
 		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
+		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
 #define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
 		if (COLORS) {
 			if (write_colors) {   // (0: the geometry stage left dRGB already and a collective may be reading the slot by now)
@@ -1461,7 +1418,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 // below writes a 192-B row with twelve 16-B stores at a stride of 192 B per lane: 0.127 ms at C3 against 0.090.)
 template <int D, int MS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_wide_kernel(
-    int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
+    int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shjac,
     const GsCam* __restrict__ cam, const GsRec* __restrict__ recs, const float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh)
 {
@@ -1481,12 +1438,11 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_wide_kernel(
 #pragma unroll
 	for (int i = 0; i < RF / 4; i++) reinterpret_cast<float4*>(row)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	if (vis) {
-		float sh[NC * 3], dc[NC], dRGB[3], dmean_sh[3];
-		const float* shp = shs + (size_t)idx * RF;
-#pragma unroll
-		for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+		float J[9], dc[NC], dRGB[3], dmean_sh[3];
+		if (D > 0) gs_load_shjac(shjac, P, idx, J);
+		else { for (int k = 0; k < 9; k++) J[k] = 0.f; }
 		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
+		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
 #pragma unroll
 		for (int i = 0; i < NC * 3; i++) row[i] = dc[i / 3] * dRGB[i % 3];
 #pragma unroll
@@ -1498,8 +1454,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_wide_kernel(
 
 template <int D, bool SPLIT, bool COLORS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
-    int g_base, int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shs,
-    const float* __restrict__ shs_rest, const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs,
+    int g_base, int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shjac,
+    const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_rest, int write_colors)
 {
@@ -1507,67 +1463,43 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 	if (idx >= P) return;
 	constexpr int NC = (D + 1) * (D + 1);
 	const bool vis = radii[idx] > 0;
-	float sh[NC * 3], dc[NC], dRGB[3], dmean_sh[3];
-	if (COLORS) {
-		if (!vis) return;                       // the row of dL_dcolor of a culled Gaussian is zero already
+	float J[9], dc[NC], dRGB[3], dmean_sh[3];
+	if (!vis) {
+		if (COLORS) return;                     // the row of dL_dcolor of a culled Gaussian is zero already
 		if (SPLIT) {
-			sh[0] = shs[3 * (size_t)idx]; sh[1] = shs[3 * (size_t)idx + 1]; sh[2] = shs[3 * (size_t)idx + 2];
-			const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
-#pragma unroll
-			for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
+			// split storage (f1): dL_dsh -> dL_df_dc [P,1,3], dL_dsh_rest -> dL_df_rest [P,M-1,3]
+			float* ddc = dL_dsh + 3 * (size_t)idx;
+			float* drest = dL_dsh_rest + (size_t)idx * (M - 1) * 3;
+			ddc[0] = ddc[1] = ddc[2] = 0.f;
+			for (int i = 0; i < (M - 1) * 3; i++) drest[i] = 0.f;
 		} else {
-			const float* shp = shs + (size_t)idx * M * 3;
-#pragma unroll
-			for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+			float* dsh = dL_dsh + (size_t)idx * M * 3;
+			if (sh_vec4)
+				for (int i = 0; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+			else
+				for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
 		}
-		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
+		return;
+	}
+	if (D > 0) gs_load_shjac(shjac, P, idx, J);
+	else { for (int k = 0; k < 9; k++) J[k] = 0.f; }
+	const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+	gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
+#define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
+	if (COLORS) {
 		if (write_colors) {
 			float* dcol = const_cast<float*>(dL_dcolor) + 3 * (size_t)idx;
 			dcol[0] = dRGB[0]; dcol[1] = dRGB[1]; dcol[2] = dRGB[2];
 		}
 	} else if (SPLIT) {
-		// split storage (f1): dL_dsh -> dL_df_dc [P,1,3], dL_dsh_rest -> dL_df_rest [P,M-1,3]
 		float* ddc = dL_dsh + 3 * (size_t)idx;
 		float* drest = dL_dsh_rest + (size_t)idx * (M - 1) * 3;
-		if (!vis) {
-			ddc[0] = ddc[1] = ddc[2] = 0.f;
-			for (int i = 0; i < (M - 1) * 3; i++) drest[i] = 0.f;
-			return;
-		}
-		sh[0] = shs[3 * (size_t)idx]; sh[1] = shs[3 * (size_t)idx + 1]; sh[2] = shs[3 * (size_t)idx + 2];
-		const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
-#pragma unroll
-		for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
-		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
 		ddc[0] = dc[0] * dRGB[0]; ddc[1] = dc[0] * dRGB[1]; ddc[2] = dc[0] * dRGB[2];
 #pragma unroll
-		for (int i = 3; i < NC * 3; i++) drest[i - 3] = dc[i / 3] * dRGB[i % 3];
+		for (int i = 3; i < NC * 3; i++) drest[i - 3] = OSH(i);
 		for (int i = NC * 3; i < M * 3; i++) drest[i - 3] = 0.f;   // coefficients above the active degree
 	} else {
 		float* dsh = dL_dsh + (size_t)idx * M * 3;
-		if (!vis) {
-			if (sh_vec4)
-				for (int i = 0; i < M * 3 / 4; i++) reinterpret_cast<float4*>(dsh)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-			else
-				for (int i = 0; i < M * 3; i++) dsh[i] = 0.f;
-			return;
-		}
-		const float* shp = shs + (size_t)idx * M * 3;
-		if (sh_vec4 && (NC * 3) % 4 == 0) {
-#pragma unroll
-			for (int i = 0; i < NC * 3 / 4; i++) {
-				const float4 v = reinterpret_cast<const float4*>(shp)[i];
-				sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
-			}
-		} else {
-#pragma unroll
-			for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
-		}
-		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, sh, dc, dRGB, dmean_sh);
-#define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
 		if (sh_vec4 && (NC * 3) % 4 == 0) {
 #pragma unroll
 			for (int i = 0; i < NC * 3 / 4; i++)
@@ -1578,13 +1510,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 			for (int i = 0; i < NC * 3; i++) dsh[i] = OSH(i);
 			for (int i = NC * 3; i < M * 3; i++) dsh[i] = 0.f;   // coefficients above the active degree
 		}
-#undef OSH
 	}
+#undef OSH
 #pragma unroll
 	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] += dmean_sh[i];
 }
 
-void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* goff,
+void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const float* shjac, const uint32_t* goff,
                            const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
                            float* dL_drot, int parts, int sh_g0, int sh_g1, hipStream_t s)
@@ -1614,8 +1546,8 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	grid = dim3((sh_g1 - sh_g0 + 255) / 256);
 	if (a.shs != nullptr) {
 #define GSR_LAUNCH_SH(DEG)                                                                                       \
-	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT, COLORS>), grid, block, 0, s, sh_g0, sh_end, a.M, a.means3D, a.radii, a.shs, \
-	                   a.shs_rest, cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
+	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT, COLORS>), grid, block, 0, s, sh_g0, sh_end, a.M, a.means3D, a.radii, shjac, \
+	                   cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
 #define GSR_LAUNCH_SH_D()                        \
 		switch (a.D) {                            \
 			case 0: GSR_LAUNCH_SH(0); break;      \
@@ -1627,19 +1559,20 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 		const bool split = a.shs_rest != nullptr;
 		const bool colors = (parts & GSR_PART_SH_COLORS) != 0;   // factored form: dRGB into dL_dcolor, no dL_dsh (not with split storage)
 		const int NCd = (a.D + 1) * (a.D + 1);
-		const float* stream_in = split ? a.shs_rest : a.shs;
-		const float* stream_out = colors ? stream_in : (split ? dL_dsh_rest : dL_dsh);
-		const bool coop = a.M == NCd && (sh_g0 % 256 == 0) && ((uintptr_t)stream_in % 16 == 0) && ((uintptr_t)stream_out % 16 == 0) &&
-		                  (!split || NCd == 1 || (stream_in != nullptr && stream_out != nullptr));
+		// (the coefficient rows are no longer read here -- the forward left d(rgb)/d(direction), gs_sh_dir_jacobian -- so only the
+		// gradient rows stream through the slab)
+		const float* stream_out = split ? dL_dsh_rest : dL_dsh;
+		const bool coop = a.M == NCd && (sh_g0 % 256 == 0) && (colors || ((uintptr_t)stream_out % 16 == 0)) &&
+		                  (colors || !split || NCd == 1 || stream_out != nullptr);
 #define GSR_LAUNCH_SHC(DEG, SPL, COL)                                                                             \
 	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL, COL>), grid, block,                                  \
 	                   sizeof(float) * 256 * gs_row_stride<gs_sh_row_floats(DEG, SPL)>(), s, sh_g0, sh_end, \
-	                   a.means3D, a.radii, a.shs, a.shs_rest, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
+	                   a.means3D, a.radii, shjac, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
 		// stored rows wider than the active degree ([P,16,3] storage while the degree is still being raised): the wide kernel
 		const bool wide = !colors && !split && a.M == 16 && NCd < 16 && (sh_g0 % 256 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
 #define GSR_LAUNCH_SHW(DEG)                                                                                            \
 	hipLaunchKernelGGL((preprocess_bwd_sh_wide_kernel<DEG, 16>), grid, block, sizeof(float) * 256 * gs_row_stride<48>(), s, sh_g0, \
-	                   sh_end, a.means3D, a.radii, a.shs, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh)
+	                   sh_end, a.means3D, a.radii, shjac, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh)
 		if (wide) {
 			switch (a.D) {
 				case 0: GSR_LAUNCH_SHW(0); break;

@@ -55,15 +55,15 @@ void require_device(const torch::Tensor& t, const char* name)
 }
 
 // per-call options (include/gsrast.h gsr_options) as Python hands them over: [tight_binning, cull, fwd_variant,
-// bwd_variant, speculative, tile_row_lo, tile_row_hi, fast_exp], -1 = process default; a shorter (or empty) list
+// bwd_variant, speculative, tile_row_lo, tile_row_hi, fast_exp, forward_only], -1 = process default; a shorter (or empty) list
 // leaves the remaining fields at their defaults
 gsr_options make_options(const std::vector<int>& v)
 {
 	gsr_options o;
 	gsr_options_init(&o);
-	int32_t* f[8] = {&o.tight_binning, &o.cull, &o.fwd_variant, &o.bwd_variant, &o.speculative, &o.tile_row_lo, &o.tile_row_hi,
-	                 &o.fast_exp};
-	for (size_t i = 0; i < v.size() && i < 8; i++) *f[i] = v[i];
+	int32_t* f[9] = {&o.tight_binning, &o.cull, &o.fwd_variant, &o.bwd_variant, &o.speculative, &o.tile_row_lo, &o.tile_row_hi,
+	                 &o.fast_exp, &o.forward_only};
+	for (size_t i = 0; i < v.size() && i < 9; i++) *f[i] = v[i];
 	return o;
 }
 

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .options import resolved as _current_options
+from .options import for_forward as _options_for_forward
 from .rasterizer import _dense_image_grads, _run_guarded
 
 ACT_OPACITY_SIGMOID = 1
@@ -33,7 +33,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     def forward(ctx, means3D, means2D, f_dc, f_rest, raw_opacities, raw_scales, raw_rotations, raster_settings, act):
         rs = raster_settings
         n = _C.native()
-        opts = [int(v) for v in _current_options()]       # per-call options, kept with the graph (options.py)
+        opts = [int(v) for v in _options_for_forward(any(ctx.needs_input_grad))]       # per-call options, kept with the graph (options.py)
         call = (rs.bg, means3D, f_dc, f_rest, raw_opacities, raw_scales, raw_rotations, float(rs.scale_modifier), int(act),
                 rs.viewmatrix, rs.projmatrix, float(rs.tanfovx), float(rs.tanfovy), int(rs.image_height),
                 int(rs.image_width), int(rs.sh_degree), rs.campos, bool(rs.prefiltered), bool(rs.debug), opts)

@@ -17,7 +17,7 @@ A field that is not set falls back to the enclosing `with`, then to the process 
 """
 import threading
 
-FIELDS = ("tight_binning", "cull", "fwd_variant", "bwd_variant", "speculative", "tile_row_lo", "tile_row_hi", "fast_exp")
+FIELDS = ("tight_binning", "cull", "fwd_variant", "bwd_variant", "speculative", "tile_row_lo", "tile_row_hi", "fast_exp", "forward_only")
 _tls = threading.local()
 
 
@@ -66,4 +66,12 @@ def resolved():
     if cur[i] < 0:
         from . import _C
         cur[i] = int(_C.get_option("fast_exp"))
+    return tuple(cur)
+
+
+def for_forward(needs_backward: bool):
+    """resolved(), plus `forward_only` = 1 when nothing of this call can be differentiated (torch.no_grad(), or no input requires
+    grad): the forward then skips what only a backward would read."""
+    cur = list(resolved())
+    cur[FIELDS.index("forward_only")] = 0 if needs_backward else 1
     return tuple(cur)

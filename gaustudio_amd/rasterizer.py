@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .options import resolved as _current_options
+from .options import for_forward as _options_for_forward
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -64,7 +64,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         # per-call options of the calling thread (gaustudio_amd/options.py; all -1 = process defaults unless a
         # `with options(...)` block is active): they stay with the graph, the backward below runs with the same ones
-        opts = _current_options()
+        opts = _options_for_forward(any(ctx.needs_input_grad))
         # argument order of _C.rasterize_gaussians (rasterize_points.h:18-38), then the options
         call = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,

@@ -249,6 +249,9 @@ typedef struct gsr_options {
 	int32_t tile_row_lo;    /* tile band of THIS call: [lo, hi), hi <= 0 with lo >= 0 = the whole image */
 	int32_t tile_row_hi;
 	int32_t fast_exp;
+	int32_t forward_only;   /* 0|1  (default 0) this forward will have no backward: skip what only a backward reads (the 36 B per Gaussian
+	                         * of d(rgb)/d(view direction) that preprocess_fwd leaves for the SH backward).  gsr_backward on the buffers of
+	                         * such a forward is refused.  The Python adapters set it for forwards under torch.no_grad(). */
 } gsr_options;
 void gsr_options_init(gsr_options* opt);   /* struct_bytes = sizeof, every field -1 */
 

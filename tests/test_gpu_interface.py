@@ -264,3 +264,36 @@ def test_longest_first_tile_order_changes_no_bit():
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "acc"):
         assert torch.equal(res[0][1][k], res[1][1][k]), k
     assert _C.get_option("tile_order") == 1
+
+
+def test_forward_only_skips_what_only_a_backward_reads_and_refuses_one():
+    """gsr_options.forward_only (set by the autograd Functions for calls under torch.no_grad()): the forward leaves out the
+    36 B per Gaussian it otherwise keeps for the SH backward -- same images, same state -- and a backward on its buffers
+    is refused instead of reading garbage."""
+    from gaustudio_amd import _C
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = "cuda"
+    cam = scenes.make_camera(200, 120)
+    sc = scenes.make_scene(5000, cam, seed=21, sigma_px_median=2.5)
+    kw = scene_kwargs(sc, True, False)
+    normal = hip_forward(sc, cam, 3, kw)
+    e = torch.Tensor([])
+    out = _C.rasterize_gaussians(torch.zeros(3), sc.means3D.to(dev), e, sc.opacities.to(dev), sc.scales.to(dev), sc.rotations.to(dev), 1.0, e,
+                                 cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.tanfovx, cam.tanfovy, cam.height, cam.width,
+                                 sc.shs.to(dev), 3, cam.campos.to(dev), False, False, options=(-1,) * 8 + (1,))
+    for i, k in ((1, "color"), (2, "depth"), (3, "median"), (4, "opacity"), (5, "radii")):
+        assert torch.equal(out[i], normal[k]), k
+    fo = dict(normal, geom=out[6], binning=out[7], img=out[8], num_rendered=out[0])
+    with pytest.raises(RuntimeError, match="forward_only"):
+        hip_backward_raw(fo, sc, cam, 3, kw, scenes.make_output_grads(cam))
+    # through autograd: a no_grad render followed by a differentiable one of the same rasterizer object
+    rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+    P = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    r = GaussianRasterizer(rs)
+    with torch.no_grad():
+        a = r(means3D=P["means3D"], means2D=torch.zeros_like(P["means3D"]), opacities=P["opacities"], shs=P["shs"], scales=P["scales"], rotations=P["rotations"])
+    b = r(means3D=P["means3D"], means2D=torch.zeros_like(P["means3D"]), opacities=P["opacities"], shs=P["shs"], scales=P["scales"], rotations=P["rotations"])
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    b[0].sum().backward()
+    assert P["means3D"].grad is not None and bool(torch.isfinite(P["means3D"].grad).all()) and float(P["means3D"].grad.abs().sum()) > 0

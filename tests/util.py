@@ -109,7 +109,7 @@ def _nonempty(os_):
 class GsrOptions(__import__("ctypes").Structure):
     """include/gsrast.h gsr_options (ABI v6)."""
     _fields_ = [(n, __import__("ctypes").c_int32) for n in ("struct_bytes", "tight_binning", "cull", "fwd_variant", "bwd_variant",
-                                                           "speculative", "tile_row_lo", "tile_row_hi", "fast_exp")]
+                                                           "speculative", "tile_row_lo", "tile_row_hi", "fast_exp", "forward_only")]
 
 
 def make_options(L, struct_bytes=None, **fields):
