@@ -103,10 +103,11 @@ def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
     """Achieved algorithmic GB/s of every stage against the 8 TB/s HBM roofline (BASELINE.md s4 byte counts; the
     records are 64 B here instead of the reference's 48 B of SoA fields, counted as written).  R = instances binned."""
     sh = 12 * (D + 1) ** 2
+    jac = 36 if D > 0 else 0          # d(rgb)/d(view direction), left by preprocess_fwd for the SH backward (round 4)
     HW = H * W
     stages = {}
     if fwd_ms:
-        b = {"preprocess": P * (12 + 12 + 16 + 4 + sh) + P_vis * (64 + 4 + 4),
+        b = {"preprocess": P * (12 + 12 + 16 + 4 + sh) + P_vis * (64 + 4 + 4 + (0 if fwd_only else jac)),
              "scatter": R * 8 + P_vis * 64, "sort": R * 12,
              "composite": R * 44 + T * 8 + HW * 32 + (0 if fwd_only else HW * 8)}
         for k, nbytes in b.items():
@@ -116,7 +117,9 @@ def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
                     "ms": round(fwd_ms[k], 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1), "frac_hbm": round(gbs / 8000.0, 4)}
     if bwd_ms:
         b = {"composite_bwd": R * 44 + HW * 32 + R * 48,
-             "preprocess_bwd": R * 48 + P_vis * (12 + 4 + sh + 64 + 12 + 16 + 8) + P * (12 + 4 + 12 + 12 + 24 + 12 * 16 + 12 + 16)}
+             # rows, then per visible Gaussian mean / radius / jacobian (instead of the 192-B coefficient row) / record / scale /
+             # rotation / row offsets, and the outputs (dL_dcov3D only exists when covariances were supplied: not here)
+             "preprocess_bwd": R * 48 + P_vis * (12 + 4 + jac + 64 + 12 + 16 + 8) + P * (12 + 4 + 12 + 12 + sh + 12 + 16)}
         for k, nbytes in b.items():
             if bwd_ms.get(k):
                 gbs = nbytes / (bwd_ms[k] * 1e-3) / 1e9

@@ -322,6 +322,15 @@ class FactoredGradExchange:
             self.counts = torch.zeros((self.V, self.world), dtype=torch.int32, device=dev)
             self._scratch = torch.zeros((self.P + 255) // 256, dtype=torch.int32, device=dev)
             self.hdr_union = torch.zeros(self.Hw, dtype=torch.int32, device=dev)
+            # the visible counts reach the HOST without touching the compute stream: header kernels, count all-gather and a
+            # non-blocking copy into pinned memory run on a side stream; the backward's callback waits for that stream's event
+            # (long signalled by then), never for the compute stream it is being enqueued on
+            self._cuda = dev.type == "cuda"
+            self._side = torch.cuda.Stream(device=dev) if self._cuda else None
+            self._counts_host = torch.zeros((self.V, self.world), dtype=torch.int32, pin_memory=self._cuda)
+            self._off_host = torch.zeros(self.V * self.world, dtype=torch.int64, pin_memory=self._cuda)
+            self._off_dev = torch.zeros(self.V * self.world, dtype=torch.int64, device=dev)
+            self._count_events = {}
         else:
             self.colors = torch.zeros((self.V, self.world, self.P, 3), dtype=torch.float32, device=dev)     # view-major
         self.sh_grad = torch.empty((self.P, self.M, 3), dtype=torch.float32, device=dev)
@@ -396,11 +405,30 @@ class FactoredGradExchange:
         visibility header and gathers the visible counts of all ranks (asynchronously: nothing here waits)."""
         if not self.by_view:
             return
-        self._pk.visible_index(radii.detach().contiguous(), self.hdr[v], self._scratch)
-        if _multi(self.group):
-            self._count_works[v] = dist.all_gather_into_tensor(self.counts[v], self.hdr[v][0:1], group=self.group, async_op=True)
+        radii = radii.detach().contiguous()
+
+        def build():
+            self._pk.visible_index(radii, self.hdr[v], self._scratch)
+            if _multi(self.group):
+                w = dist.all_gather_into_tensor(self.counts[v], self.hdr[v][0:1], group=self.group, async_op=True)
+                if self._cuda:
+                    w.wait()                               # the side stream waits for the communicator's stream; the host does not
+                else:
+                    self._count_works[v] = w
+            else:
+                self.counts[v, 0:1].copy_(self.hdr[v][0:1])
+        if self._cuda:
+            cur = torch.cuda.current_stream(self.geo.device)
+            with torch.cuda.stream(self._side):
+                self._side.wait_stream(cur)                # radii come from the forward just enqueued
+                build()
+                self._counts_host[v].copy_(self.counts[v], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            radii.record_stream(self._side)
+            self._count_events[v] = ev
         else:
-            self.counts[v, 0:1].copy_(self.hdr[v][0:1])
+            build()
         self._seen.add(v)
 
     def _send_view(self, v: int):
@@ -410,10 +438,17 @@ class FactoredGradExchange:
         the device still has the rest of the backward queued)."""
         if v not in self._seen:
             raise RuntimeError(f'FactoredGradExchange(compact="view"): call visible({v}, radii) after the forward of local view {v}')
-        w = self._count_works.pop(v, None)
-        if w is not None:
-            w.wait()
-        kcap = int(self.counts[v].max().item())
+        if self._cuda:
+            ev = self._count_events.pop(v)
+            ev.synchronize()                                                 # the side stream only: signalled long ago
+            torch.cuda.current_stream(self.geo.device).wait_event(ev)        # the header is read by the kernels enqueued below
+            kcap = int(self._counts_host[v].max())
+        else:
+            w = self._count_works.pop(v, None)
+            if w is not None:
+                w.wait()
+            kcap = int(self.counts[v].max().item())
+            self._counts_host[v].copy_(self.counts[v])
         L = self.Hw + 3 * kcap
         buf = self.msgs[v][: self.world * L].view(self.world, L)
         mine = buf[self.rank]
@@ -538,11 +573,13 @@ def _exchange_by_view_impl(self, campos_all, D, views, multi):
     for v in range(V):
         if self._works[v] is not None:
             self._works[v].wait()
-    # word offset of every message in memory order (local view major, rank minor), computed on the device from the counts
-    Lv = self.Hw + 3 * self.counts.max(dim=1).values.to(torch.int64)                                        # [V]
-    offsets = (torch.arange(V, device=dev, dtype=torch.int64) * (W * self.Lmax))[:, None] + \
-        torch.arange(W, device=dev, dtype=torch.int64)[None, :] * Lv[:, None]
-    offsets = offsets.reshape(-1).contiguous()
+    # word offset of every message in memory order (local view major, rank minor): from the counts the host already holds,
+    # handed to the device by a non-blocking copy out of pinned memory
+    Lv = self.Hw + 3 * self._counts_host.max(dim=1).values.to(torch.int64)                                  # [V], host
+    self._off_host.copy_(((torch.arange(V, dtype=torch.int64) * (W * self.Lmax))[:, None] +
+                          torch.arange(W, dtype=torch.int64)[None, :] * Lv[:, None]).reshape(-1))
+    self._off_dev.copy_(self._off_host, non_blocking=True)
+    offsets = self._off_dev
     msgs = self.msgs.view(-1)
     campos = campos_all.detach().to(dev, torch.float32)[self._order].contiguous()
     self._pk.sh_from_packed(self.p["means3D"].detach(), campos, msgs, offsets, D, self.sh_grad)

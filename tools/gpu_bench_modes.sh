@@ -8,12 +8,20 @@ run() { tag=$1; shift; timeout 600 "$@" > "$out/$tag.json" 2> "$out/$tag.err"; e
 run default python bench.py --steps 30 --warmup 10 --no-ref-ab
 run extract python bench.py --workload C3-extract --steps 16 --warmup 8
 run rotate python bench.py --rotate-cameras 8 --steps 24 --warmup 8 --no-cpu-baseline --no-ref-ab
+run exact python bench.py --exact --steps 30 --warmup 10 --no-cpu-baseline --no-ref-ab --no-extras
+for w in C1 C2 C2-clustered C3D0 C4 C5; do run $w python bench.py --workload $w --steps 24 --warmup 8 --no-cpu-baseline --no-ref-ab --no-extras; done
+# the N > 1 code path over RCCL on the one GPU (process group of one rank: every collective call of the step meets the library)
+for ex in "dense none" "factored none" "factored view" "factored view+geometry"; do set -- $ex
+  GSR_BENCH_FORCE_PG=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 run nccl1_$1_$2 python bench.py --gpus 1 --steps 12 --warmup 4 --exchange $1 --compact $2 --no-cpu-baseline --no-ref-ab
+done
 for ex in dense factored; do
   GSR_BENCH_BACKEND=gloo run n2_${ex} python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
       bench.py --gpus 2 --steps 6 --warmup 3 --workload C2 --exchange $ex
 done
 GSR_BENCH_BACKEND=gloo run n2_factored_v2 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 \
     bench.py --gpus 2 --steps 6 --warmup 3 --workload C2 --exchange factored --views-per-rank 2
+GSR_BENCH_BACKEND=gloo run n2_factored_view python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 \
+    bench.py --gpus 2 --steps 6 --warmup 3 --workload C2 --exchange factored --compact view
 python - "$out" <<'PY'
 import json, sys, glob, os
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "*.json"))):
