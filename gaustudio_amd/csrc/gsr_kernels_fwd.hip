@@ -710,18 +710,10 @@ __device__ __forceinline__ void gs_cex(uint64_t& a, uint64_t& b, bool asc)
 	b = hi;
 }
 
+// the network on 64 x KPL keys in registers; result in blocked order (key index = lane * KPL + e)
 template <int KPL>
-__device__ __forceinline__ void gs_wave_sort_tile(const uint64_t* __restrict__ keys, uint32_t* __restrict__ out, uint32_t n,
-                                                  int lane)
+__device__ __forceinline__ void gs_wave_sort_regs(uint64_t (&k)[KPL], int lane)
 {
-	uint64_t k[KPL];
-	// the input order is irrelevant to a sort: fetch striped (coalesced, 512 B per instruction); only the result
-	// is in blocked order
-#pragma unroll
-	for (int e = 0; e < KPL; e++) {
-		const uint32_t i = (uint32_t)e * 64 + lane;
-		k[e] = i < n ? keys[i] : ~0ull;
-	}
 	// sizes 2 .. KPL/2: entirely inside a lane, direction known at compile time (bit `size` of e)
 #pragma unroll
 	for (int size = 2; size < KPL; size <<= 1) {
@@ -775,6 +767,20 @@ __device__ __forceinline__ void gs_wave_sort_tile(const uint64_t* __restrict__ k
 				if ((e & j) == 0) gs_cex(k[e], k[e | j], asc);
 		}
 	}
+}
+template <int KPL>
+__device__ __forceinline__ void gs_wave_sort_tile(const uint64_t* __restrict__ keys, uint32_t* __restrict__ out, uint32_t n,
+                                                  int lane)
+{
+	uint64_t k[KPL];
+	// the input order is irrelevant to a sort: fetch striped (coalesced, 512 B per instruction); only the result
+	// is in blocked order
+#pragma unroll
+	for (int e = 0; e < KPL; e++) {
+		const uint32_t i = (uint32_t)e * 64 + lane;
+		k[e] = i < n ? keys[i] : ~0ull;
+	}
+	gs_wave_sort_regs<KPL>(k, lane);
 #pragma unroll
 	for (int e = 0; e < KPL; e++) {
 		const uint32_t i = (uint32_t)lane * KPL + e;
@@ -782,9 +788,17 @@ __device__ __forceinline__ void gs_wave_sort_tile(const uint64_t* __restrict__ k
 	}
 }
 
+// With `q` (a frame of the queue pipeline below, long_level 2), the wave of a LONG list -- idle here otherwise -- prepares its
+// first cut: it appends the list's slices to the slice queue and sorts the list's 1024 evenly spaced sample keys (the same
+// register network, KPL = 16: the work of one 1024-key tile) into the head of the list's `keys2` range, where slice_hist
+// picks the splitters up before slice_scatter overwrites them.
+struct GsSortQ;
+__device__ __forceinline__ void gs_enter_long_list(uint2 range, GsSortQ* __restrict__ q, uint4* __restrict__ slice_items, uint32_t slice_cap,
+                                                   const uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2, int lane);
 __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
                                                         uint32_t* __restrict__ point_list, const GsCtl* __restrict__ ctl,
-                                                        uint32_t cap)
+                                                        uint32_t cap, GsSortQ* __restrict__ q, uint4* __restrict__ slice_items,
+                                                        uint32_t slice_cap, uint64_t* __restrict__ keys2)
 {
 	if (ctl->num_binned > cap) return;   // see bin_scatter_kernel
 	const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per tile, no cross-wave traffic
@@ -792,7 +806,11 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint2* __re
 	const int lane = threadIdx.x & 63;
 	const uint2 range = ranges[tile];
 	const uint32_t n = range.y - range.x;
-	if (n == 0 || n > GSR_SORT_LDS_MAX) return;   // empty, or handled by tile_radix_sort
+	if (n == 0) return;
+	if (n > GSR_SORT_LDS_MAX) {   // handled by tile_radix_sort_kernel, or (q) by the queue pipeline
+		if (q != nullptr) gs_enter_long_list(range, q, slice_items, slice_cap, keys, keys2, lane);
+		return;
+	}
 	const uint64_t* src = keys + range.x;
 	uint32_t* dst = point_list + range.x;
 	if (n <= 64) gs_wave_sort_tile<1>(src, dst, n, lane);
@@ -868,101 +886,144 @@ __device__ __forceinline__ void tile_radix_pass(const uint64_t* __restrict__ src
 // to four counting passes over the whole list.  On a clustered scene (bench.py --workload C2-clustered: per-tile lists
 // p50 10 / p99 11 k / max 58 k) that kernel was 55 % of the step: 0.98 ms for the workgroup that owned the 58 k list.
 // Now the stage is a small pipeline over a WORK QUEUE in the binning buffer (GsSortQ + item arrays):
-//   tile_partition     one 1024-thread workgroup per long tile: min / max of the 64-bit keys (depth << 32 | id), B = 2^k
-//                      buckets of equal KEY width (~128 keys on average, <= 4096 buckets), histogram + scatter into
-//                      `keys2`; every non-empty bucket becomes a queue item: <= 1024 keys -> sort item, more -> a
-//                      segment for the next round.  (64-bit keys: a pile of equal depths spreads over the id bits.)
-//   segment_partition  the same cut applied to the oversized buckets, each by its own key range, into the other key buffer
-//                      (two more levels; also takes the <= 8192-key lists whose one-workgroup cut overflowed, see
-//                      tile_radix_sort_kernel); what is STILL oversized after three levels goes to
-//   segment_fallback   the counting sort that used to take the whole tile (tile_radix_pass), one workgroup per segment.
-//   bucket_sort        every wave of the chip sorts buckets from the queue in registers (gs_wave_sort_tile) -> point_list.
+//   tile_sort (long-list branch) / slice_hist / slice_scatter
+//                      the first cut of every long list, by ceil(n / 8192) workgroups (see there): 1024 evenly spaced keys of
+//                      the list are sorted and every (1024 / B)-th becomes a splitter (sample sort; B = 2^k <= 512 buckets of
+//                      ~128 keys: equal COUNT, whatever the depth distribution), histogram + scatter into `keys2`; every
+//                      non-empty bucket becomes a queue item: <= 1024 keys -> sort item, more (lists beyond 64 k keys,
+//                      sampling noise) -> a segment for the next round.  (64-bit keys (depth << 32 | id) are distinct: a pile
+//                      of equal depths splits on the id bits.)
+//   segment_partition  the same cut (gs_partition_segment: one workgroup sorts the segment's own samples) applied to the oversized
+//                      buckets, into the other key buffer; what is STILL oversized goes to the fallback queue.
+//   bucket_sort        every wave of the chip sorts buckets from the queue in registers (gs_wave_sort_tile) -> point_list; in
+//                      front of that its workgroups take the fallback segments (normally none): the counting sort that used to
+//                      take the whole tile (tile_radix_pass).
 // The order is (depth, id) as before; point_list is bit-identical to the oracle's.
 struct GsSortQ {
-	uint32_t n_sort, n_seg, n_seg2, n_fall, err, pad[3];
+	uint32_t n_sort, n_seg, n_fall, err, n_slice, pad[3];
 };
 #define GSR_Q_IN_KEYS 0x80000000u    // item flag (in .y): the bucket's keys are in `keys` (second round), else in `keys2`
 #define GSR_PART_THREADS 1024
-#define GSR_PART_BMAX 4096u
 #define GSR_PART_AVG 128u            // target keys per bucket
 #define GSR_PART_REGS 8192u          // lists up to this many keys are read once and held in registers (NT threads x 8192 / NT keys)
 
-// One workgroup (GSR_PART_THREADS threads) cuts the n keys at src into buckets written to dst (same offsets); items are
-// positions relative to the binning arrays (`abs0` = index of src[0] in them).  item_flag marks where the buckets live.
+// One workgroup (NT threads) cuts the n > NT keys at src into buckets written to dst (same offsets); items are positions
+// relative to the binning arrays (`abs0` = index of src[0] in them).  item_flag marks where the buckets live.
+//
+// The cut is by SPLITTERS TAKEN FROM THE LIST (sample sort), not by equal key width: NT evenly spaced keys are sorted by the
+// workgroup (in-wave stages through ds_bpermute, the ten cross-wave stages through LDS), every (NT / B)-th of them is a
+// splitter, a key's bucket is found by binary search (log2 B LDS reads).  Until this change the buckets were B equal slices
+// of [min key, max key]: on the surface a tile looks at the depths pile up, 44 % of the clustered scene's 58 k-key list fell
+// into 4 of 512 buckets -- 12 oversized buckets holding 55 k keys went through a second cut, and in the first one ~10 lanes of
+// every wave met in one LDS counter (same-address atomics serialise).  Buckets of equal COUNT (~128 +- sampling noise) need
+// no second cut, spread the atomics, and make the min / max sweep unnecessary.
+// NT threads, one sample each: ascending bitonic sort, result in s_samp[0 .. NT) (s_samp holds 2 NT words: the cross-wave
+// stages alternate between its halves, one barrier per stage; the 45 in-wave stages exchange through ds_bpermute)
+template <int NT>
+__device__ __forceinline__ void gs_sort_samples(unsigned long long v, unsigned long long* s_samp)
+{
+	const int tid = threadIdx.x;
+	int pp = 0;
+	for (int k = 2; k <= NT; k <<= 1) {
+		const bool asc = (tid & k) == 0;
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			unsigned long long o;
+			if (j >= 64) {
+				unsigned long long* b = s_samp + (pp ? NT : 0);
+				pp ^= 1;
+				b[tid] = v;
+				__syncthreads();
+				o = b[tid ^ j];
+			} else {
+				o = (unsigned long long)__shfl_xor((long long)v, j, 64);
+			}
+			const bool take_min = ((tid & j) == 0) == asc;   // the lower index of an ascending pair keeps the smaller key
+			v = take_min ? min(v, o) : max(v, o);
+		}
+	}
+	__syncthreads();   // the last LDS stage's reads
+	s_samp[tid] = v;
+	__syncthreads();
+}
+// The B - 1 splitters (every spb-th of the sorted samples) as a search tree in breadth-first order: node 1 is the middle
+// splitter, node v has the children 2 v and 2 v + 1; level L sits in tree[2^L .. 2^(L+1)).  A binary search over the SORTED
+// array reads addresses that are multiples of large powers of two on its first levels -- all in one LDS bank, a 2^L-way
+// conflict at level L (measured: the histogram kernel of the first cut 33 us, LDS-bound) -- here the 2^L nodes of a level are
+// neighbours.  Thread v < B fills node v from `samples` (LDS or global).
+__device__ __forceinline__ void gs_build_splitter_tree(unsigned long long* tree, const unsigned long long* samples, uint32_t B, uint32_t spb)
+{
+	const uint32_t v = threadIdx.x;
+	if (v >= 1u && v < B) {
+		const int L = 31 - __clz((int)v);
+		const uint32_t i = v - (1u << L);
+		tree[v] = samples[(((2u * i + 1u) * B) >> (L + 1)) * spb];
+	}
+}
+// bucket of key k = number of splitters <= k  (B a power of two, log2 B steps)
+__device__ __forceinline__ uint32_t gs_tree_bucket(const unsigned long long* tree, uint32_t B, unsigned long long k)
+{
+	uint32_t v = 1;
+	while (v < B) v = 2u * v + (tree[v] <= k ? 1u : 0u);
+	return v - B;
+}
+__device__ __forceinline__ uint32_t gs_bucket_count(uint32_t n, uint32_t nt)   // B * GSR_PART_AVG >= n, 2 <= B <= nt / 2
+{
+	uint32_t B = 2;
+	while (B < nt / 2u && B * GSR_PART_AVG < n) B <<= 1;
+	return B;
+}
+
 template <int NT>
 __device__ __forceinline__ void gs_partition_segment(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t abs0,
                                                      uint32_t n, uint32_t item_flag, GsSortQ* __restrict__ q,
                                                      uint2* __restrict__ sort_items, uint32_t sort_cap,
                                                      uint2* __restrict__ over_items, uint32_t over_cap, uint32_t* over_count,
-                                                     uint32_t* s_off, uint32_t* s_cur, uint32_t* s_misc, unsigned long long* s_mm,
-                                                     uint32_t* __restrict__ fused_out)
+                                                     uint32_t* s_off, uint32_t* s_cur, uint32_t* s_misc, unsigned long long* s_samp)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	constexpr int NW = NT / 64, RK = (int)(GSR_PART_REGS / NT);
-	if (tid == 0) { s_mm[0] = ~0ull; s_mm[1] = 0ull; s_misc[0] = 0u; s_misc[1] = 0u; }
-	__syncthreads();
+	if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
 	const bool in_regs = n <= (uint32_t)NT * RK;
 	uint64_t kreg[RK];
-	unsigned long long mn = ~0ull, mx = 0ull;
-	const unsigned long long kmax_init = 0ull;
 	if (in_regs) {
 #pragma unroll
 		for (int r = 0; r < RK; r++) {
 			const uint32_t i = (uint32_t)tid + (uint32_t)NT * r;
 			kreg[r] = i < n ? src[i] : ~0ull;
-			if (i < n) { mn = min(mn, (unsigned long long)kreg[r]); mx = max(mx, (unsigned long long)kreg[r]); }
+		}
+	}
+	gs_sort_samples<NT>(src[(uint32_t)(((unsigned long long)tid * n) / NT)], s_samp);   // n > NT: distinct positions, distinct keys
+	const uint32_t B = gs_bucket_count(n, (uint32_t)NT);
+	const uint32_t spb = (uint32_t)NT / B;                 // samples per bucket (>= 2)
+	for (uint32_t b = tid; b <= B; b += NT) s_off[b] = 0u;
+	unsigned long long* tree = s_samp + NT;                // the sort's second buffer: B <= NT / 2 nodes
+	gs_build_splitter_tree(tree, s_samp, B, spb);
+	__syncthreads();
+	auto bucket_of = [&](const unsigned long long k) -> uint32_t { return gs_tree_bucket(tree, B, k); };
+	uint32_t breg[RK];
+	if (in_regs) {
+#pragma unroll
+		for (int r = 0; r < RK; r++) {
+			breg[r] = 0u;
+			if ((uint32_t)tid + (uint32_t)NT * r < n) { breg[r] = bucket_of(kreg[r]); atomicAdd(&s_off[breg[r]], 1u); }
 		}
 	} else {
 		// long lists: eight independent loads in flight per thread and sweep (one load at a time made the 58 k-key list of
-		// the clustered scene take 58 us here: three sweeps of 57 dependent round trips)
+		// the clustered scene take 58 us here: sweeps of 57 dependent round trips)
 		for (uint32_t i0 = tid; i0 < n; i0 += 8u * NT) {
 			unsigned long long k8[8];
 #pragma unroll
-			for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)u * NT; k8[u] = i < n ? src[i] : kmax_init; }
+			for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)u * NT; k8[u] = i < n ? src[i] : 0ull; }
 #pragma unroll
-			for (int u = 0; u < 8; u++) if (i0 + (uint32_t)u * NT < n) { mn = min(mn, k8[u]); mx = max(mx, k8[u]); }
-		}
-	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		mn = min(mn, (unsigned long long)__shfl_xor((long long)mn, o, 64));
-		mx = max(mx, (unsigned long long)__shfl_xor((long long)mx, o, 64));
-	}
-	if (lane == 0) { atomicMin(&s_mm[0], mn); atomicMax(&s_mm[1], mx); }
-	__syncthreads();
-	const unsigned long long kmin = s_mm[0], span = s_mm[1] - s_mm[0];   // span > 0: the keys are distinct and n > 1
-	uint32_t B = 2;
-	while (B < GSR_PART_BMAX && B < 4u * NT && B * GSR_PART_AVG < n) B <<= 1;
-	const int span_bits = 64 - __builtin_clzll(span | 1ull), logB = 31 - __clz((int)B);
-	const int shift = max(0, span_bits - logB);            // (k - kmin) >> shift < B
-	for (uint32_t b = tid; b <= B; b += NT) s_off[b] = 0u;
-	__syncthreads();
-	if (in_regs) {
-#pragma unroll
-		for (int r = 0; r < RK; r++)
-			if ((uint32_t)tid + (uint32_t)NT * r < n) atomicAdd(&s_off[(uint32_t)((kreg[r] - kmin) >> shift)], 1u);
-	} else {
-		for (uint32_t i0 = tid; i0 < n; i0 += 8u * NT) {
-			unsigned long long k8[8];
-#pragma unroll
-			for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)u * NT; k8[u] = i < n ? src[i] : kmin; }
-#pragma unroll
-			for (int u = 0; u < 8; u++) if (i0 + (uint32_t)u * NT < n) atomicAdd(&s_off[(uint32_t)((k8[u] - kmin) >> shift)], 1u);
+			for (int u = 0; u < 8; u++) if (i0 + (uint32_t)u * NT < n) atomicAdd(&s_off[bucket_of(k8[u])], 1u);
 		}
 	}
 	__syncthreads();
-	// exclusive scan of the B counts (4 per thread); how many sort / oversized items this cut produces
+	// exclusive scan of the B counts (B <= NT / 2: at most one per thread); how many sort / oversized items this cut produces
 	{
-		uint32_t c[4], sum = 0, n_s = 0, n_o = 0;
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const uint32_t b = 4 * tid + k;
-			c[k] = b < B ? s_off[b] : 0u;
-			sum += c[k];
-			n_s += (c[k] > 0u && c[k] <= GSR_SORT_LDS_MAX) ? 1u : 0u;
-			n_o += c[k] > GSR_SORT_LDS_MAX ? 1u : 0u;
-		}
-		uint32_t incl = sum;
+		const uint32_t c = (uint32_t)tid < B ? s_off[tid] : 0u;
+		const bool is_s = c > 0u && c <= GSR_SORT_LDS_MAX, is_o = c > GSR_SORT_LDS_MAX;
+		uint32_t incl = c;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
 			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
@@ -972,65 +1033,37 @@ __device__ __forceinline__ void gs_partition_segment(const uint64_t* __restrict_
 		if (lane == 63) s_wtot[wv] = incl;
 		// local item slots (order irrelevant)
 		uint32_t ls = 0, lo_ = 0;
-		if (n_s) ls = atomicAdd(&s_misc[0], n_s);
-		if (n_o) lo_ = atomicAdd(&s_misc[1], n_o);
+		if (is_s) ls = atomicAdd(&s_misc[0], 1u);
+		if (is_o) lo_ = atomicAdd(&s_misc[1], 1u);
 		__syncthreads();
-		uint32_t run = incl - sum;
+		uint32_t run = incl - c;
 		for (int w = 0; w < wv; w++) run += s_wtot[w];
-		// a list held in registers whose buckets all fit the register sort is finished right here by this workgroup's own
-		// waves (the C4 regime: every tile ~3.7 k keys) -- no queue round trip; only longer lists and overflowing cuts
-		// hand their buckets to bucket_sort_kernel
-		const bool fused = fused_out != nullptr && in_regs && s_misc[1] == 0u;
 		if (tid == 0) {   // one reservation per workgroup and queue
-			const uint32_t ts = fused ? 0u : s_misc[0], to = s_misc[1];
+			const uint32_t ts = s_misc[0], to = s_misc[1];
 			s_misc[2] = ts ? atomicAdd(&q->n_sort, ts) : 0u;
 			s_misc[3] = to ? atomicAdd(over_count, to) : 0u;
 		}
 		__syncthreads();
 		const uint32_t gs = s_misc[2], go = s_misc[3];
-		if ((!fused && gs + s_misc[0] > sort_cap) || go + s_misc[1] > over_cap) { if (tid == 0) q->err = 1u; }
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const uint32_t b = 4 * tid + k;
-			if (b < B) { s_off[b] = run; s_cur[b] = run; }
-			if (b == B - 1) s_off[B] = run + c[k];
-			if (c[k] > 0u && c[k] <= GSR_SORT_LDS_MAX) { if (!fused && gs + ls < sort_cap) sort_items[gs + ls] = make_uint2(abs0 + run, c[k] | item_flag); ls++; }
-			else if (c[k] > GSR_SORT_LDS_MAX) { if (go + lo_ < over_cap) over_items[go + lo_] = make_uint2(abs0 + run, c[k] | item_flag); lo_++; }
-			run += c[k];
-		}
+		if (gs + s_misc[0] > sort_cap || go + s_misc[1] > over_cap) { if (tid == 0) q->err = 1u; }
+		if ((uint32_t)tid < B) { s_off[tid] = run; s_cur[tid] = run; }
+		if ((uint32_t)tid == B - 1) s_off[B] = run + c;
+		if (is_s) { if (gs + ls < sort_cap) sort_items[gs + ls] = make_uint2(abs0 + run, c | item_flag); }
+		else if (is_o) { if (go + lo_ < over_cap) over_items[go + lo_] = make_uint2(abs0 + run, c | item_flag); }
 	}
 	__syncthreads();
 	if (in_regs) {
 #pragma unroll
-		for (int r = 0; r < RK; r++) {
-			if ((uint32_t)tid + (uint32_t)NT * r < n) {
-				const uint64_t k = kreg[r];
-				dst[atomicAdd(&s_cur[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
-			}
-		}
+		for (int r = 0; r < RK; r++)
+			if ((uint32_t)tid + (uint32_t)NT * r < n) dst[atomicAdd(&s_cur[breg[r]], 1u)] = kreg[r];
 	} else {
 		for (uint32_t i0 = tid; i0 < n; i0 += 8u * NT) {
 			unsigned long long k8[8];
 #pragma unroll
-			for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)u * NT; k8[u] = i < n ? src[i] : kmin; }
+			for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)u * NT; k8[u] = i < n ? src[i] : 0ull; }
 #pragma unroll
 			for (int u = 0; u < 8; u++)
-				if (i0 + (uint32_t)u * NT < n) dst[atomicAdd(&s_cur[(uint32_t)((k8[u] - kmin) >> shift)], 1u)] = k8[u];
-		}
-	}
-	if (fused_out != nullptr && in_regs && s_misc[1] == 0u) {
-		__threadfence_block();
-		__syncthreads();
-		for (uint32_t b = wv; b < B; b += NW) {
-			const uint32_t st = s_off[b], cnt = s_off[b + 1] - st;   // s_off[B] = n was left by the scan below
-			const uint64_t* bs = dst + st;
-			uint32_t* bo = fused_out + st;
-			if (cnt == 0) continue;
-			if (cnt <= 64) gs_wave_sort_tile<1>(bs, bo, cnt, lane);
-			else if (cnt <= 128) gs_wave_sort_tile<2>(bs, bo, cnt, lane);
-			else if (cnt <= 256) gs_wave_sort_tile<4>(bs, bo, cnt, lane);
-			else if (cnt <= 512) gs_wave_sort_tile<8>(bs, bo, cnt, lane);
-			else gs_wave_sort_tile<16>(bs, bo, cnt, lane);
+				if (i0 + (uint32_t)u * NT < n) dst[atomicAdd(&s_cur[bucket_of(k8[u])], 1u)] = k8[u];
 		}
 	}
 	__syncthreads();
@@ -1243,23 +1276,163 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 }
 
 
-// (NT = 256 for the lists of 1025 .. 8192 keys was measured: slower than 1024 threads -- C4 sort 0.240 against 0.216 ms)
-template <int NT>
-__global__ __launch_bounds__(NT) void tile_partition_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
-                                                                         uint64_t* __restrict__ keys2, uint32_t* __restrict__ point_list, GsSortQ* __restrict__ q,
-                                                                         uint2* __restrict__ sort_items, uint32_t sort_cap,
-                                                                         uint2* __restrict__ seg_items, uint32_t seg_cap,
+// ---- first cut of every long list, by SLICES: a list of n keys is cut by ceil(n / 8192) workgroups ------------------
+// (One workgroup per list, round 4's first form, left the longest list of a skewed frame to one CU: 52 us for the 58 k-key
+// list of the clustered scene, three sweeps of 57 keys per thread.)  A slice is <= 8192 consecutive list positions, held in
+// registers (8 keys per thread).  Every slice workgroup of a list uses the same splitters -- the list's 1024 evenly spaced
+// sample keys, sorted once per list -- and
+//   tile_sort       the wave that has nothing to sort for a long list (tile_sort_kernel) appends the list's slices to the
+//                   slice queue (one device atomic per long list) and sorts its samples: gs_enter_long_list;
+//   slice_hist      per slice: bucket of every key (kept for the scatter: 4 B per key in the not yet written point_list),
+//                   LDS histogram -> row of u16 counts in the queue memory;
+//   slice_scatter   per slice: bucket starts = scan over the list's bucket totals, plus what the slices in front of this one
+//                   put into each bucket; keys scattered into `keys2`; slice 0 enters the list's buckets into the work queue.
+#define GSR_SLICE_KEYS GSR_PART_REGS
+#define GSR_SLICE_ROW (GSR_PART_THREADS / 2)     // u16 counts per slice row
+__device__ __forceinline__ void gs_enter_long_list(uint2 range, GsSortQ* __restrict__ q, uint4* __restrict__ slice_items, uint32_t slice_cap,
+                                                   const uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2, int lane)
+{
+	const uint32_t n = range.y - range.x;
+	const uint32_t nsl = (n + GSR_SLICE_KEYS - 1u) / GSR_SLICE_KEYS;
+	uint32_t base = 0;
+	if (lane == 0) base = atomicAdd(&q->n_slice, nsl);   // one device atomic per long list
+	base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+	if (base + nsl > slice_cap) { if (lane == 0) q->err = 1u; return; }   // cannot happen: SortQueueLayout::slice_cap
+	for (uint32_t sl = lane; sl < nsl; sl += 64) slice_items[base + sl] = make_uint4(range.x, n, sl, base);
+	// samples: key at position floor(i n / 1024), i = 0 .. 1023 (n > 1024: distinct positions, distinct keys)
+	uint64_t k[16];
+#pragma unroll
+	for (int e = 0; e < 16; e++) k[e] = keys[range.x + (uint32_t)(((unsigned long long)(e * 64 + lane) * n) >> 10)];
+	gs_wave_sort_regs<16>(k, lane);
+	uint64_t* out = keys2 + range.x + (uint32_t)lane * 16u;
+#pragma unroll
+	for (int e = 0; e < 16; e++) out[e] = k[e];
+}
+
+__global__ __launch_bounds__(GSR_PART_THREADS) void slice_hist_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys2,
+                                                                      uint32_t* __restrict__ bucket_ids, const GsSortQ* __restrict__ q,
+                                                                      const uint4* __restrict__ slice_items, uint32_t slice_cap,
+                                                                      uint16_t* __restrict__ rows, const GsCtl* __restrict__ ctl, uint32_t cap)
+{
+	constexpr int NT = GSR_PART_THREADS, RK = (int)(GSR_SLICE_KEYS / NT);
+	static_assert(NT == 1024, "gs_enter_long_list sorts 1024 samples");
+	__shared__ uint32_t s_cnt[GSR_SLICE_ROW];
+	__shared__ unsigned long long s_tree[GSR_SLICE_ROW];
+	// the guard words, the queue length and this workgroup's first item are fetched together: one round trip instead of three
+	const uint32_t nb_ = ctl->num_binned, mt_ = ctl->max_tile_count, nq_ = q->n_slice;
+	const uint4 item0 = blockIdx.x < slice_cap ? slice_items[blockIdx.x] : make_uint4(0u, 0u, 0u, 0u);
+	if (nb_ > cap || mt_ <= GSR_SORT_LDS_MAX) return;   // see bin_scatter_kernel; no long list at all
+	const int tid = threadIdx.x;
+	const uint32_t nsl_all = min(nq_, slice_cap);
+	for (uint32_t it = blockIdx.x; it < nsl_all; it += gridDim.x) {
+		const uint4 item = it == blockIdx.x ? item0 : slice_items[it];
+		const uint64_t* src = keys + item.x;
+		const uint32_t n = item.y, lo = item.z * GSR_SLICE_KEYS, cnt = min(GSR_SLICE_KEYS, n - lo);
+		const uint32_t B = gs_bucket_count(n, (uint32_t)NT), spb = (uint32_t)NT / B;
+		gs_build_splitter_tree(s_tree, reinterpret_cast<const unsigned long long*>(keys2 + item.x), B, spb);   // the list's sorted samples (gs_enter_long_list)
+		uint64_t kreg[RK];
+#pragma unroll
+		for (int r = 0; r < RK; r++) {
+			const uint32_t i = (uint32_t)tid + (uint32_t)NT * r;
+			kreg[r] = i < cnt ? src[lo + i] : ~0ull;
+		}
+		if ((uint32_t)tid < B) s_cnt[tid] = 0u;
+		__syncthreads();
+		// eight independent searches per thread (padding keys land in the last bucket and are dropped below)
+		uint32_t breg[RK];
+#pragma unroll
+		for (int r = 0; r < RK; r++) breg[r] = 1u;
+		for (uint32_t lv = 1; lv < B; lv <<= 1) {
+#pragma unroll
+			for (int r = 0; r < RK; r++) breg[r] = 2u * breg[r] + (s_tree[breg[r]] <= kreg[r] ? 1u : 0u);
+		}
+#pragma unroll
+		for (int r = 0; r < RK; r++) {
+			const uint32_t i = (uint32_t)tid + (uint32_t)NT * r;
+			breg[r] -= B;
+			if (i < cnt) {
+				atomicAdd(&s_cnt[breg[r]], 1u);
+				bucket_ids[item.x + lo + i] = breg[r];
+			}
+		}
+		__syncthreads();
+		if ((uint32_t)tid < B) rows[(size_t)(item.w + item.z) * GSR_SLICE_ROW + tid] = (uint16_t)s_cnt[tid];   // <= 8192
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(GSR_PART_THREADS) void slice_scatter_kernel(const uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
+                                                                         const uint32_t* __restrict__ bucket_ids, GsSortQ* __restrict__ q,
+                                                                         const uint4* __restrict__ slice_items, uint32_t slice_cap,
+                                                                         const uint16_t* __restrict__ rows, uint2* __restrict__ sort_items,
+                                                                         uint32_t sort_cap, uint2* __restrict__ seg_items, uint32_t seg_cap,
                                                                          const GsCtl* __restrict__ ctl, uint32_t cap)
 {
-	constexpr uint32_t BM = 4u * NT < GSR_PART_BMAX ? 4u * NT : GSR_PART_BMAX;
-	__shared__ uint32_t s_off[BM + 1], s_cur[BM], s_misc[4];
-	__shared__ unsigned long long s_mm[2];
-	if (ctl->num_binned > cap || ctl->max_tile_count <= GSR_SORT_LDS_MAX) return;   // see bin_scatter_kernel; no long list at all
-	const uint2 range = ranges[blockIdx.x];
-	const uint32_t n = range.y - range.x;
-	if (n <= GSR_SORT_LDS_MAX) return;   // tile_sort_kernel's
-	gs_partition_segment<NT>(keys + range.x, keys2 + range.x, range.x, n, 0u, q, sort_items, sort_cap, seg_items, seg_cap, &q->n_seg,
-	                         s_off, s_cur, s_misc, s_mm, nullptr);
+	constexpr int NT = GSR_PART_THREADS, NW = NT / 64, RK = (int)(GSR_SLICE_KEYS / NT);
+	__shared__ uint32_t s_cur[GSR_SLICE_ROW], s_wtot[NW], s_misc[4];
+	const uint32_t nb_ = ctl->num_binned, mt_ = ctl->max_tile_count, nq_ = q->n_slice;   // one round trip, see slice_hist_kernel
+	const uint4 item0 = blockIdx.x < slice_cap ? slice_items[blockIdx.x] : make_uint4(0u, 0u, 0u, 0u);
+	if (nb_ > cap || mt_ <= GSR_SORT_LDS_MAX) return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t nsl_all = min(nq_, slice_cap);
+	for (uint32_t it = blockIdx.x; it < nsl_all; it += gridDim.x) {
+		const uint4 item = it == blockIdx.x ? item0 : slice_items[it];
+		const uint32_t n = item.y, sl = item.z, lo = sl * GSR_SLICE_KEYS, cnt = min(GSR_SLICE_KEYS, n - lo);
+		const uint32_t nsl = (n + GSR_SLICE_KEYS - 1u) / GSR_SLICE_KEYS;
+		const uint32_t B = gs_bucket_count(n, (uint32_t)NT);
+		uint64_t kreg[RK];
+		uint32_t breg[RK];
+#pragma unroll
+		for (int r = 0; r < RK; r++) {
+			const uint32_t i = (uint32_t)tid + (uint32_t)NT * r;
+			kreg[r] = i < cnt ? keys[item.x + lo + i] : 0ull;
+			breg[r] = i < cnt ? bucket_ids[item.x + lo + i] : 0u;
+		}
+		if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
+		// thread b: the list's total of bucket b and what the slices in front of this one hold of it
+		uint32_t tot = 0, pre = 0;
+		if ((uint32_t)tid < B) {
+			const uint16_t* col = rows + (size_t)item.w * GSR_SLICE_ROW + tid;
+#pragma unroll 8
+			for (uint32_t r = 0; r < nsl; r++) {
+				const uint32_t c = col[(size_t)r * GSR_SLICE_ROW];
+				tot += c;
+				pre += r < sl ? c : 0u;
+			}
+		}
+		uint32_t incl = tot;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+			if (lane >= o) incl += t;
+		}
+		if (lane == 63) s_wtot[wv] = incl;
+		__syncthreads();
+		uint32_t start = incl - tot;
+		for (int w = 0; w < wv; w++) start += s_wtot[w];
+		if ((uint32_t)tid < B) s_cur[tid] = start + pre;
+		// slice 0 enters the list's buckets into the queues: <= 1024 keys -> sort item, more -> a segment for the next level
+		const bool is_s = sl == 0u && tot > 0u && tot <= GSR_SORT_LDS_MAX, is_o = sl == 0u && tot > GSR_SORT_LDS_MAX;
+		uint32_t ls = 0, lo_ = 0;
+		if (is_s) ls = atomicAdd(&s_misc[0], 1u);
+		if (is_o) lo_ = atomicAdd(&s_misc[1], 1u);
+		__syncthreads();
+		if (tid == 0) {   // one reservation per list and queue
+			const uint32_t ts = s_misc[0], to = s_misc[1];
+			s_misc[2] = ts ? atomicAdd(&q->n_sort, ts) : 0u;
+			s_misc[3] = to ? atomicAdd(&q->n_seg, to) : 0u;
+		}
+		__syncthreads();
+		const uint32_t gs = s_misc[2], go = s_misc[3];
+		if (gs + s_misc[0] > sort_cap || go + s_misc[1] > seg_cap) { if (tid == 0) q->err = 1u; }
+		if (is_s) { if (gs + ls < sort_cap) sort_items[gs + ls] = make_uint2(item.x + start, tot); }          // flag 0: the bucket lives in keys2
+		else if (is_o) { if (go + lo_ < seg_cap) seg_items[go + lo_] = make_uint2(item.x + start, tot); }
+		uint64_t* dst = keys2 + item.x;
+#pragma unroll
+		for (int r = 0; r < RK; r++)
+			if ((uint32_t)tid + (uint32_t)NT * r < cnt) dst[atomicAdd(&s_cur[breg[r]], 1u)] = kreg[r];
+		__syncthreads();
+	}
 }
 
 // further levels: the oversized buckets of the level before (and the overflowing lists tile_radix_sort_kernel hands over) cut
@@ -1272,44 +1445,22 @@ __global__ __launch_bounds__(GSR_PART_THREADS) void segment_partition_kernel(uin
                                                                             uint2* __restrict__ out_items, uint32_t* __restrict__ out_count,
                                                                             const GsCtl* __restrict__ ctl, uint32_t cap)
 {
-	__shared__ uint32_t s_off[GSR_PART_BMAX + 1], s_cur[GSR_PART_BMAX], s_misc[4];
-	__shared__ unsigned long long s_mm[2];
-	if (ctl->num_binned > cap || ctl->max_tile_count <= GSR_SORT_LDS_MAX) return;
-	const uint32_t nseg = min(*in_count, seg_cap);
+	__shared__ uint32_t s_off[GSR_PART_THREADS / 2 + 1], s_cur[GSR_PART_THREADS / 2], s_misc[4];
+	__shared__ unsigned long long s_samp[2 * GSR_PART_THREADS];
+	const uint32_t nb_ = ctl->num_binned, mt_ = ctl->max_tile_count, nq_ = *in_count;   // one round trip
+	if (nb_ > cap || mt_ <= GSR_SORT_LDS_MAX) return;
+	const uint32_t nseg = min(nq_, seg_cap);
 	for (uint32_t it = blockIdx.x; it < nseg; it += gridDim.x) {
 		const uint2 sg = in_items[it];
 		const bool in_keys = (sg.y & GSR_Q_IN_KEYS) != 0u;     // where the segment's keys are; its buckets go to the other buffer
 		const uint32_t cnt = sg.y & ~GSR_Q_IN_KEYS;
 		gs_partition_segment<GSR_PART_THREADS>((in_keys ? keys : keys2) + sg.x, (in_keys ? keys2 : keys) + sg.x, sg.x, cnt,
 		                                       in_keys ? 0u : GSR_Q_IN_KEYS, q, sort_items, sort_cap, out_items, seg_cap,
-		                                       out_count, s_off, s_cur, s_misc, s_mm, nullptr);
+		                                       out_count, s_off, s_cur, s_misc, s_samp);
 	}
 }
 
-// every wave of the launch sorts buckets (<= 1024 keys each) from the queue in registers
-__global__ __launch_bounds__(256) void bucket_sort_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys2,
-                                                          uint32_t* __restrict__ point_list, const GsSortQ* __restrict__ q,
-                                                          const uint2* __restrict__ sort_items, uint32_t sort_cap,
-                                                          const GsCtl* __restrict__ ctl, uint32_t cap)
-{
-	if (ctl->num_binned > cap || ctl->max_tile_count <= GSR_SORT_LDS_MAX) return;
-	const int lane = threadIdx.x & 63;
-	const uint32_t nitems = min(q->n_sort, sort_cap);
-	const uint32_t nwaves = gridDim.x * 4u;
-	for (uint32_t it = blockIdx.x * 4u + (threadIdx.x >> 6); it < nitems; it += nwaves) {
-		const uint2 item = sort_items[it];
-		const uint32_t cnt = item.y & ~GSR_Q_IN_KEYS;
-		const uint64_t* bs = ((item.y & GSR_Q_IN_KEYS) ? keys : keys2) + item.x;
-		uint32_t* bo = point_list + item.x;
-		if (cnt <= 64) gs_wave_sort_tile<1>(bs, bo, cnt, lane);
-		else if (cnt <= 128) gs_wave_sort_tile<2>(bs, bo, cnt, lane);
-		else if (cnt <= 256) gs_wave_sort_tile<4>(bs, bo, cnt, lane);
-		else if (cnt <= 512) gs_wave_sort_tile<8>(bs, bo, cnt, lane);
-		else gs_wave_sort_tile<16>(bs, bo, cnt, lane);
-	}
-}
-
-// last resort for a segment that two levels of key-range cuts could not break up: stable LSD counting sort on the 32
+// last resort for a segment that two levels of cuts could not break up: stable LSD counting sort on the 32
 // depth bits (ping-pong src <-> tmp, data ends in src), runs of equal depth put in id order afterwards; one workgroup
 // (256 threads) per segment.
 __device__ __forceinline__ void gs_radix_sort_segment(uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint32_t* __restrict__ out,
@@ -1367,30 +1518,60 @@ __device__ __forceinline__ void gs_radix_sort_segment(uint64_t* __restrict__ src
 	__syncthreads();
 }
 
-__global__ __launch_bounds__(256) void segment_fallback_kernel(uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
-                                                               uint32_t* __restrict__ point_list, const GsSortQ* __restrict__ q,
-                                                               const uint2* __restrict__ fall_items, uint32_t fall_cap,
-                                                               const GsCtl* __restrict__ ctl, uint32_t cap)
+// every wave of the launch sorts buckets (<= 1024 keys each) from the queue in registers; in front of that, workgroups take
+// the fallback segments (normally none)
+__global__ __launch_bounds__(256) void bucket_sort_kernel(uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
+                                                          uint32_t* __restrict__ point_list, const GsSortQ* __restrict__ q,
+                                                          const uint2* __restrict__ sort_items, uint32_t sort_cap,
+                                                          const uint2* __restrict__ fall_items, uint32_t fall_cap,
+                                                          const GsCtl* __restrict__ ctl, uint32_t cap)
 {
 	__shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave running offsets
 	__shared__ uint32_t s_tot[4];
 	__shared__ uint32_t s_maxrun;
-	if (ctl->num_binned > cap || ctl->max_tile_count <= GSR_SORT_LDS_MAX) return;
-	const uint32_t nf = min(q->n_fall, fall_cap);
+	const uint32_t nb_ = ctl->num_binned, mt_ = ctl->max_tile_count, nfq_ = q->n_fall, nsq_ = q->n_sort;   // one round trip
+	if (nb_ > cap || mt_ <= GSR_SORT_LDS_MAX) return;
+	const uint32_t nf = min(nfq_, fall_cap);
 	for (uint32_t it = blockIdx.x; it < nf; it += gridDim.x) {
 		const uint2 sg = fall_items[it];
 		const bool in_keys = (sg.y & GSR_Q_IN_KEYS) != 0u;
 		gs_radix_sort_segment((in_keys ? keys : keys2) + sg.x, (in_keys ? keys2 : keys) + sg.x, point_list + sg.x, sg.y & ~GSR_Q_IN_KEYS,
 		                      whist, s_tot, &s_maxrun);
 	}
+	const int lane = threadIdx.x & 63;
+	const uint32_t nitems = min(nsq_, sort_cap);
+	const uint32_t nwaves = gridDim.x * 4u;
+	for (uint32_t it = blockIdx.x * 4u + (threadIdx.x >> 6); it < nitems; it += nwaves) {
+		const uint2 item = sort_items[it];
+		const uint32_t cnt = item.y & ~GSR_Q_IN_KEYS;
+		const uint64_t* bs = ((item.y & GSR_Q_IN_KEYS) ? keys : keys2) + item.x;
+		uint32_t* bo = point_list + item.x;
+		if (cnt <= 64) gs_wave_sort_tile<1>(bs, bo, cnt, lane);
+		else if (cnt <= 128) gs_wave_sort_tile<2>(bs, bo, cnt, lane);
+		else if (cnt <= 256) gs_wave_sort_tile<4>(bs, bo, cnt, lane);
+		else if (cnt <= 512) gs_wave_sort_tile<8>(bs, bo, cnt, lane);
+		else gs_wave_sort_tile<16>(bs, bo, cnt, lane);
+	}
 }
 
-// queue storage behind keys2 (BinLayout::queue): [GsSortQ][sort items][segment items][fallback items]
-size_t sort_queue_bytes(size_t R, int T)
-{
-	const size_t sort_cap = R / 16 + 4 * (size_t)T + 4096, seg_cap = R / 512 + (size_t)T + 64;
-	return 256 + sizeof(uint2) * (sort_cap + 3 * seg_cap) + 256;
-}
+// queue storage behind keys2 (BinLayout::queue): [GsSortQ][sort items][segment items][fallback items][slice items][slice rows]
+struct SortQueueLayout {
+	uint32_t sort_cap, seg_cap, slice_cap;
+	size_t sort_items, seg_items, slice_items, rows, total;
+	SortQueueLayout(size_t R, int T)
+	{
+		sort_cap = (uint32_t)(R / 16 + 4 * (size_t)T + 4096);
+		seg_cap = (uint32_t)(R / 512 + (size_t)T + 64);
+		// sum over the long lists of ceil(n / 8192) <= R / 8192 + their number, and a long list has more than 1024 keys
+		slice_cap = (uint32_t)(R / GSR_SLICE_KEYS + std::min((size_t)T, R / GSR_SORT_LDS_MAX) + 1);
+		sort_items = 256;
+		seg_items = sort_items + sizeof(uint2) * (size_t)sort_cap;
+		slice_items = (seg_items + sizeof(uint2) * 2 * (size_t)seg_cap + 15) & ~(size_t)15;
+		rows = slice_items + sizeof(uint4) * (size_t)slice_cap;
+		total = rows + sizeof(uint16_t) * GSR_SLICE_ROW * (size_t)slice_cap + 256;
+	}
+};
+size_t sort_queue_bytes(size_t R, int T) { return SortQueueLayout(R, T).total; }
 
 void launch_tile_sort(int T, bool with_short, int long_level, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
                       uint32_t* point_list, char* queue, size_t R, const GsCtl* ctl, uint32_t cap, hipStream_t s)
@@ -1398,33 +1579,37 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 	// <= GSR_SORT_LDS_MAX keys: register bitonic network, one wave per tile (tile_sort_kernel).
 	// long_level 1 (lists up to GSR_SORT_GIANT keys, e.g. the C4 regime: every tile ~3.7 k): one 256-thread workgroup per tile
 	// cuts and sorts its list (tile_radix_sort_kernel, the round-2/3 kernel: 0.19 ms at C4 against 0.216 for the pipeline).
-	// long_level 2 (a longer list exists in the frame): the queue pipeline for every long list -- cut by 1024-thread
-	// workgroups, every overflowing cut cut again (two more levels), the buckets sorted by all waves of the chip.
-	if (with_short)
-		hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list, ctl, cap);
-	if (long_level <= 0) return;
-	const uint32_t sort_cap = (uint32_t)(R / 16 + 4 * (size_t)T + 4096), seg_cap = (uint32_t)(R / 512 + (size_t)T + 64);
-	if (long_level == 1) {
-		hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, GSR_SORT_LDS_MAX, (GsSortQ*)nullptr,
-		                   (uint2*)nullptr, 0u, ctl, cap);
+	// long_level 2 (a longer list exists in the frame): the queue pipeline for every long list -- cut in slices of 8192 keys by
+	// 1024-thread workgroups, every overflowing bucket cut again, the buckets sorted by all waves of the chip.
+	if (long_level <= 1) {
+		if (with_short)
+			hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list, ctl, cap, (GsSortQ*)nullptr,
+			                   (uint4*)nullptr, 0u, (uint64_t*)nullptr);
+		if (long_level == 1)
+			hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, GSR_SORT_LDS_MAX, (GsSortQ*)nullptr,
+			                   (uint2*)nullptr, 0u, ctl, cap);
 		return;
 	}
 	// (measured on the clustered scene: sending the 1025 .. 8192-key lists of such a frame through tile_radix_sort_kernel
 	// first costs 42 us in front of the pipeline -- 0.177 against 0.123 ms for the stage; the pipeline takes every long list)
+	const SortQueueLayout ql(R, T);
+	const uint32_t sort_cap = ql.sort_cap, seg_cap = ql.seg_cap, slice_cap = ql.slice_cap;
 	GsSortQ* q = reinterpret_cast<GsSortQ*>(queue);
-	uint2* sort_items = reinterpret_cast<uint2*>(queue + 256);
-	uint2* seg_items = sort_items + sort_cap;
-	uint2* seg2_items = seg_items + seg_cap;
-	uint2* fall_items = seg2_items + seg_cap;
+	uint2* sort_items = reinterpret_cast<uint2*>(queue + ql.sort_items);
+	uint2* seg_items = reinterpret_cast<uint2*>(queue + ql.seg_items);
+	uint2* fall_items = seg_items + seg_cap;
+	uint4* slice_items = reinterpret_cast<uint4*>(queue + ql.slice_items);
+	uint16_t* rows = reinterpret_cast<uint16_t*>(queue + ql.rows);
 	(void)hipMemsetAsync(q, 0, sizeof(GsSortQ), s);
-	hipLaunchKernelGGL(tile_partition_kernel<GSR_PART_THREADS>, dim3(T), dim3(GSR_PART_THREADS), 0, s, ranges, keys, keys2, point_list, q,
+	// short lists sorted; long lists entered into the slice queue, their samples sorted (gs_enter_long_list)
+	hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list, ctl, cap, q, slice_items, slice_cap, keys2);
+	hipLaunchKernelGGL(slice_hist_kernel, dim3(512), dim3(GSR_PART_THREADS), 0, s, keys, keys2, point_list, q, slice_items, slice_cap, rows, ctl, cap);
+	hipLaunchKernelGGL(slice_scatter_kernel, dim3(512), dim3(GSR_PART_THREADS), 0, s, keys, keys2, point_list, q, slice_items, slice_cap, rows,
 	                   sort_items, sort_cap, seg_items, seg_cap, ctl, cap);
-	hipLaunchKernelGGL(segment_partition_kernel, dim3(256), dim3(GSR_PART_THREADS), 0, s, keys, keys2, q, sort_items, sort_cap,
-	                   seg_items, &q->n_seg, seg_cap, seg2_items, &q->n_seg2, ctl, cap);
-	hipLaunchKernelGGL(segment_partition_kernel, dim3(256), dim3(GSR_PART_THREADS), 0, s, keys, keys2, q, sort_items, sort_cap,
-	                   seg2_items, &q->n_seg2, seg_cap, fall_items, &q->n_fall, ctl, cap);
-	hipLaunchKernelGGL(segment_fallback_kernel, dim3(256), dim3(256), 0, s, keys, keys2, point_list, q, fall_items, seg_cap, ctl, cap);
-	hipLaunchKernelGGL(bucket_sort_kernel, dim3(2048), dim3(256), 0, s, keys, keys2, point_list, q, sort_items, sort_cap, ctl, cap);
+	// oversized buckets (lists beyond 64 k keys; sampling noise) cut once more, what is STILL oversized: counting sort
+	hipLaunchKernelGGL(segment_partition_kernel, dim3(128), dim3(GSR_PART_THREADS), 0, s, keys, keys2, q, sort_items, sort_cap,
+	                   seg_items, &q->n_seg, seg_cap, fall_items, &q->n_fall, ctl, cap);
+	hipLaunchKernelGGL(bucket_sort_kernel, dim3(2048), dim3(256), 0, s, keys, keys2, point_list, q, sort_items, sort_cap, fall_items, seg_cap, ctl, cap);
 }
 
 
@@ -1705,7 +1890,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 				const float dx = A.x - pixfx, dy = A.y - pixfy;
 				const float power = FMA(A.w * dx, dy, FMA(B.x * dy, dy, (A.z * dx) * dx));
 				const float alpha = fminf(0.99f, B.y * (FX ? gs_exp_hw(power) : gs_exp(power)));
-				const bool valid = (!done) & (power <= 0.0f) & (power >= (NOCULL ? -80.0f : B.w)) & (!(alpha < 1.0f / 255.0f));
+				// FX: gs_exp_hw is valid for every power <= 0 and power < pcut implies alpha < 1/255 (preprocess): the pcut
+				// pre-test is implied by the alpha test, as in composite_bwd's FX arm -- one compare and one LDS read less per step
+				const bool valid = (!done) & (power <= 0.0f) & (FX ? true : (power >= (NOCULL ? -80.0f : B.w))) & (!(alpha < 1.0f / 255.0f));
 				const float test_T = T_ * (1 - alpha);
 				const bool stop = valid & (test_T < 0.0001f);
 				done = done | stop;

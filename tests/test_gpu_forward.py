@@ -58,10 +58,12 @@ def test_large_footprints_cooperative_binning(oracle):
     assert int(to_np(hs["tiles_touched"]).max()) > 32
 
 
-@pytest.mark.parametrize("P,lo,hi", [(2500, 256, 4096), (12000, 4096, 16384), (100000, 16384, 1 << 30)])
+@pytest.mark.parametrize("P,lo,hi", [(2500, 256, 4096), (12000, 4096, 16384), (100000, 16384, 1 << 19), (700000, 1 << 19, 1 << 30)])
 def test_long_tile_lists_lds_and_global_sort(oracle, P, lo, hi):
-    """Per-tile lists in each regime of the sort: 2 k keys (past the 1024-key register network: bucketed path with
-    register-resident keys), 10 k and 87 k keys per tile (bucketed / radix path streaming from memory)."""
+    """Per-tile lists in each regime of the sort: 2 k keys (past the 1024-key register network: one workgroup per list),
+    10 k and 87 k keys per tile (queue pipeline: 2 and 11 slices per list, sample splitters, buckets of ~128), 600 k keys
+    per tile (73 slices; the 512 buckets of the first cut hold ~1200 keys each: every one of them goes through
+    segment_partition's second cut)."""
     cam = scenes.make_camera(48, 32)
     sc = scenes.make_scene(P, cam, seed=13, sigma_px_median=6.0)
     kw = scene_kwargs(sc, True, False)

@@ -1,6 +1,7 @@
 """-m gpu: fused parameter activations against the unfused path -- torch activations exactly
 as VanillaPointCloud.get_attribute / get_features apply them (gaustudio/models/vanilla_sg.py:58-63,103-106), then the
-standard operator -- for outputs and for the gradients of the RAW attributes."""
+standard operator -- for outputs and for the gradients of the RAW attributes; test_fused_matches_unfused also anchors
+the comparison on the CPU oracle directly."""
 import numpy as np
 import pytest
 import torch
@@ -19,8 +20,10 @@ def _raw_params(sc, dev):
     return {k: v.to(dev).requires_grad_(True) for k, v in raw.items()}
 
 
-def _assert_images_equal_up_to_attributed_events(sc, cam, D, a, out_a, out_b):
-    """The in-kernel activations (expf / sqrtf of the device library) differ from torch's in the last bit, so the two
+def _assert_images_equal_up_to_attributed_events(sc, cam, D, a, out_a, out_b, oracle=None):
+    """With `oracle`: the unfused forward on the torch-activated parameters is first shown bit-equal to the CPU ORACLE's
+    (every output and intermediate), so what follows is the fused mode's own comparison with the oracle, not only with the
+    library.  The in-kernel activations (expf / sqrtf of the device library) differ from torch's in the last bit, so the two
     paths see parameters a few 1e-8 apart: images agree to 1e-5 except where that moves an alpha / transmittance across a
     threshold or a radius across a ceil() -- and every such pixel must be ATTRIBUTED by the replay of tests/attribution.py
     (decoded state of the unfused forward), exactly as against the reference kernels.  No blanket flip budget."""
@@ -31,6 +34,9 @@ def _assert_images_equal_up_to_attributed_events(sc, cam, D, a, out_a, out_b):
                           torch.cat((a["f_dc"].reshape(-1, 1, 3), a["f_rest"].reshape(-1, 15, 3)), dim=1).detach().cpu())
     st = hip_forward(sc_act, cam, D, dict(shs=sc_act.shs, scales=sc_act.scales, rotations=sc_act.rotations))
     assert torch.equal(st["color"], out_a[0]) and torch.equal(st["radii"], out_a[1])      # the same forward, decoded
+    if oracle is not None:
+        from util import compare_forward_exact, oracle_forward
+        compare_forward_exact(st, oracle_forward(oracle, sc_act, cam, D, dict(shs=sc_act.shs, scales=sc_act.scales, rotations=sc_act.rotations)))
     assert float((out_a[1] != out_b[1]).float().mean()) < 1e-4                            # radii: a ceil() on the other side at most
     ia = {k: out_a[i].detach().cpu().numpy() for i, k in ((0, "color"), (2, "depth"), (4, "opacity"))}
     ib = {k: out_b[i].detach().cpu().numpy() for i, k in ((0, "color"), (2, "depth"), (4, "opacity"))}
@@ -61,7 +67,7 @@ def test_fused_matches_unfused_at_c3_size():
 
 
 @pytest.mark.parametrize("D", [0, 3])
-def test_fused_matches_unfused(D):
+def test_fused_matches_unfused(oracle, D):
     from gaustudio_amd.fused import FusedGaussianRasterizer
     from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     dev = "cuda"
@@ -84,7 +90,7 @@ def test_fused_matches_unfused(D):
                                         raw_scales=b["scale"], raw_rotations=b["rot"])
     torch.autograd.backward([out_b[0], out_b[2], out_b[3], out_b[4]], grads)
 
-    _assert_images_equal_up_to_attributed_events(sc, cam, D, a, out_a, out_b)
+    _assert_images_equal_up_to_attributed_events(sc, cam, D, a, out_a, out_b, oracle)
     for k in a:
         ga, gb = a[k].grad, b[k].grad
         assert gb is not None and gb.shape == ga.shape, k

@@ -201,17 +201,22 @@ def test_grad_arena_gradients_are_born_in_the_flat_bucket():
     assert all(p.grad.data_ptr() != v.data_ptr() for p, v in zip(leaves3.values(), views))
 
 
-def test_tile_band_sharding_of_one_view():
+def test_tile_band_sharding_of_one_view(oracle):
     """one view split by tile rows across processes (emulated here by rendering the bands one after the
-    other).  Inside its band every output bit equals the full render's, outside it the image is an empty scene's,
-    radii / num_rendered describe the whole view, and the bands' per-Gaussian gradients SUM to the full view's."""
+    other).  Inside its band every output bit equals the full render's AND THE CPU ORACLE'S full render (the mode's own
+    oracle comparison, not only the chain of trust through the library's full view); outside it the image is an empty
+    scene's, radii / num_rendered describe the whole view, and the bands' per-Gaussian gradients SUM to the full view's and,
+    within the fp32 summation bound of tests/test_gpu_backward.py, to the oracle's double-summed gradients."""
     from gaustudio_amd import parallel
+    from util import oracle_forward
     cam = scenes.make_camera(640, 360)                      # 23 tile rows
     sc = scenes.make_scene(60000, cam, seed=14)
     kw = scene_kwargs(sc, True, False)
     grads = scenes.make_output_grads(cam)
     full = hip_forward(sc, cam, 3, kw)
     gfull = hip_backward_raw(full, sc, cam, 3, kw, grads)
+    os_ = oracle_forward(oracle, sc, cam, 3, kw)
+    ob = oracle.backward(os_, *[g.numpy() for g in grads])
     assert parallel.tile_row_band(360, 0, 2) == (0, 12) and parallel.tile_row_band(360, 1, 2) == (12, 23)
     acc = None
     covered = torch.zeros(360, dtype=torch.bool)
@@ -226,6 +231,7 @@ def test_tile_band_sharding_of_one_view():
         assert part["num_binned"] < full["num_binned"]
         for k in ("color", "depth", "median", "opacity"):
             assert torch.equal(part[k][:, rows], full[k][:, rows]), k
+            assert np.array_equal(to_np(part[k][:, rows]), os_[k].reshape(part[k].shape)[:, rows]), k + " vs the oracle"
         outside = torch.ones(360, dtype=torch.bool)
         outside[rows] = False
         assert float(part["color"][:, outside].abs().sum()) == 0.0 and float(part["opacity"][:, outside].abs().sum()) == 0.0
@@ -235,6 +241,10 @@ def test_tile_band_sharding_of_one_view():
     for k, v in gfull.items():
         scale = float(v.abs().max())
         assert float((acc[k] - v).abs().max()) <= 1e-5 * scale, k       # two partial sums instead of one: fp32 re-association only
+        if k in ob and ob[k].size:
+            keep = ob["flip9"] == 0                                       # as tests/test_gpu_backward.py::_check
+            err = np.abs(to_np(acc[k]).reshape(ob[k].shape) - ob[k])[keep].max() / max(np.abs(ob[k]).max(), 1e-30)
+            assert err < 2e-4, (k, err)
 
 
 def test_longest_first_tile_order_changes_no_bit():
