@@ -49,7 +49,7 @@ struct GsCtl {
 	uint32_t ref_rendered;   // the reference's num_rendered: sum of getRect areas (rasterizer_impl.cu:280-284)
 	uint32_t has_qmask;      // composite_fwd left one 16-bit block mask per list entry behind the list (see gs_qmask_ptr)
 	uint32_t opts;           // options the forward ran with (GSR_CTL_OPT_*): the backward of this image buffer must agree
-	uint32_t pad[1];
+	uint32_t n_long;         // tiles whose list is beyond the one-wave register sort (> GSR_SORT_LDS_MAX keys)
 };
 
 #define GSR_CTL_OPT_FAST_EXP 1u     // compositing used gs_exp_hw: the backward must take its decisions with it as well

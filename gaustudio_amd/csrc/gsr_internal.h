@@ -120,7 +120,11 @@ void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const 
 void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
                          const uint2* ranges, uint64_t* keys, const uint32_t* bsums, uint32_t* goff, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 // long_level: 0 = no list beyond GSR_SORT_LDS_MAX, 1 = lists up to GSR_SORT_GIANT keys (one workgroup per tile), 2 = longer ones too
+#define GSR_PART_REGS 8192u     // keys a 1024-thread workgroup holds in registers: a slice of the queue pipeline; the longest list of the per-list kernel
+#define GSR_SORT_MANY 1024u     // long lists in a frame from which the lists of up to GSR_SORT_GIANT keys take the per-list kernel
+#ifndef GSR_SORT_GIANT
 #define GSR_SORT_GIANT 8192u
+#endif
 void launch_tile_sort(int T, bool with_short, int long_level, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
                       uint32_t* point_list, char* queue, size_t R, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,

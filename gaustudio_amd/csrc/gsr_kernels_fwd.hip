@@ -382,7 +382,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
                                                          GsCtl* __restrict__ ctl, GsCtl* __restrict__ host_ctl)
 {
 	__shared__ uint32_t s_wave[16];
-	__shared__ uint32_t s_max[16];
+	__shared__ uint32_t s_max[16], s_long[16];
 	__shared__ uint64_t s_wave64[16];
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
@@ -432,30 +432,32 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
 	}
 	const int chunk = (T + 1023) / 1024;
 	const int b = min(T, tid * chunk), e = min(T, b + chunk);
-	uint32_t sum = 0, mx = 0;
+	uint32_t sum = 0, mx = 0, nlong = 0;
 #pragma unroll 8
 	for (int i = b; i < e; i++) {   // (unrolled: eight independent loads in flight; 32 serial round trips took 59 us at 4K)
 		const uint32_t c = tile_count[i];
 		sum += c;
 		mx = max(mx, c);
+		nlong += c > GSR_SORT_LDS_MAX ? 1u : 0u;
 	}
 	// inclusive scan across the wave, then across the 16 waves
 	const uint32_t incl = wave_incl_scan(sum, lane);
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+	for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); nlong += (uint32_t)__shfl_xor((int)nlong, o, 64); }
 	uint64_t wsum = sum;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) wsum += (uint64_t)__shfl_xor((long long)wsum, o, 64);
 	if (lane == 63) s_wave[wv] = incl;
-	if (lane == 0) { s_max[wv] = mx; s_wave64[wv] = wsum; }
+	if (lane == 0) { s_max[wv] = mx; s_long[wv] = nlong; s_wave64[wv] = wsum; }
 	__syncthreads();
-	uint32_t base = 0, total = 0, gmax = 0;
+	uint32_t base = 0, total = 0, gmax = 0, glong = 0;
 	uint64_t total64 = 0;
 	for (int w = 0; w < 16; w++) {
 		if (w < wv) base += s_wave[w];
 		total += s_wave[w];
 		total64 += s_wave64[w];
 		gmax = max(gmax, s_max[w]);
+		glong += s_long[w];
 	}
 	// the u32 scan wraps past 2^32 instances (the host rejects the frame: the reference count is at least as large);
 	// report a count no capacity can hold so that every kernel enqueued ahead of the host's check leaves at once
@@ -471,6 +473,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int T, uint32_t* __rest
 	if (tid == 0) {
 		ctl->num_binned = total;           // <= the reference count, whose overflow block 1 checks
 		ctl->max_tile_count = gmax;
+		ctl->n_long = glong;
 		if (host_ctl) {
 			host_ctl->num_binned = total;
 			host_ctl->max_tile_count = gmax;
@@ -807,8 +810,8 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(int T, const uint2* __re
 	const uint2 range = ranges[tile];
 	const uint32_t n = range.y - range.x;
 	if (n == 0) return;
-	if (n > GSR_SORT_LDS_MAX) {   // handled by tile_radix_sort_kernel, or (q) by the queue pipeline
-		if (q != nullptr) gs_enter_long_list(range, q, slice_items, slice_cap, keys, keys2, lane);
+	if (n > GSR_SORT_LDS_MAX) {   // handled by tile_radix_sort_kernel, or (q) by the queue pipeline -- see launch_tile_sort
+		if (q != nullptr && (n > GSR_PART_REGS || ctl->n_long < GSR_SORT_MANY)) gs_enter_long_list(range, q, slice_items, slice_cap, keys, keys2, lane);
 		return;
 	}
 	const uint64_t* src = keys + range.x;
@@ -905,7 +908,6 @@ struct GsSortQ {
 #define GSR_Q_IN_KEYS 0x80000000u    // item flag (in .y): the bucket's keys are in `keys` (second round), else in `keys2`
 #define GSR_PART_THREADS 1024
 #define GSR_PART_AVG 128u            // target keys per bucket
-#define GSR_PART_REGS 8192u          // lists up to this many keys are read once and held in registers (NT threads x 8192 / NT keys)
 
 // One workgroup (NT threads) cuts the n > NT keys at src into buckets written to dst (same offsets); items are positions
 // relative to the binning arrays (`abs0` = index of src[0] in them).  item_flag marks where the buckets live.
@@ -966,6 +968,9 @@ __device__ __forceinline__ uint32_t gs_tree_bucket(const unsigned long long* tre
 	while (v < B) v = 2u * v + (tree[v] <= k ? 1u : 0u);
 	return v - B;
 }
+// samples per list: four per bucket, 64 .. 1024 (a 3.7 k-key list has 32 buckets: 128 samples, sorted by its wave at 1/30
+// of the cost of 1024 -- with 1024 for every list the sample sorts of a C4-like frame took 81 us)
+__device__ __forceinline__ uint32_t gs_sample_count(uint32_t B) { return min(1024u, max(64u, 4u * B)); }
 __device__ __forceinline__ uint32_t gs_bucket_count(uint32_t n, uint32_t nt)   // B * GSR_PART_AVG >= n, 2 <= B <= nt / 2
 {
 	uint32_t B = 2;
@@ -1082,7 +1087,7 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 	const uint2 range = ranges[blockIdx.x];
 	const uint32_t n = range.y - range.x;
 	if (n <= lo) return;
-	if (q != nullptr && n > GSR_PART_REGS) return;   // the queue pipeline's (tile_partition_kernel), when it is launched
+	if (q != nullptr && (n > GSR_PART_REGS || ctl->n_long < GSR_SORT_MANY)) return;   // the queue pipeline's (tile_sort_kernel entered it)
 	if (q == nullptr && ctl->max_tile_count > GSR_SORT_GIANT) return;   // launched for the wrong regime: the host re-launches with the pipeline
 	const int tid = threadIdx.x, wv = tid >> 6;
 	uint64_t* src = keys + range.x;
@@ -1289,6 +1294,16 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 //                   put into each bucket; keys scattered into `keys2`; slice 0 enters the list's buckets into the work queue.
 #define GSR_SLICE_KEYS GSR_PART_REGS
 #define GSR_SLICE_ROW (GSR_PART_THREADS / 2)     // u16 counts per slice row
+template <int KPL>
+__device__ __forceinline__ void gs_sort_list_samples(const uint64_t* __restrict__ src, uint32_t n, uint64_t* __restrict__ out, int lane)
+{
+	uint64_t k[KPL];
+#pragma unroll
+	for (int e = 0; e < KPL; e++) k[e] = src[(uint32_t)(((unsigned long long)(e * 64 + lane) * n) / (64u * KPL))];
+	gs_wave_sort_regs<KPL>(k, lane);
+#pragma unroll
+	for (int e = 0; e < KPL; e++) out[lane * KPL + e] = k[e];
+}
 __device__ __forceinline__ void gs_enter_long_list(uint2 range, GsSortQ* __restrict__ q, uint4* __restrict__ slice_items, uint32_t slice_cap,
                                                    const uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2, int lane)
 {
@@ -1299,23 +1314,68 @@ __device__ __forceinline__ void gs_enter_long_list(uint2 range, GsSortQ* __restr
 	base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 	if (base + nsl > slice_cap) { if (lane == 0) q->err = 1u; return; }   // cannot happen: SortQueueLayout::slice_cap
 	for (uint32_t sl = lane; sl < nsl; sl += 64) slice_items[base + sl] = make_uint4(range.x, n, sl, base);
-	// samples: key at position floor(i n / 1024), i = 0 .. 1023 (n > 1024: distinct positions, distinct keys)
-	uint64_t k[16];
-#pragma unroll
-	for (int e = 0; e < 16; e++) k[e] = keys[range.x + (uint32_t)(((unsigned long long)(e * 64 + lane) * n) >> 10)];
-	gs_wave_sort_regs<16>(k, lane);
-	uint64_t* out = keys2 + range.x + (uint32_t)lane * 16u;
-#pragma unroll
-	for (int e = 0; e < 16; e++) out[e] = k[e];
+	// samples: the keys at positions floor(i n / S), i = 0 .. S - 1 (n > 1024 >= S: distinct positions, distinct keys), sorted
+	const uint32_t S = gs_sample_count(gs_bucket_count(n, (uint32_t)GSR_PART_THREADS));
+	if (S <= 64) gs_sort_list_samples<1>(keys + range.x, n, keys2 + range.x, lane);
+	else if (S <= 128) gs_sort_list_samples<2>(keys + range.x, n, keys2 + range.x, lane);
+	else if (S <= 256) gs_sort_list_samples<4>(keys + range.x, n, keys2 + range.x, lane);
+	else if (S <= 512) gs_sort_list_samples<8>(keys + range.x, n, keys2 + range.x, lane);
+	else gs_sort_list_samples<16>(keys + range.x, n, keys2 + range.x, lane);
 }
 
+// bucket starts from the bucket totals (thread b < B: tot, what slices in front hold: pre), the buckets entered into the work
+// queues when `enter` (<= 1024 keys -> sort item, more -> a segment for the next level; flag 0: the buckets live in keys2),
+// the slice's keys scattered into dst.  Returns this thread's bucket start.
+template <int NT, int RK>
+__device__ __forceinline__ uint32_t gs_slice_place(uint32_t tot, uint32_t pre, bool enter, uint32_t B, uint32_t abs0, uint32_t cnt,
+                                                   const uint64_t (&kreg)[RK], const uint32_t (&breg)[RK], uint64_t* __restrict__ dst,
+                                                   GsSortQ* __restrict__ q, uint2* __restrict__ sort_items, uint32_t sort_cap,
+                                                   uint2* __restrict__ seg_items, uint32_t seg_cap, uint32_t* s_cur, uint32_t* s_wtot,
+                                                   uint32_t* s_misc)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
+	uint32_t incl = tot;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+		if (lane >= o) incl += t;
+	}
+	if (lane == 63) s_wtot[wv] = incl;
+	__syncthreads();
+	uint32_t start = incl - tot;
+	for (int w = 0; w < wv; w++) start += s_wtot[w];
+	if ((uint32_t)tid < B) s_cur[tid] = start + pre;
+	const bool is_s = enter && tot > 0u && tot <= GSR_SORT_LDS_MAX, is_o = enter && tot > GSR_SORT_LDS_MAX;
+	uint32_t ls = 0, lo_ = 0;
+	if (is_s) ls = atomicAdd(&s_misc[0], 1u);
+	if (is_o) lo_ = atomicAdd(&s_misc[1], 1u);
+	__syncthreads();
+	if (tid == 0) {   // one reservation per list and queue
+		const uint32_t ts = s_misc[0], to = s_misc[1];
+		s_misc[2] = ts ? atomicAdd(&q->n_sort, ts) : 0u;
+		s_misc[3] = to ? atomicAdd(&q->n_seg, to) : 0u;
+	}
+	__syncthreads();
+	const uint32_t gs = s_misc[2], go = s_misc[3];
+	if (gs + s_misc[0] > sort_cap || go + s_misc[1] > seg_cap) { if (tid == 0) q->err = 1u; }
+	if (is_s) { if (gs + ls < sort_cap) sort_items[gs + ls] = make_uint2(abs0 + start, tot); }
+	else if (is_o) { if (go + lo_ < seg_cap) seg_items[go + lo_] = make_uint2(abs0 + start, tot); }
+#pragma unroll
+	for (int r = 0; r < RK; r++)
+		if ((uint32_t)tid + (uint32_t)NT * r < cnt) dst[atomicAdd(&s_cur[breg[r]], 1u)] = kreg[r];
+	return start;
+}
+
+// (A one-slice list finished by its slice_hist workgroup -- starts, scatter and the sort of its buckets by the workgroup's own
+// sixteen waves, no queue round trip -- was built and measured SLOWER: clustered-scene sort 0.076 -> 0.097 ms, C4 through the
+// pipeline 0.337 -> 0.351 ms: a 3.7 k-key list has 32 buckets, two per wave, while the chip-wide bucket_sort runs them all at once.)
 __global__ __launch_bounds__(GSR_PART_THREADS) void slice_hist_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keys2,
                                                                       uint32_t* __restrict__ bucket_ids, const GsSortQ* __restrict__ q,
                                                                       const uint4* __restrict__ slice_items, uint32_t slice_cap,
                                                                       uint16_t* __restrict__ rows, const GsCtl* __restrict__ ctl, uint32_t cap)
 {
 	constexpr int NT = GSR_PART_THREADS, RK = (int)(GSR_SLICE_KEYS / NT);
-	static_assert(NT == 1024, "gs_enter_long_list sorts 1024 samples");
 	__shared__ uint32_t s_cnt[GSR_SLICE_ROW];
 	__shared__ unsigned long long s_tree[GSR_SLICE_ROW];
 	// the guard words, the queue length and this workgroup's first item are fetched together: one round trip instead of three
@@ -1328,7 +1388,7 @@ __global__ __launch_bounds__(GSR_PART_THREADS) void slice_hist_kernel(const uint
 		const uint4 item = it == blockIdx.x ? item0 : slice_items[it];
 		const uint64_t* src = keys + item.x;
 		const uint32_t n = item.y, lo = item.z * GSR_SLICE_KEYS, cnt = min(GSR_SLICE_KEYS, n - lo);
-		const uint32_t B = gs_bucket_count(n, (uint32_t)NT), spb = (uint32_t)NT / B;
+		const uint32_t B = gs_bucket_count(n, (uint32_t)NT), spb = gs_sample_count(B) / B;
 		gs_build_splitter_tree(s_tree, reinterpret_cast<const unsigned long long*>(keys2 + item.x), B, spb);   // the list's sorted samples (gs_enter_long_list)
 		uint64_t kreg[RK];
 #pragma unroll
@@ -1373,7 +1433,7 @@ __global__ __launch_bounds__(GSR_PART_THREADS) void slice_scatter_kernel(const u
 	const uint32_t nb_ = ctl->num_binned, mt_ = ctl->max_tile_count, nq_ = q->n_slice;   // one round trip, see slice_hist_kernel
 	const uint4 item0 = blockIdx.x < slice_cap ? slice_items[blockIdx.x] : make_uint4(0u, 0u, 0u, 0u);
 	if (nb_ > cap || mt_ <= GSR_SORT_LDS_MAX) return;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int tid = threadIdx.x;
 	const uint32_t nsl_all = min(nq_, slice_cap);
 	for (uint32_t it = blockIdx.x; it < nsl_all; it += gridDim.x) {
 		const uint4 item = it == blockIdx.x ? item0 : slice_items[it];
@@ -1388,7 +1448,6 @@ __global__ __launch_bounds__(GSR_PART_THREADS) void slice_scatter_kernel(const u
 			kreg[r] = i < cnt ? keys[item.x + lo + i] : 0ull;
 			breg[r] = i < cnt ? bucket_ids[item.x + lo + i] : 0u;
 		}
-		if (tid == 0) { s_misc[0] = 0u; s_misc[1] = 0u; }
 		// thread b: the list's total of bucket b and what the slices in front of this one hold of it
 		uint32_t tot = 0, pre = 0;
 		if ((uint32_t)tid < B) {
@@ -1400,37 +1459,8 @@ __global__ __launch_bounds__(GSR_PART_THREADS) void slice_scatter_kernel(const u
 				pre += r < sl ? c : 0u;
 			}
 		}
-		uint32_t incl = tot;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-			if (lane >= o) incl += t;
-		}
-		if (lane == 63) s_wtot[wv] = incl;
-		__syncthreads();
-		uint32_t start = incl - tot;
-		for (int w = 0; w < wv; w++) start += s_wtot[w];
-		if ((uint32_t)tid < B) s_cur[tid] = start + pre;
-		// slice 0 enters the list's buckets into the queues: <= 1024 keys -> sort item, more -> a segment for the next level
-		const bool is_s = sl == 0u && tot > 0u && tot <= GSR_SORT_LDS_MAX, is_o = sl == 0u && tot > GSR_SORT_LDS_MAX;
-		uint32_t ls = 0, lo_ = 0;
-		if (is_s) ls = atomicAdd(&s_misc[0], 1u);
-		if (is_o) lo_ = atomicAdd(&s_misc[1], 1u);
-		__syncthreads();
-		if (tid == 0) {   // one reservation per list and queue
-			const uint32_t ts = s_misc[0], to = s_misc[1];
-			s_misc[2] = ts ? atomicAdd(&q->n_sort, ts) : 0u;
-			s_misc[3] = to ? atomicAdd(&q->n_seg, to) : 0u;
-		}
-		__syncthreads();
-		const uint32_t gs = s_misc[2], go = s_misc[3];
-		if (gs + s_misc[0] > sort_cap || go + s_misc[1] > seg_cap) { if (tid == 0) q->err = 1u; }
-		if (is_s) { if (gs + ls < sort_cap) sort_items[gs + ls] = make_uint2(item.x + start, tot); }          // flag 0: the bucket lives in keys2
-		else if (is_o) { if (go + lo_ < seg_cap) seg_items[go + lo_] = make_uint2(item.x + start, tot); }
-		uint64_t* dst = keys2 + item.x;
-#pragma unroll
-		for (int r = 0; r < RK; r++)
-			if ((uint32_t)tid + (uint32_t)NT * r < cnt) dst[atomicAdd(&s_cur[breg[r]], 1u)] = kreg[r];
+		gs_slice_place<NT, RK>(tot, pre, sl == 0u, B, item.x, cnt, kreg, breg, keys2 + item.x, q, sort_items, sort_cap, seg_items, seg_cap,
+		                       s_cur, s_wtot, s_misc);   // slice 0 enters the list's buckets into the queues
 		__syncthreads();
 	}
 }
@@ -1578,9 +1608,10 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 {
 	// <= GSR_SORT_LDS_MAX keys: register bitonic network, one wave per tile (tile_sort_kernel).
 	// long_level 1 (lists up to GSR_SORT_GIANT keys, e.g. the C4 regime: every tile ~3.7 k): one 256-thread workgroup per tile
-	// cuts and sorts its list (tile_radix_sort_kernel, the round-2/3 kernel: 0.19 ms at C4 against 0.216 for the pipeline).
-	// long_level 2 (a longer list exists in the frame): the queue pipeline for every long list -- cut in slices of 8192 keys by
-	// 1024-thread workgroups, every overflowing bucket cut again, the buckets sorted by all waves of the chip.
+	// cuts and sorts its list (tile_radix_sort_kernel, the round-2/3 kernel: 0.19 ms at C4 against 0.34 for the pipeline).
+	// long_level 2 (a longer list exists in the frame): the queue pipeline -- lists cut in slices of 8192 keys by 1024-thread
+	// workgroups, an overflowing bucket cut again, the buckets sorted by all waves of the chip -- for the lists beyond 8192 keys
+	// and, unless the frame has MANY long lists, for all the others beyond 1024 too.
 	if (long_level <= 1) {
 		if (with_short)
 			hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list, ctl, cap, (GsSortQ*)nullptr,
@@ -1590,8 +1621,6 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 			                   (uint2*)nullptr, 0u, ctl, cap);
 		return;
 	}
-	// (measured on the clustered scene: sending the 1025 .. 8192-key lists of such a frame through tile_radix_sort_kernel
-	// first costs 42 us in front of the pipeline -- 0.177 against 0.123 ms for the stage; the pipeline takes every long list)
 	const SortQueueLayout ql(R, T);
 	const uint32_t sort_cap = ql.sort_cap, seg_cap = ql.seg_cap, slice_cap = ql.slice_cap;
 	GsSortQ* q = reinterpret_cast<GsSortQ*>(queue);
@@ -1603,6 +1632,11 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 	(void)hipMemsetAsync(q, 0, sizeof(GsSortQ), s);
 	// short lists sorted; long lists entered into the slice queue, their samples sorted (gs_enter_long_list)
 	hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list, ctl, cap, q, slice_items, slice_cap, keys2);
+	// a frame with MANY long lists (>= GSR_SORT_MANY, e.g. C4 plus one giant tile): those of up to 8192 keys go to the one-workgroup-
+	// per-list kernel (throughput: 0.19 ms for C4's 4346 lists against 0.34 ms through the queues); a cut of it that overflows
+	// (depths piled up) becomes a segment of the pipeline.  With few long lists (clustered scene: 341) that kernel would be a
+	// latency -- its longest list, alone on a CU, 42 us -- in front of a pipeline that takes them in its stride: it leaves at once.
+	hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, GSR_SORT_LDS_MAX, q, seg_items, seg_cap, ctl, cap);
 	hipLaunchKernelGGL(slice_hist_kernel, dim3(512), dim3(GSR_PART_THREADS), 0, s, keys, keys2, point_list, q, slice_items, slice_cap, rows, ctl, cap);
 	hipLaunchKernelGGL(slice_scatter_kernel, dim3(512), dim3(GSR_PART_THREADS), 0, s, keys, keys2, point_list, q, slice_items, slice_cap, rows,
 	                   sort_items, sort_cap, seg_items, seg_cap, ctl, cap);

@@ -74,6 +74,28 @@ def test_long_tile_lists_lds_and_global_sort(oracle, P, lo, hi):
     compare_forward_exact(hs, os_)
 
 
+def test_many_long_lists_and_a_giant_one(oracle):
+    """The sort regime of a C4-like frame with one giant tile: more than 1024 lists beyond the one-wave sort (they take the
+    one-workgroup-per-list kernel) AND lists beyond 8192 keys (the slice pipeline), in one frame."""
+    cam = scenes.make_camera(576, 512)
+    sc = scenes.make_scene(260000, cam, seed=21, sigma_px_median=5.0)
+    m = sc.means3D.clone()
+    K = 12000                                          # a clump on the line of sight of tile (10, 10), depths kept
+    z = m[:K, 2]
+    x = (10 * 16 + 8.5 - cam.width / 2) / (cam.width / 2) * cam.tanfovx
+    y = (10 * 16 + 8.5 - cam.height / 2) / (cam.height / 2) * cam.tanfovy
+    g = torch.Generator().manual_seed(5)
+    m[:K, 0] = z * (x + 0.002 * torch.randn(K, generator=g))
+    m[:K, 1] = z * (y + 0.002 * torch.randn(K, generator=g))
+    sc = sc._replace(means3D=m.contiguous())
+    kw = scene_kwargs(sc, True, False)
+    os_ = oracle_forward(oracle, sc, cam, 1, kw)
+    n = os_["ranges"][:, 1].astype(np.int64) - os_["ranges"][:, 0]
+    assert int((n > 1024).sum()) >= 1024 and int(n.max()) > 8192 and int((n <= 8192).sum()) > 1000
+    hs = hip_forward(sc, cam, 1, kw)
+    compare_forward_exact(hs, os_)
+
+
 @pytest.mark.parametrize("P", [2000, 40000, 300000])
 def test_depth_ties_resolve_by_id(oracle, P):
     """Equal depths inside a tile must order by ascending Gaussian id; P=40000 puts ~10 k keys
