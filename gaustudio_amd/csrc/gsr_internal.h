@@ -112,7 +112,7 @@ void launch_bin_scatter(int P, int gx, const int* radii, const uint32_t* tiles_t
                         const uint2* ranges, uint32_t* cursor, uint64_t* keys, const GsCtl* ctl, uint32_t cap,
                         hipStream_t s);
 // binning without global atomics (default when the tile grid fits an LDS histogram)
-int bin_chunks(int P);
+int bin_chunks(int P, int T);
 size_t bin_hist_bytes(int P, int T);
 bool bin_lds_path_ok(int T);
 void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,

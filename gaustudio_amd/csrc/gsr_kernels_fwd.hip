@@ -585,6 +585,9 @@ void launch_bin_scatter(int P, int gx, const int* radii, const uint32_t* tiles_t
 // One 1024-thread workgroup per chunk (16 waves per CU instead of 4 hide the record-fetch latency: the kernels are
 // latency-, not bandwidth-bound).
 #define GSR_BIN_THREADS 1024
+#ifndef GSR_BIN_BATCH
+#define GSR_BIN_BATCH 4
+#endif
 template <bool SCATTER>
 __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int chunk, int gx, int T,
                                                         const uint32_t* __restrict__ tiles_touched,
@@ -610,24 +613,41 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int c
 	uint32_t* row = Hm + (size_t)g * T;
 	for (int i = tid; i < T; i += GSR_BIN_THREADS) cnt[i] = SCATTER ? ranges[i].x + row[i] : 0u;
 	__syncthreads();
+	// The scatter takes NB = 4 Gaussians per thread and round: their visibility words are fetched together, then their records
+	// together (culled ones read the chunk's first record: one cached line), then the tiles are walked.  One Gaussian per round
+	// is a chain of dependent round trips in which every load's wait also waits for the scattered stores issued before it
+	// (vmcnt counts stores): C4 0.256 -> 0.240 ms, C5 0.174 -> 0.154, C3 unchanged (8 gave C5 0.138 but C4 0.246; the counting
+	// pass, which stores nothing, lost 2.5 us at C3 with batches and keeps one).  What bounds the scatter beyond that is the
+	// issue rate of uncoalesced 8-B stores -- one lane-address per ~4 cycles and CU: 16 M keys = 0.1-0.2 ms at C4 -- and
+	// twice the workgroups (512 chunks) only shortens the per-(chunk, tile) runs: measured slower (C3 0.0525 -> 0.055, C4 0.240 -> 0.253).
+	constexpr int NB = SCATTER ? GSR_BIN_BATCH : 1;
 	const int base = g * chunk;
-	for (int off = 0; off < chunk; off += GSR_BIN_THREADS) {
-		const int idx = base + off + tid;
-		bool vis = false;
-		int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
-		uint32_t dbits = 0, dead = 0;
-		if (idx < P && tiles_touched[idx] > 0) {
-			vis = true;
-			const uint4 q3 = recs[idx].q3;
-			rminx = q3.x & 0xffff; rminy = q3.x >> 16;
-			rmaxx = q3.y & 0xffff; rmaxy = q3.y >> 16;
-			dead = (q3.z >> GSR_Q3Z_DEAD_SHIFT) & 15u;
-			if (SCATTER) dbits = (uint32_t)__float_as_int(recs[idx].q1.z);
+	for (int off = 0; off < chunk; off += NB * GSR_BIN_THREADS) {
+		int idxs[NB];
+		bool vis[NB];
+#pragma unroll
+		for (int u = 0; u < NB; u++) {
+			idxs[u] = base + off + u * GSR_BIN_THREADS + tid;
+			vis[u] = off + u * GSR_BIN_THREADS < chunk && idxs[u] < P && tiles_touched[idxs[u]] > 0;
 		}
-		for_each_tile(vis, rminx, rminy, rmaxx, rmaxy, dead, dbits, (uint32_t)idx, [&](int x, int y, uint32_t d, uint32_t id) {
-			const uint32_t slot = atomicAdd(&cnt[y * gx + x], 1u);   // ds_add(_rtn)_u32
-			if (SCATTER) keys[slot] = ((uint64_t)d << 32) | id;
-		});
+		uint4 q3s[NB];
+		uint32_t dbs[NB];
+#pragma unroll
+		for (int u = 0; u < NB; u++) {
+			const GsRec* r = recs + (vis[u] ? idxs[u] : base);
+			q3s[u] = r->q3;
+			dbs[u] = SCATTER ? (uint32_t)__float_as_int(r->q1.z) : 0u;
+		}
+#pragma unroll
+		for (int u = 0; u < NB; u++) {
+			const uint4 q3 = q3s[u];
+			const int rminx = q3.x & 0xffff, rminy = q3.x >> 16, rmaxx = q3.y & 0xffff, rmaxy = q3.y >> 16;
+			const uint32_t dead = (q3.z >> GSR_Q3Z_DEAD_SHIFT) & 15u;
+			for_each_tile(vis[u], rminx, rminy, rmaxx, rmaxy, dead, dbs[u], (uint32_t)idxs[u], [&](int x, int y, uint32_t d, uint32_t id) {
+				const uint32_t slot = atomicAdd(&cnt[y * gx + x], 1u);   // ds_add(_rtn)_u32
+				if (SCATTER) keys[slot] = ((uint64_t)d << 32) | id;
+			});
+		}
 	}
 	if (!SCATTER) {
 		__syncthreads();
@@ -665,8 +685,16 @@ __global__ __launch_bounds__(64 * GSR_COLSCAN_Q) void bin_colscan_kernel(int G, 
 	}
 }
 
-int bin_chunks(int P) { return P >= 256 * GSR_BIN_THREADS ? 256 : (P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS; }
-size_t bin_hist_bytes(int P, int T) { return sizeof(uint32_t) * (size_t)bin_chunks(P) * (size_t)T; }
+#ifndef GSR_BIN_CHUNKS2
+#define GSR_BIN_CHUNKS2 256
+#endif
+// chunks = workgroups: one per CU, or (GSR_BIN_CHUNKS2 = 512) two per CU where two tile histograms fit the LDS
+int bin_chunks(int P, int T)
+{
+	const int gmax = (size_t)T * sizeof(uint32_t) <= 72 * 1024 ? GSR_BIN_CHUNKS2 : 256;
+	return P >= gmax * GSR_BIN_THREADS ? gmax : (P >= 256 * GSR_BIN_THREADS ? 256 : (P + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS);
+}
+size_t bin_hist_bytes(int P, int T) { return sizeof(uint32_t) * (size_t)bin_chunks(P, T) * (size_t)T; }
 bool bin_lds_path_ok(int T) { return (size_t)T * sizeof(uint32_t) <= 150 * 1024; }
 
 static void set_dyn_lds(const void* fn, size_t bytes)
@@ -677,7 +705,7 @@ static void set_dyn_lds(const void* fn, size_t bytes)
 void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
                      uint32_t* tile_count, hipStream_t s)
 {
-	const int G = bin_chunks(P);
+	const int G = bin_chunks(P, T);
 	const int chunk = ((P + G - 1) / G + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS * GSR_BIN_THREADS;
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<false>, lds);
@@ -690,7 +718,7 @@ void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, co
                          const uint2* ranges, uint64_t* keys, const uint32_t* bsums, uint32_t* goff, const GsCtl* ctl,
                          uint32_t cap, hipStream_t s)
 {
-	const int G = bin_chunks(P);
+	const int G = bin_chunks(P, T);
 	const int chunk = ((P + G - 1) / G + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS * GSR_BIN_THREADS;
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<true>, lds);
