@@ -911,7 +911,7 @@ __device__ __forceinline__ void tile_radix_pass(const uint64_t* __restrict__ src
 	__syncthreads();
 }
 
-// ---- long lists, round 4: partition by key range, then sort the buckets ALL OVER THE CHIP -------------------------
+// ---- long lists, round 4: partition by sample splitters, then sort the buckets ALL OVER THE CHIP ------------------
 // Until round 3 one workgroup did everything for its tile: cut the list into <= 1024 equal-width depth buckets, sort the
 // buckets with its four waves -- and, when one bucket overflowed (depths piled up: the surface a tile looks at), fall back
 // to four counting passes over the whole list.  On a clustered scene (bench.py --workload C2-clustered: per-tile lists
@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 	}
 	if (q != nullptr) {
 		// an overflowing cut while the queue pipeline runs anyway (a list > GSR_PART_REGS keys exists in this frame): the
-		// list becomes a segment of its second stage (64-bit key ranges, buckets sorted all over the chip) -- its keys are
+		// list becomes a segment of its second stage (cut by its own sample splitters, buckets sorted all over the chip) -- its keys are
 		// still where the scatter left them, in `keys`
 		if (tid == 0) {
 			const uint32_t at = atomicAdd(&q->n_seg, 1u);
@@ -1493,9 +1493,9 @@ __global__ __launch_bounds__(GSR_PART_THREADS) void slice_scatter_kernel(const u
 	}
 }
 
-// further levels: the oversized buckets of the level before (and the overflowing lists tile_radix_sort_kernel hands over) cut
-// again, each by its OWN key range, into the other key buffer; workgroups stride over the segment queue `in_items`, what is
-// still oversized goes to `out_items` (the next level's queue, or the fallback's)
+// second level: the oversized buckets of the first cut (and the overflowing lists tile_radix_sort_kernel hands over) cut again,
+// each by its OWN sample splitters (gs_partition_segment), into the other key buffer; workgroups stride over the segment queue
+// `in_items`, what is still oversized goes to `out_items` (the fallback's queue)
 __global__ __launch_bounds__(GSR_PART_THREADS) void segment_partition_kernel(uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
                                                                             GsSortQ* __restrict__ q, uint2* __restrict__ sort_items,
                                                                             uint32_t sort_cap, const uint2* __restrict__ in_items,
