@@ -74,6 +74,18 @@ def test_long_tile_lists_lds_and_global_sort(oracle, P, lo, hi):
     compare_forward_exact(hs, os_)
 
 
+def test_one_list_of_millions_of_keys(oracle):
+    """One tile, 4.7 M keys: every one of the first cut's 512 buckets holds ~9 k keys, i.e. is a segment too long for a
+    workgroup's registers -- segment_partition's streaming path (gs_partition_segment, n > 8192)."""
+    cam = scenes.make_camera(16, 16)
+    sc = scenes.make_scene(4_700_000, cam, seed=3, sigma_px_median=1.5)
+    kw = scene_kwargs(sc, True, False)
+    os_ = oracle_forward(oracle, sc, cam, 0, kw)
+    assert os_["ranges"].shape[0] == 1 and int(os_["ranges"][0, 1]) > 512 * 8192
+    hs = hip_forward(sc, cam, 0, kw)
+    compare_forward_exact(hs, os_)
+
+
 def test_many_long_lists_and_a_giant_one(oracle):
     """The sort regime of a C4-like frame with one giant tile: more than 1024 lists beyond the one-wave sort (they take the
     one-workgroup-per-list kernel) AND lists beyond 8192 keys (the slice pipeline), in one frame."""
@@ -96,9 +108,11 @@ def test_many_long_lists_and_a_giant_one(oracle):
     compare_forward_exact(hs, os_)
 
 
-@pytest.mark.parametrize("P", [2000, 40000, 300000])
+@pytest.mark.parametrize("P", [2000, 12000, 40000, 300000])
 def test_depth_ties_resolve_by_id(oracle, P):
-    """Equal depths inside a tile must order by ascending Gaussian id; P=40000 puts ~10 k keys
+    """Equal depths inside a tile must order by ascending Gaussian id; P=12000: 3-6 k keys per tile, the
+    one-workgroup-per-list kernel, whose equal-width depth buckets overflow on ~18 distinct depths: its counting-sort fallback
+    with the per-run id fix-up; P=40000 puts ~10 k keys
     with only ~18 distinct depths in each tile (runs of ~500 equal depths), P=300000 ~75 k keys with runs of
     ~4 k: the radix path's long-run branch (full 64-bit LSD sort instead of the per-run fix-up)."""
     cam = scenes.make_camera(64, 64)
