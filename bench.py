@@ -292,8 +292,8 @@ def run_extract(a, dev, scenes, _C):
             marks.append(e)
         return nrm, invalid
 
-    for i in range(max(a.warmup, K)):                                           # at least one full ring: allocates the blocks
-        step(i)
+    for i in range(max(0, a.settle) + max(a.warmup, K)):                        # --settle (sustained clock), then the warm-up: at least one
+        step(i)                                                                 # full ring, which also allocates the blocks
     torch.cuda.synchronize()
     _C.set_profiling(True)
     t0 = time.perf_counter()
@@ -347,6 +347,7 @@ def run_extract(a, dev, scenes, _C):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     line = {"metric": "Mpixels/s depth+normal render + TSDF integrate @1M Gaussians 1920x1080 (gs-extract-mesh path)",
             "value": round(HW * a.steps / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, K),
+            "settle_steps": max(0, a.settle),
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3-extract: 1M synthetic Gaussians, 1920x1080, SH degree 3, no_grad render -> median-depth mask -> "
@@ -368,6 +369,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=100,
+                    help="untimed steps of the same workload run ONCE, in front of the --warmup steps, to bring the device to its "
+                         "sustained clock (after the idle seconds of scene generation the first ~30 steps of the two VALU-bound "
+                         "compositing kernels run 5-6 %% slower: --steps 20 --warmup 5 measured 1.076 ms, the same 20 steps after "
+                         "50 or 200 warm-up steps 1.030-1.033 ms; profiles/r04_warmup_ramp.txt); 0 = off")
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS) + ["C3-extract"])
     ap.add_argument("--fwd-only", action="store_true", help="time the no_grad forward only (inference paths)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -524,7 +530,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    settled = {"done": False}
+
     def timed_run(fn, steps, warmup):
+        if not settled["done"]:                              # once per process: the device at its sustained clock (see --settle)
+            settled["done"] = True
+            for _ in range(max(0, a.settle)):
+                fn(False)
         for _ in range(warmup):
             fn(False)
         barrier()
@@ -675,6 +687,7 @@ def main():
             "metric": "Mpixels/s fwd+bwd @1M Gaussians 1920x1080" if a.workload == "C3" and not a.fwd_only
                       else f"Mpixels/s {'fwd' if a.fwd_only else 'fwd+bwd'} @{a.workload}",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "settle_steps": max(0, a.settle),
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "gaussians": P, "visible": vis, "width": W, "height": H, "sh_degree": D,
