@@ -6,7 +6,7 @@ name="${1:-prof}"; wl="${2:-C3}"; passes="${3:-stats sq fetch write}"; extra="${
 out="gpurun_out/$name"; mkdir -p "$out"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 root="$(pwd)"
-bench="python $root/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-ref-ab --no-extras $extra"
+bench="python $root/bench.py --workload $wl --steps 5 --warmup 2 --settle 0 --no-cpu-baseline --no-ref-ab --no-extras $extra"   # (--settle 0: counters, not clocks)
 cd /tmp
 for p in $passes; do
   case $p in
