@@ -281,12 +281,15 @@ def inspect_image(imgBuffer, width, height):
 
 
 def set_profiling(enable):
-    lib().gsr_set_profiling(ctypes.c_int(bool(enable)))
+    """False / 0: off.  True / 1: one HIP event at every stage boundary of every forward / backward (nine per step: ~3 % of a C3
+    step).  2: only the two boundaries of composite_fwd, the north-star kernel (what bench.py's timed steps record)."""
+    lib().gsr_set_profiling(ctypes.c_int(int(enable)))
 
 
 def last_forward_ms():
-    """Mean per-stage GPU milliseconds over the forward calls since set_profiling(True) (HIP events
-    recorded on the launch stream); None if nothing was recorded."""
+    """Mean per-stage GPU milliseconds over the forward calls since set_profiling(...) (HIP events
+    recorded on the launch stream; a stage that was not recorded -- level 2 records `composite` only -- reads 0); None if
+    nothing was recorded."""
     a = (ctypes.c_float * 5)()
     n = lib().gsr_last_forward_ms(a)
     if not n:

@@ -21,7 +21,7 @@ thread_local std::string g_err;
 // ---- per-stage profiling: HIP events recorded on the launch stream, resolved lazily ----
 struct ProfSet {
 	hipEvent_t ev[6];
-	int n = 0;
+	uint32_t have = 0;   // bit k: boundary k of the call was recorded (stage k lies between boundaries k and k + 1)
 };
 struct ProfLog {
 	std::vector<ProfSet*> sets;   // pool, reused across resets
@@ -34,7 +34,7 @@ struct ProfLog {
 			sets.push_back(p);
 		}
 		ProfSet* p = sets[used++];
-		p->n = 0;
+		p->have = 0;
 		return p;
 	}
 	// mean stage times over every recorded call; returns the number of calls
@@ -43,29 +43,35 @@ struct ProfLog {
 		for (int i = 0; i < k; i++) out[i] = 0.f;
 		if (used == 0) return 0;
 		int calls = 0;
+		int per_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 		for (size_t c = 0; c < used; c++) {
 			ProfSet* p = sets[c];
-			if (p->n < 2) continue;
-			if (hipEventSynchronize(p->ev[p->n - 1]) != hipSuccess) continue;
-			for (int i = 0; i < k && i + 1 < p->n; i++) {
+			if (p->have == 0) continue;
+			const int last = 31 - __builtin_clz(p->have);
+			if (hipEventSynchronize(p->ev[last]) != hipSuccess) continue;
+			for (int i = 0; i < k && i + 1 < 6; i++) {
+				if (((p->have >> i) & 3u) != 3u) continue;   // both boundaries of stage i recorded (level 2 records one stage only)
 				float ms = 0.f;
 				(void)hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
 				out[i] += ms;
+				per_stage[i]++;
 			}
 			calls++;
 		}
-		for (int i = 0; i < k && calls; i++) out[i] /= (float)calls;
+		for (int i = 0; i < k; i++) if (per_stage[i]) out[i] /= (float)per_stage[i];
 		return calls;
 	}
 };
 // process-wide (autograd runs backward on its own thread); guarded by g_prof_mu
 std::mutex g_prof_mu;
-bool g_prof = false;
+int g_prof = 0;                  // 0 off, 1 every stage boundary, 2 the two boundaries of composite_fwd only
+uint32_t g_prof_fwd_mask = 0, g_prof_bwd_mask = 0;   // boundaries recorded at the current level
 ProfLog g_fwd_log, g_bwd_log;
 ProfSet* prof_next(ProfLog& log)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
-	return g_prof ? log.next() : nullptr;
+	const uint32_t mask = &log == &g_fwd_log ? g_prof_fwd_mask : g_prof_bwd_mask;
+	return (g_prof && mask) ? log.next() : nullptr;
 }
 
 int fail(int code, const char* what, const char* file, int line, hipError_t e = hipSuccess)
@@ -328,17 +334,22 @@ struct Timer {
 	ProfSet* set;
 	hipStream_t s;
 	const char* const* names;
-	int k = 0;
+	int k = 0, ord = 0;
+	uint32_t mask = 0x3fu;
 	bool open = false, ranges;
-	Timer(ProfSet* p, hipStream_t st, const char* const* stage_names = nullptr)
-	    : set(p), s(st), names(stage_names), ranges(stage_names != nullptr && g_opt_roctx.load() != 0 && roctx().push != nullptr) {}
+	Timer(ProfSet* p, hipStream_t st, const char* const* stage_names = nullptr, uint32_t boundary_mask = 0x3fu)
+	    : set(p), s(st), names(stage_names), mask(boundary_mask), ranges(stage_names != nullptr && g_opt_roctx.load() != 0 && roctx().push != nullptr) {}
 	~Timer()
 	{
 		if (open) roctx().pop();
 	}
 	void mark()
 	{
-		if (set && set->n < 6) (void)hipEventRecord(set->ev[set->n++], s);
+		if (set && ord < 6 && ((mask >> ord) & 1u)) {
+			(void)hipEventRecord(set->ev[ord], s);
+			set->have |= 1u << ord;
+		}
+		ord++;
 		if (ranges) {
 			if (open) roctx().pop();
 			open = names[k] != nullptr;
@@ -421,7 +432,9 @@ const char* gsr_last_error(void) { return g_err.c_str(); }
 void gsr_set_profiling(int enable)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
-	g_prof = enable != 0;
+	g_prof = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
+	g_prof_fwd_mask = g_prof == 1 ? 0x3fu : (g_prof == 2 ? 0x30u : 0u);   // level 2: boundaries 4 and 5 = composite_fwd
+	g_prof_bwd_mask = g_prof == 1 ? 0x3fu : 0u;
 	g_fwd_log.used = 0;
 	g_bwd_log.used = 0;
 }
@@ -516,7 +529,7 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + il.n_contrib);
 	uint32_t* med_pos = reinterpret_cast<uint32_t*>(img + il.med_pos);
 
-	Timer tm(prof_next(g_fwd_log), s, kFwdStages);
+	Timer tm(prof_next(g_fwd_log), s, kFwdStages, g_prof_fwd_mask);
 	// control words (+ tile counters: only the atomic-counter binning path needs them cleared -- the chunked path
 	// writes every tile's count and range itself), then the camera block and the options this call runs with: one tiny
 	// launch, which also clears the 8 control words
@@ -787,7 +800,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 
 	// The background is re-staged here because the reference reads the backward's own `background`
 	// argument (backward.cu:584-587), which the forward never dereferences.
-	Timer tm(prof_next(g_bwd_log), s, kBwdStages);
+	Timer tm(prof_next(g_bwd_log), s, kBwdStages, g_prof_bwd_mask);
 	// long lists (average > GSR_FLAG_AVG entries per tile): one validity byte per instance row, set by composite_bwd for the
 	// rows it writes; short lists: no flags, composite_bwd zeroes the rows of the entries its walk does not reach
 	const bool flagged = (size_t)(R > 0 ? R : 0) > (size_t)il.T * GSR_FLAG_AVG;

@@ -414,8 +414,9 @@ int gsr_tsdf_mc_emit(const uint64_t* block_keys, uint64_t capacity, const uint64
 /* Per-stage GPU time, averaged over every gsr_forward / gsr_backward call made in this process (any thread) since
  * gsr_set_profiling(1): milliseconds for {preprocess, scan (tile histogram + scans + row offsets), scatter, sort, composite} (forward)
  * or {composite_bwd, preprocess_bwd} (backward), measured with HIP events recorded on the launch stream.
- * Recording costs one event per stage and no synchronisation; the getters synchronise on the last
- * recorded event and return the number of calls averaged (0 = nothing recorded). */
+ * Recording costs one event per stage boundary (nine per forward + backward: ~3 % of a 1-ms step) and no synchronisation; the
+ * getters synchronise on the last recorded event and return the number of calls averaged (0 = nothing recorded).
+ * gsr_set_profiling(2) records the two boundaries of composite_fwd only (the other stages then read 0); 0 switches it off. */
 void gsr_set_profiling(int enable);
 int gsr_last_forward_ms(float ms[5]);
 int gsr_last_backward_ms(float ms[2]);
