@@ -374,6 +374,24 @@ def run_extract(a, dev, scenes, _C):
     print(json.dumps(line), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-runs this command line as N ranks under torch.distributed.run
+    (one node, rendezvous on 127.0.0.1, a free port) and exits with its return code.  Under torchrun (WORLD_SIZE set)
+    bench.py never comes here."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = str(so.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -413,13 +431,18 @@ def main():
                          "committed measurement in profiles/r*_traffic.json for this workload, else null")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N` (the way the driver starts N = 1): become the launcher -- one process
+        # per GPU under torch.distributed.run on this node, the same argv; rank 0 of the children prints the JSON line
+        return self_launch(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus} "
+                         f"(or unset WORLD_SIZE: `python bench.py --gpus {a.gpus}` launches its own ranks)")
     # GSR_BENCH_BACKEND=gloo + fewer GPUs than ranks is a plumbing test of the N > 1 path on a 1-GPU box
     # (ranks share device 0, the collective goes through gloo); the measured configuration is nccl = RCCL.
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
@@ -503,6 +526,8 @@ def main():
 
     def step(timed=False, rasts=None):
         state["steps_run"] = state.get("steps_run", 0) + 1
+        mode_key = "steps_factored" if factored else "steps_dense"
+        state[mode_key] = state.get(mode_key, 0) + 1
         rasts = rasterizers if rasts is None else rasts
         if a.fwd_only:
             with torch.no_grad():
@@ -633,6 +658,52 @@ def main():
             opt_ms = None
 
     extras = {}
+    if multi and not a.fwd_only and not a.no_extras and not rotating_headline and not state.get("fallback_reason"):
+        # N > 1: the OTHER exchange beside the headline, a few steps of the same views (north_star words the exchange as "a single
+        # RCCL all-reduce": that is `dense`; the default headline is its factored form) -- both on one line.  Every rank takes
+        # the same branch: `factored` / the fallback flag were agreed above.
+        head_ev = list(comm_ev)
+        del comm_ev[:]
+        was_factored = factored
+        vsteps, vwarm = max(3, min(a.steps, 10)), 3
+        other, err = ("dense" if was_factored else "factored"), None
+        try:
+            _C.set_grad_arena([])
+            for p in params.values():
+                p.grad = None
+            if was_factored:
+                factored = False
+            else:
+                if fx is None:
+                    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact={"none": False, "union": True}.get(a.compact, a.compact))
+                    campos_all = torch.stack([c.campos for c in all_cams]).to(dev)
+                factored = True
+            with mode:
+                vdt, vf, vb = timed_run(lambda timed: step(timed), vsteps, vwarm)
+            torch.cuda.synchronize()
+            vexp = sum(e0.elapsed_time(e1) for e0, e1 in comm_ev) / max(1, len(comm_ev))
+        except Exception as e:  # noqa: BLE001  (the variant must never take the headline down with it)
+            err = f"{type(e).__name__}: {e}"[:300]
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            extras["variants"] = {other: {
+                "steps": vsteps, "warmup": vwarm, "ms_per_step": round(vdt / vsteps * 1e3, 4),
+                "value": round(world * V * H * W / (vdt / vsteps) / 1e6, 3), "unit": "Mpixels/s",
+                "comm_exposed_ms": round(vexp, 4),
+                "payload_bytes_per_rank": bucket.nbytes if other == "dense" else fx.payload()["payload_bytes_per_rank"],
+                "note": ("--exchange dense: ONE logical RCCL all-reduce of the flat 236 B/Gaussian gradient buffer (north_star's wording), "
+                         f"its SH ranges reduced from inside the backward in {a.overlap_chunks if a.overlap_chunks > 1 and V == 1 else 1} chunk(s)")
+                        if other == "dense" else
+                        "--exchange factored: all-gather of the per-view colour gradients + all-reduce of the 44 B/Gaussian geometry block"}}
+        else:
+            extras["variants"] = {other: {"error": err or "another rank failed"}}
+        _C.set_grad_arena([])
+        for p in params.values():
+            p.grad = None
+        factored = was_factored
+        del comm_ev[:]
+        comm_ev.extend(head_ev)
     if not multi and not a.no_extras and not rotating_headline and a.workload in ("C3", "C3D0"):
         # beside the static-camera headline: (1) the rotating / optimizer-contended step (same mode), (2) the OTHER compositing mode
         K = 8
@@ -739,7 +810,8 @@ def main():
             exposed = sum(e0.elapsed_time(e1) for e0, e1 in comm_ev) / len(comm_ev)
             comp_total = (sum((fwd_ms or {}).get(k, 0.0) for k in ("preprocess", "scan", "scatter", "sort", "composite")) +
                           sum((bwd_ms or {}).get(k, 0.0) for k in ("composite_bwd", "preprocess_bwd")))
-            n_it = max(1, state.get("steps_run", a.steps + a.warmup))   # every step of the process: settle, warm-up, timed, stage pass
+            # every dense step of the process (settle, warm-up, timed, stage pass; the `variants` block included when it ran dense)
+            n_it = max(1, state.get("steps_dense", a.steps + a.warmup))
             comm = {"exchange": "factored" if factored else "dense", "exchange_fallback": state.get("fallback_reason"),
                     "compute_ms": round(comp_total * V, 4), "comm_exposed_ms": round(exposed, 4),
                     "note": "compute_ms = sum of the operator's kernel stages (HIP events) x views per rank; comm_exposed_ms = time "

@@ -540,6 +540,67 @@ def test_nccl_world1_through_bench_py(tmp_path, exchange, compact):
 
 
 @pytest.mark.gpu
+def test_bench_py_gpus2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` as a PLAIN subprocess -- no torchrun, no WORLD_SIZE: bench.py re-runs itself under
+    torch.distributed.run (the driver starts N = 1 that way, and a SCALE run that did the same for N > 1 used to
+    die with a usage message).  GSR_BENCH_BACKEND=gloo: both ranks share the leased GPU (RCCL refuses two ranks on one device).
+    One JSON line: n_gpus 2, a `comm` block for the factored headline and the dense exchange beside it (`variants.dense`)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(GSR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "3", "--warmup", "1",
+                        "--settle", "0", "--no-cpu-baseline", "--no-ref-ab"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
+    assert line["config"]["views_per_step"] == 2
+    assert line["comm"]["exchange"] == "factored" and line["comm"]["exchange_fallback"] is None, line["comm"]
+    dense = line["variants"]["dense"]
+    assert "error" not in dense and dense["value"] > 0 and dense["payload_bytes_per_rank"] == 300_000 * 59 * 4, dense
+
+
+def test_bench_py_self_launch_command(monkeypatch):
+    """The launcher half of the test above without a GPU: `--gpus 4` with no WORLD_SIZE in the environment becomes
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node=4 --master-addr 127.0.0.1 --master-port <free> bench.py <same argv>`
+    and bench.py exits with the launcher's return code; under a launcher (WORLD_SIZE set) it never re-launches."""
+    import importlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    # under a launcher: no re-launch (it goes on and, on this CPU box, stops at the GPU check)
+    if not torch.cuda.is_available():
+        seen.clear()
+        monkeypatch.setenv("WORLD_SIZE", "4")
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        assert not seen and "ROCm GPU" in str(e.value.code)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("P", [1, 255, 256, 257, 5000, 100003])
 def test_packed_messages_hip_vs_torch(P):
     """The packed row messages of compact="view" (csrc/gsr_comm.hip): header (count, block bases, mask), row packing /
