@@ -622,6 +622,9 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int c
 	// twice the workgroups (512 chunks) only shortens the per-(chunk, tile) runs: measured slower (C3 0.0525 -> 0.055, C4 0.240 -> 0.253).
 	constexpr int NB = SCATTER ? GSR_BIN_BATCH : 1;
 	const int base = g * chunk;
+	// the record culled lanes read instead of their own: the chunk's first, or -- for the trailing chunks that start behind the
+	// last Gaussian (chunk is rounded up to 1024, so G * chunk can reach ~2 P) -- the last record of the buffer
+	const int spare = base < P ? base : P - 1;
 	for (int off = 0; off < chunk; off += NB * GSR_BIN_THREADS) {
 		int idxs[NB];
 		bool vis[NB];
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int c
 		uint32_t dbs[NB];
 #pragma unroll
 		for (int u = 0; u < NB; u++) {
-			const GsRec* r = recs + (vis[u] ? idxs[u] : base);
+			const GsRec* r = recs + (vis[u] ? idxs[u] : spare);
 			q3s[u] = r->q3;
 			dbs[u] = SCATTER ? (uint32_t)__float_as_int(r->q1.z) : 0u;
 		}

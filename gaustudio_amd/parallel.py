@@ -282,6 +282,9 @@ class FactoredGradExchange:
     SH gradient is rebuilt straight from the packed messages (gsr_sh_grad_from_packed: same arithmetic, same order, same
     bits).  `compact="view+geometry"` also cuts the geometry all-reduce down to the UNION of the step's views (the OR of the
     gathered masks -- every rank already holds them, no mask all-reduce; one host synchronisation for the row count).
+    Precondition of "view+geometry": geometry gradients outside the union come from the rasterizer only (they are zero there);
+    another loss term that touches culled Gaussians (a scale / opacity regulariser) is DETECTED per step and that step falls
+    back to the dense 44 B/Gaussian all-reduce (`payload()["geometry_fallbacks"]`), so the sum is always complete.
     `compact=True` (round 3; kept): exchanges only the Gaussians that are visible (radii > 0 <=> a non-zero colour OR
     geometry gradient row) in at least one view of the step: one bit-mask all-reduce, then compacted buffers (it costs a
     host synchronisation for the row count, and the mask must be agreed first: no early all-gather in this form).
@@ -372,6 +375,7 @@ class FactoredGradExchange:
                     "allgather_bytes_sent": int(crow * 12 + hdrb), "allgather_bytes_received": int((crow * 12 + hdrb) * (self.world - 1)),
                     "dense_payload_bytes_per_rank": self.P * (self.M * 3 + 11) * 4, "color_rows_per_view": crow / self.V,
                     "geometry_rows": grow, "rows_total": self.P, "compacted": "view+geometry" if self.union_geometry else "view",
+                    "geometry_fallbacks": self.stats.get("geometry_fallbacks", 0),
                     "early_allgathers_per_step": self.stats["early_allgathers"] / n}
         rows = self.stats["rows_exchanged"] / n if self.compact else self.P
         sent = rows * (44 + 12 * self.V)
@@ -584,10 +588,27 @@ def _exchange_by_view_impl(self, campos_all, D, views, multi):
     campos = campos_all.detach().to(dev, torch.float32)[self._order].contiguous()
     self._pk.sh_from_packed(self.p["means3D"].detach(), campos, msgs, offsets, D, self.sh_grad)
     if self.union_geometry:
-        # rows with a non-zero geometry gradient anywhere in the step = the OR of the gathered masks (identical on every rank)
+        # rows with a non-zero RASTERIZER geometry gradient anywhere in the step = the OR of the gathered masks (identical on
+        # every rank).  PRECONDITION of summing only those rows: no other loss term put a gradient on a row outside the union
+        # (a scale / opacity regulariser does: ADVICE r4) -- checked here: rows of this rank's geometry block that are non-zero
+        # outside the union raise a flag, the ranks agree on it (4-byte MAX all-reduce, read back together with the row count: no
+        # extra host synchronisation), and a flagged step sums the whole dense block instead (`geometry_fallbacks` in payload()).
         self._pk.union_index(P, msgs, offsets, self.hdr_union, self._scratch)
-        K = int(self.hdr_union[0].item())               # host synchronisation: the all-reduce below is sized by it
-        self.stats["geometry_rows"] += K
+        live = torch.zeros(P, dtype=torch.bool, device=dev)
+        for r in GEOMETRY_ROLES:
+            live |= (views[r].reshape(P, -1) != 0).any(dim=1)
+        kf = torch.stack([self.hdr_union[0], (live & ~_header_mask(self.hdr_union, P)).any().to(torch.int32)])
+        if multi:
+            dist.all_reduce(kf[1:2], op=dist.ReduceOp.MAX, group=self.group)
+        K, outside = (int(x) for x in kf.tolist())      # host synchronisation: the all-reduce below is sized by it
+        if outside:
+            self.stats["geometry_fallbacks"] = self.stats.get("geometry_fallbacks", 0) + 1
+            self.stats["geometry_rows"] += P
+            if multi:
+                dist.all_reduce(self.geo, op=dist.ReduceOp.SUM, group=self.group)
+            K = 0
+        else:
+            self.stats["geometry_rows"] += K
         if K > 0:
             rows = torch.empty((K, 11), dtype=torch.float32, device=dev)
             col = 0
@@ -613,6 +634,15 @@ def _exchange_by_view_impl(self, campos_all, D, views, multi):
 
 
 FactoredGradExchange._exchange_by_view = _exchange_by_view_impl
+
+
+def _header_mask(hdr: torch.Tensor, P: int):
+    """bool[P] from the bit mask of a visibility header (include/gsrast.h: 4 words, (P + 255) / 256 block bases, (P + 31) / 32
+    mask words, bit i of word w = Gaussian 32 w + i)."""
+    nb, nw = (P + 255) // 256, (P + 31) // 32
+    words = hdr[4 + nb:4 + nb + nw].to(torch.int64) & 0xFFFFFFFF
+    bits = (words[:, None] >> torch.arange(32, device=hdr.device, dtype=torch.int64)[None, :]) & 1
+    return bits.reshape(-1)[:P].bool()
 
 
 def _all_gather_in_place(buf: torch.Tensor, rank: int, V: int, group):

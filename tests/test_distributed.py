@@ -216,6 +216,15 @@ def _worker_factored(rank, world, port, out_dir, V, compact):
         dist.destroy_process_group()
 
 
+def _culled_everywhere(views):
+    seen = torch.zeros(views[0]["colors"].shape[0], dtype=torch.bool)
+    for gv in views:
+        seen |= gv["colors"].abs().amax(1) > 0
+    rows = torch.nonzero(~seen).flatten()
+    assert rows.numel() > 0
+    return int(rows[0])
+
+
 def _worker_factored_by_view(rank, world, out_dir, V, compact):
     """compact="view" / "view+geometry" on CPU tensors: the packed-message primitives come from tests/packed_ref.py (the HIP
     kernels are held against the same restatement on the GPU: test_packed_messages_hip_vs_torch)."""
@@ -224,7 +233,7 @@ def _worker_factored_by_view(rank, world, out_dir, V, compact):
     views, means, campos, (P, M) = _factored_inputs(world, V)
     shapes = dict(means3D=(P, 3), shs=(P, M, 3), opacities=(P, 1), scales=(P, 3), rotations=(P, 4))
     params = {k: (means.clone() if k == "means3D" else torch.zeros(shp)).requires_grad_(True) for k, shp in shapes.items()}
-    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact, packed=TorchPacked)
+    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact.replace("+reg", ""), packed=TorchPacked)
     assert fx.by_view and fx.colors.shape == (V, P, 3)
     with pytest.raises(RuntimeError, match="call visible"):
         fx._send_view(0)                                   # the radii of the view have not arrived
@@ -237,15 +246,22 @@ def _worker_factored_by_view(rank, world, out_dir, V, compact):
         for k in parallel.GEOMETRY_ROLES:
             params[k].grad = gv[k].clone() if params[k].grad is None else params[k].grad + gv[k]
     assert fx.stats["early_allgathers"] == V
+    regularised = compact == "view+geometry+reg"
+    if regularised and rank == 1:
+        # another loss term (a scale regulariser, say) leaves a gradient on a Gaussian NO view of the step sees -- on one rank only
+        params["scales"].grad[_culled_everywhere(views), 1] += 0.25
     fx.exchange(campos, sh_degree=3)
     pay = fx.payload()
     assert pay["color_rows_per_view"] < 0.8 * P and pay["allgather_bytes_sent"] < 12 * P * V      # a third of the rows are culled per view
-    if compact == "view+geometry":
+    if fx.union_geometry:
         assert 0 < pay["geometry_rows"] <= P
+        # detected on every rank (the flag is agreed), and that step summed the whole dense block
+        assert pay["geometry_fallbacks"] == (1 if regularised else 0) and (pay["geometry_rows"] == P) == regularised
     torch.save({k: p.grad.clone() for k, p in params.items()}, os.path.join(out_dir, f"fx_rank{rank}.pt"))
 
 
-@pytest.mark.parametrize("V,compact", [(1, False), (2, False), (1, True), (1, "view"), (2, "view"), (2, "view+geometry")])
+@pytest.mark.parametrize("V,compact", [(1, False), (2, False), (1, True), (1, "view"), (2, "view"), (2, "view+geometry"),
+                                       (1, "view+geometry+reg")])
 def test_factored_exchange_equals_dense_accumulation(tmp_path, V, compact):
     """FactoredGradExchange (all-gather of per-view colour gradients + all-reduce of the geometry block + local rebuild of the
     SH gradient) == the sum over all world * V views of the dense per-view gradients, on every rank; with and without
@@ -254,6 +270,8 @@ def test_factored_exchange_equals_dense_accumulation(tmp_path, V, compact):
     mp.spawn(_worker_factored, args=(world, _free_port(), str(tmp_path), V, compact), nprocs=world, join=True)
     views, means, campos, (P, M) = _factored_inputs(world, V)
     want = {k: sum(v[k] for v in views) for k in parallel.GEOMETRY_ROLES}
+    if compact == "view+geometry+reg":     # "+reg": rank 1 adds a regulariser gradient on a row culled in every view:
+        want["scales"][_culled_everywhere(views), 1] += 0.25   # it must arrive in the sum (the step falls back to the dense block)
     order = [r * V + v for v in range(V) for r in range(world)]          # FactoredGradExchange.view_order(): local view major, rank minor
     want["shs"] = _sh_from_colors_torch(means, campos[order], torch.stack([views[g]["colors"] for g in order]), 3, torch.zeros(P, M, 3))
     got = [torch.load(os.path.join(tmp_path, f"fx_rank{r}.pt")) for r in range(world)]

@@ -52,6 +52,21 @@ def test_scale_modifier_and_white_bg(oracle):
     assert torch.equal(a["color"], b["color"])
 
 
+def test_trailing_chunks_do_not_read_past_the_geometry_buffer(oracle):
+    """the chunked binning kernels are launched with G chunks of roundup1024(ceil(P / G)) Gaussians, so for P just
+    above G * 1024 the trailing chunks start behind the last Gaussian (base up to ~2 P); their culled lanes used to read
+    `recs[base]`, up to ~5 MB past the geometry buffer.  P in (262144, ~309 k] for any T, (524288, ~619 k] when 4 T <= 72 KiB.
+    Run under a non-caching allocator (each buffer its own hipMalloc) and checked against the oracle bit for bit."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1", GSR_FAST_EXP="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "guard_forward.py"), "262145x320x200", "300000x320x200", "524289x256x160",
+                        "262145x2048x1200"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("ok ") == 4, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_large_footprints_cooperative_binning(oracle):
     """Screen-filling Gaussians exercise the wave-cooperative tile walk (> 32 tiles per Gaussian)."""
     hs, os_ = _run(oracle, 600, 512, 384, 1, seed=11, sigma_px=60.0)
