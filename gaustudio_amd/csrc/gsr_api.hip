@@ -203,6 +203,7 @@ int recall_forward_mode(const void* img)    // -1: unknown
 // options of ONE call: the caller's gsr_options where given (>= 0), the process defaults elsewhere
 struct Resolved {
 	int tight, cull, fwd_variant, bwd_variant, speculative, band_lo, band_hi, fast_exp, forward_only;
+	bool fast_exp_explicit;   // asked for by the caller's gsr_options (not the process default)
 };
 Resolved resolve_options(const gsr_options* o)
 {
@@ -221,6 +222,7 @@ Resolved resolve_options(const gsr_options* o)
 	if (v.tile_row_lo >= 0) { r.band_lo = v.tile_row_lo; r.band_hi = v.tile_row_hi; }
 	else { r.band_lo = g_opt_band_lo.load(); r.band_hi = g_opt_band_hi.load(); }
 	r.fast_exp = v.fast_exp >= 0 ? v.fast_exp : g_opt_fast_exp.load();
+	r.fast_exp_explicit = v.fast_exp >= 0;
 	r.forward_only = v.forward_only > 0 ? 1 : 0;
 	return r;
 }
@@ -505,9 +507,15 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	if (!geometry_alloc || !binning_alloc || !image_alloc)
 		return fail(GSR_ERR_ARG, "gsr_forward: NULL allocator", __FILE__, __LINE__);
 
-	const Resolved ro = resolve_options(opt);
-	if (ro.fast_exp && ro.fwd_variant == 1)
-		return fail(GSR_ERR_ARG, "gsr_forward: fast_exp needs the per-quarter compositing kernels (fwd_variant 0)", __FILE__, __LINE__);
+	Resolved ro = resolve_options(opt);
+	if (ro.fast_exp && ro.fwd_variant == 1) {
+		// the per-wave A/B kernel has no v_exp_f32 form.  Asked for both: an error.  fast_exp merely inherited from the
+		// process default (on since round 4): the A/B switch wins and the call runs in the reproducible mode;
+		// the backward follows the forward's recorded mode the same way
+		if (ro.fast_exp_explicit)
+			return fail(GSR_ERR_ARG, "gsr_forward: fast_exp needs the per-quarter compositing kernels (fwd_variant 0)", __FILE__, __LINE__);
+		ro.fast_exp = 0;
+	}
 	const GeomLayout gl((size_t)P);
 	const ImgLayout il(width, height);
 	if (il.gx > 65535 || il.gy > 65535) return fail(GSR_ERR_ARG, "gsr_forward: image too large", __FILE__, __LINE__);
@@ -542,7 +550,7 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		const bool banded = ro.band_hi > 0 || ro.band_lo > 0;
 		const uint32_t word = (ro.fast_exp ? GSR_CTL_OPT_FAST_EXP : 0u) | (ro.tight ? GSR_CTL_OPT_TIGHT : 0u) |
 		                      (ro.cull ? GSR_CTL_OPT_CULL : 0u) | (ro.fwd_variant == 1 ? GSR_CTL_OPT_WAVE_LISTS : 0u) |
-		                      (banded ? GSR_CTL_OPT_BAND : 0u);
+		                      (banded ? GSR_CTL_OPT_BAND : 0u) | (ro.forward_only ? GSR_CTL_OPT_FORWARD_ONLY : 0u);
 		HIP_TRY(stage_small(src, dst, n, s, &ctl->opts, word, reinterpret_cast<uint32_t*>(ctl), 8));
 	}
 
@@ -665,6 +673,14 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		if (next == cur || ds.cap.compare_exchange_weak(cur, next)) break;
 	}
 	ds.long_lists.store(need_long);
+	if (debug) {
+		// every stage above was synchronised (STAGE_CHECK): the long-list sort's queue-overflow flag is final
+		GsCtl c;
+		HIP_TRY(hipMemcpyAsync(&c, img + il.ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (c.err_overflow & 2u)
+			return fail(GSR_ERR_HIP, "gsr_forward: the long-list sort overflowed a work queue (SortQueueLayout bound violated)", __FILE__, __LINE__);
+	}
 	// a skewed frame (longest list > 1024 keys and > 4x the mean): its backward runs the tiles longest walk first
 	const int skew = (g_opt_tile_order.load() != 0 && max_tile > GSR_SORT_LDS_MAX && (uint64_t)max_tile * (uint64_t)il.T > 4ull * Rb) ? 1 : 0;
 	remember_forward_skew(img, skew);
@@ -790,6 +806,20 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.radii = radii;
 	a.shs_rest = shs_rest; a.act = activation_flags;
 
+	// a forward_only forward kept nothing for a backward (no shjac, no per-pixel state): refused whichever stages are asked for --
+	// the SH stage alone reads shjac too.  Host-side memory of the recent forwards; debug mode reads the
+	// forward's own record in the image buffer as well (an entry evicted from the host table is otherwise unchecked).
+	if (recall_forward_only(image_buffer))
+		return fail(GSR_ERR_ARG, "gsr_backward: these buffers come from a forward_only forward (gsr_options.forward_only): it kept nothing for a backward", __FILE__, __LINE__);
+	if (debug) {
+		GsCtl c;
+		HIP_TRY(hipMemcpyAsync(&c, image_buffer + il.ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (c.opts & GSR_CTL_OPT_FORWARD_ONLY)
+			return fail(GSR_ERR_ARG, "gsr_backward: these buffers come from a forward_only forward (gsr_options.forward_only): it kept nothing for a backward", __FILE__, __LINE__);
+		if (c.err_overflow & 2u)
+			return fail(GSR_ERR_HIP, "gsr_backward: the forward's long-list sort overflowed a work queue (point_list is not sorted)", __FILE__, __LINE__);
+	}
 	if (!(parts & GSR_BWD_PART_MAIN)) {
 		// SH stage alone over a Gaussian range (the caller interleaves a collective per chunk, gaustudio_amd/parallel.py)
 		launch_preprocess_bwd(a, cam, recs, reinterpret_cast<const float*>(geom_buffer + gl.shjac), goff, rows, nullptr, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
@@ -827,13 +857,14 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 
 	tm.mark();
 	if (R > 0) {
-		const Resolved ro = resolve_options(opt);
+		Resolved ro = resolve_options(opt);
 		{
 			const int fwd_mode = recall_forward_mode(image_buffer);
+			// fast_exp not named by the caller: the mode the forward of these buffers ran in (which may itself have left the
+			// process default for an A/B variant without a v_exp_f32 kernel, see forward_impl)
+			if (!ro.fast_exp_explicit && fwd_mode >= 0) ro.fast_exp = fwd_mode;
 			if (fwd_mode >= 0 && fwd_mode != (ro.fast_exp != 0))
 				return fail(GSR_ERR_ARG, "gsr_backward: fast_exp differs from the forward that produced these buffers", __FILE__, __LINE__);
-			if (recall_forward_only(image_buffer))
-				return fail(GSR_ERR_ARG, "gsr_backward: these buffers come from a forward_only forward (gsr_options.forward_only): it kept nothing for a backward", __FILE__, __LINE__);
 		}
 		if (debug) {
 			// the forward recorded what it ran with: a backward in another exp mode would take other alpha >= 1/255 decisions

@@ -45,7 +45,7 @@ struct GsCtl {
 	uint32_t num_binned;     // instances actually binned (tight rects): sizes every per-instance buffer
 	uint32_t max_tile_count; // longest per-tile list
 	uint32_t err_prefiltered;
-	uint32_t err_overflow;   // the reference-defined count does not fit the reference's int num_rendered
+	uint32_t err_overflow;   // bit 0: the reference-defined count does not fit the reference's int num_rendered; bit 1: the long-list sort overflowed a work queue
 	uint32_t ref_rendered;   // the reference's num_rendered: sum of getRect areas (rasterizer_impl.cu:280-284)
 	uint32_t has_qmask;      // composite_fwd left one 16-bit block mask per list entry behind the list (see gs_qmask_ptr)
 	uint32_t opts;           // options the forward ran with (GSR_CTL_OPT_*): the backward of this image buffer must agree
@@ -57,6 +57,7 @@ struct GsCtl {
 #define GSR_CTL_OPT_CULL 4u
 #define GSR_CTL_OPT_WAVE_LISTS 8u
 #define GSR_CTL_OPT_BAND 16u
+#define GSR_CTL_OPT_FORWARD_ONLY 32u   // the forward kept nothing for a backward (gsr_options.forward_only)
 
 // Per-instance block masks of the forward (bit 4*row + col: which 4x4 pixel blocks of the tile the instance can touch,
 // gs_quarter_mask<4>), kept for the backward: u16 per list entry, in the binning buffer right behind the list's

@@ -1585,13 +1585,17 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(uint64_t* __restrict__
                                                           uint32_t* __restrict__ point_list, const GsSortQ* __restrict__ q,
                                                           const uint2* __restrict__ sort_items, uint32_t sort_cap,
                                                           const uint2* __restrict__ fall_items, uint32_t fall_cap,
-                                                          const GsCtl* __restrict__ ctl, uint32_t cap)
+                                                          const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t* __restrict__ err_dst)
 {
 	__shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave running offsets
 	__shared__ uint32_t s_tot[4];
 	__shared__ uint32_t s_maxrun;
 	const uint32_t nb_ = ctl->num_binned, mt_ = ctl->max_tile_count, nfq_ = q->n_fall, nsq_ = q->n_sort;   // one round trip
 	if (nb_ > cap || mt_ <= GSR_SORT_LDS_MAX) return;
+	// the pipeline's overflow flag (a SortQueueLayout bound violated: items were dropped, point_list is not sorted) is final
+	// here -- every kernel that can raise it ran before this one: mirrored into the frame's control words (bit 1 of
+	// err_overflow), where debug-mode calls and gsr_inspect_counts see it
+	if (blockIdx.x == 0 && threadIdx.x == 0 && q->err != 0u) atomicOr(err_dst, 2u);
 	const uint32_t nf = min(nfq_, fall_cap);
 	for (uint32_t it = blockIdx.x; it < nf; it += gridDim.x) {
 		const uint2 sg = fall_items[it];
@@ -1674,7 +1678,8 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 	// oversized buckets (lists beyond 64 k keys; sampling noise) cut once more, what is STILL oversized: counting sort
 	hipLaunchKernelGGL(segment_partition_kernel, dim3(128), dim3(GSR_PART_THREADS), 0, s, keys, keys2, q, sort_items, sort_cap,
 	                   seg_items, &q->n_seg, seg_cap, fall_items, &q->n_fall, ctl, cap);
-	hipLaunchKernelGGL(bucket_sort_kernel, dim3(2048), dim3(256), 0, s, keys, keys2, point_list, q, sort_items, sort_cap, fall_items, seg_cap, ctl, cap);
+	hipLaunchKernelGGL(bucket_sort_kernel, dim3(2048), dim3(256), 0, s, keys, keys2, point_list, q, sort_items, sort_cap, fall_items, seg_cap, ctl, cap,
+	                   const_cast<uint32_t*>(&ctl->err_overflow));
 }
 
 

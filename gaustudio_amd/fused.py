@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .options import for_forward as _options_for_forward
+from .options import for_forward as _options_for_forward, note_grad_mode as _note_grad_mode
 from .rasterizer import _dense_image_grads, _run_guarded
 
 ACT_OPACITY_SIGMOID = 1
@@ -71,5 +71,6 @@ class FusedGaussianRasterizer(nn.Module):
         P = means3D.shape[0]
         f_dc = f_dc.reshape(P, 1, 3)
         f_rest = f_rest.reshape(P, -1, 3)
+        _note_grad_mode(torch.is_grad_enabled())
         return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, raw_opacities.reshape(P, 1), raw_scales,
                                             raw_rotations, self.raster_settings, self.activations)

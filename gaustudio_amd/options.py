@@ -66,12 +66,35 @@ def resolved():
     if cur[i] < 0:
         from . import _C
         cur[i] = int(_C.get_option("fast_exp"))
+        # fast_exp merely inherited from the process default (on since round 4), together with an A/B kernel variant that has
+        # no v_exp_f32 form (per-wave lists: fwd_variant 1, bwd_variant bit 1): the variant wins, the call runs in the
+        # reproducible mode -- asking for BOTH explicitly stays an error of the library
+        if cur[i]:
+            fv, bv = cur[FIELDS.index("fwd_variant")], cur[FIELDS.index("bwd_variant")]
+            fv = int(_C.get_option("fwd_variant")) if fv < 0 else fv
+            bv = int(_C.get_option("bwd_variant")) if bv < 0 else bv
+            if fv == 1 or (bv >= 0 and (bv & 2)):
+                cur[i] = 0
     return tuple(cur)
+
+
+def note_grad_mode(enabled: bool):
+    """Called by the module wrappers right before Function.apply: inside Function.forward grad mode is always off and
+    ctx.needs_input_grad ignores torch.no_grad(), so the caller's grad mode has to be captured outside."""
+    _tls.grad_enabled = bool(enabled)
+
+
+def take_grad_mode():
+    """The grad mode noted for THIS call (True when the Function was applied directly, without the wrapper)."""
+    g = getattr(_tls, "grad_enabled", None)
+    _tls.grad_enabled = None
+    return True if g is None else g
 
 
 def for_forward(needs_backward: bool):
     """resolved(), plus `forward_only` = 1 when nothing of this call can be differentiated (torch.no_grad(), or no input requires
     grad): the forward then skips what only a backward would read."""
+    needs_backward = bool(needs_backward) and take_grad_mode()
     cur = list(resolved())
     cur[FIELDS.index("forward_only")] = 0 if needs_backward else 1
     return tuple(cur)

@@ -251,7 +251,10 @@ typedef struct gsr_options {
 	int32_t fast_exp;
 	int32_t forward_only;   /* 0|1  (default 0) this forward will have no backward: skip what only a backward reads (the 36 B per Gaussian
 	                         * of d(rgb)/d(view direction) that preprocess_fwd leaves for the SH backward).  gsr_backward on the buffers of
-	                         * such a forward is refused.  The Python adapters set it for forwards under torch.no_grad(). */
+	                         * such a forward (any `parts`) is refused: from a host-side memory of the last 64 forwards, and -- debug = 1 --
+	                         * from the forward's own record in the image buffer.  The Python adapters set it for calls under
+	                         * torch.no_grad() (the grad mode is captured by the module wrapper: ctx.needs_input_grad ignores it) and for
+	                         * calls none of whose inputs requires a gradient. */
 } gsr_options;
 void gsr_options_init(gsr_options* opt);   /* struct_bytes = sizeof, every field -1 */
 
@@ -322,7 +325,9 @@ int gsr_inspect_backward_sums(const char* geom_buffer, const char* scratch, int 
                                float* sums, void* stream);
 
 /* out = { instances binned (tight rects; the length of point_list), longest tile list, the reference-defined
- * num_rendered (what gsr_forward returned), overflow flag }.  `out` is HOST memory; synchronises the stream. */
+ * num_rendered (what gsr_forward returned), error flags: bit 0 = the reference-defined count overflowed 2^31 - 1, bit 1 = the
+ * long-list sort overflowed one of its work queues (a capacity bound violated: point_list is not completely sorted; debug-mode
+ * gsr_forward / gsr_backward calls fail on it) }.  `out` is HOST memory; synchronises the stream. */
 int gsr_inspect_counts(const char* image_buffer, int width, int height, uint32_t out[4], void* stream);
 
 /* point_list[R] (Gaussian ids, tile-major, depth-sorted; R = instances binned, see gsr_inspect_counts),

@@ -101,6 +101,49 @@ def test_backward_must_run_in_the_mode_of_its_forward():
             hip_forward(sc, cam, 3, kw)
 
 
+def test_ab_variants_without_a_fast_exp_kernel_run_under_the_default_mode():
+    """the library's process default is fast_exp = 1; the per-wave A/B kernels (fwd_variant 1, bwd_variant bit 1) have
+    no v_exp_f32 form.  Asking for both explicitly is an error (test above); fast_exp merely inherited from the default gives
+    way to the variant: the call runs in the reproducible mode, bit-identical to the per-quarter kernels in that mode, and its
+    backward follows the forward's recorded mode."""
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam = scenes.make_camera(160, 96)
+    sc = scenes.make_scene(3000, cam, seed=2)
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam)
+    exact = hip_forward(sc, cam, 3, kw)                                     # suite default: GSR_FAST_EXP=0
+    gexact = hip_backward_raw(exact, sc, cam, 3, kw, grads)
+    _C.set_option("fast_exp", 1)                                            # the shipped process default
+    try:
+        with gaustudio_amd.options(fwd_variant=1):                          # Python route: options.resolved() decides
+            wave = hip_forward(sc, cam, 3, kw)
+        for k in ("color", "depth", "median", "opacity"):
+            assert torch.equal(wave[k], exact[k]), k
+        # C ABI route: gsr_forward_ex with fast_exp = -1 (default) and fwd_variant = 1, then a backward with bwd_variant bit 1
+        dev = "cuda"
+        e = torch.Tensor([])
+        out = _C.rasterize_gaussians(torch.zeros(3), sc.means3D.to(dev), e, sc.opacities.to(dev), sc.scales.to(dev), sc.rotations.to(dev), 1.0, e,
+                                     cam.viewmatrix.to(dev), cam.projmatrix.to(dev), cam.tanfovx, cam.tanfovy, cam.height, cam.width,
+                                     sc.shs.to(dev), 3, cam.campos.to(dev), False, False, options=(-1, -1, 1, -1, -1, -1, -1, -1, 0))
+        assert torch.equal(out[1], exact["color"])
+        st = dict(exact, geom=out[6], binning=out[7], img=out[8], num_rendered=out[0])
+        g = hip_backward_raw(st, sc, cam, 3, kw, grads, options=dict(bwd_variant=2))      # fast_exp not named: the forward's mode
+        for k in GRAD_KEYS:
+            assert torch.equal(g[k], gexact[k]) or k == "dL_dcov3D", k
+        # autograd: forward + backward under the default with the per-wave backward variant
+        rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                           cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+        Pm = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        with gaustudio_amd.options(bwd_variant=2):
+            o = GaussianRasterizer(rs)(means3D=Pm["means3D"], means2D=torch.zeros_like(Pm["means3D"]), opacities=Pm["opacities"],
+                                       shs=Pm["shs"], scales=Pm["scales"], rotations=Pm["rotations"])
+            assert torch.equal(o[0], exact["color"])
+        torch.autograd.backward([o[0], o[2], o[3], o[4]], [t.to(dev) for t in grads])
+        assert torch.equal(Pm["means3D"].grad, gexact["dL_dmeans3D"])
+    finally:
+        _C.set_option("fast_exp", 0)
+
+
 def test_c_abi_options_struct_and_roctx_switch():
     """gsr_options through the C ABI itself (ctypes): gsr_options_init, a per-call fast_exp on gsr_backward_ex, a SHORTER
     struct from an older caller (fields beyond struct_bytes count as -1), NULL-equivalent defaults == gsr_backward; and the

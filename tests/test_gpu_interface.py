@@ -296,6 +296,15 @@ def test_forward_only_skips_what_only_a_backward_reads_and_refuses_one():
     fo = dict(normal, geom=out[6], binning=out[7], img=out[8], num_rendered=out[0])
     with pytest.raises(RuntimeError, match="forward_only"):
         hip_backward_raw(fo, sc, cam, 3, kw, scenes.make_output_grads(cam))
+    # the refusal also covers the SH stage alone (parts without MAIN reads the jacobians the forward did not keep) ...
+    with pytest.raises(RuntimeError, match="forward_only"):
+        hip_backward_raw(fo, sc, cam, 3, kw, scenes.make_output_grads(cam), options={}, parts=2)
+    # ... and does not depend on the host-side memory of recent forwards (64 entries, keyed by the image buffer): after 70 other
+    # forwards the entry is gone; a debug backward reads the forward's own record in the image buffer
+    keep = [hip_forward(scenes.make_scene(64, cam, seed=s), cam, 0, scene_kwargs(scenes.make_scene(64, cam, seed=s), True, False))["img"] for s in range(70)]
+    with pytest.raises(RuntimeError, match="forward_only"):
+        hip_backward_raw(fo, sc, cam, 3, kw, scenes.make_output_grads(cam), debug=True)
+    del keep
     # through autograd: a no_grad render followed by a differentiable one of the same rasterizer object
     rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
                                        cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)

@@ -124,7 +124,7 @@ def make_options(L, struct_bytes=None, **fields):
     return o
 
 
-def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False, options=None, no_dcov=False):
+def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False, options=None, no_dcov=False, parts=3):
     """gsr_backward (or, with `options` = a GsrOptions / None-able dict, gsr_backward_ex) called straight through ctypes
     with a test-owned scratch buffer, so that the composite-stage accumulator rows (scratch[P,12]) can be inspected next
     to the 8 outputs."""
@@ -152,7 +152,7 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
     p = _C._ptr
     if options is not None:
         opt = options if isinstance(options, GsrOptions) else make_options(L, **options)
-        rc = L.gsr_backward_ex(ctypes.byref(opt), ctypes.c_int(3), ctypes.c_int(0), ctypes.c_int(P), ctypes.c_int(P), ctypes.c_int(D),
+        rc = L.gsr_backward_ex(ctypes.byref(opt), ctypes.c_int(parts), ctypes.c_int(0), ctypes.c_int(P), ctypes.c_int(P), ctypes.c_int(D),
                                ctypes.c_int(M), ctypes.c_int(hs["num_rendered"]), p(bg), ctypes.c_int(cam.width), ctypes.c_int(cam.height),
                                p(means), p(shs), p(None), p(col), p(scl), ctypes.c_float(scale_modifier), p(rot), p(cov), ctypes.c_int(0),
                                ctypes.c_float(cam.tanfovx), ctypes.c_float(cam.tanfovy), p(hs["radii"]), p(hs["geom"]), p(hs["binning"]),
