@@ -425,6 +425,11 @@ def main():
     ap.add_argument("--fast-exp", action="store_true", help="run the whole benchmark in the fast_exp mode (the library default since round 4; explicit here)")
     ap.add_argument("--exact", action="store_true", help="run the whole benchmark in the bit-exact mode (reproducible polynomial exp: the CPU oracle's bits; "
                                                          "the test suite's mode) instead of the library default")
+    ap.add_argument("--loss", default="all", choices=["all", "color"],
+                    help="all (the headline, BASELINE's C3: colour + depth + median + opacity gradients consumed) or color: a loss on the "
+                         "colour image alone, the usual 3DGS training call -- the three unused outputs' gradients are ABSENT (NULL through "
+                         "the C ABI: no zero planes, no loads, the colour-only compositing backward); reported beside the headline as "
+                         "`variants.loss_color`")
     ap.add_argument("--no-extras", action="store_true", help="skip the rotating-camera and fast_exp blocks of the default line")
     ap.add_argument("--traffic", type=float, default=None,
                     help="measured HBM bytes per composite_fwd launch from a rocprofv3 --pmc pass; default: the "
@@ -547,7 +552,10 @@ def main():
             color, radii, depth, median, opac = render(v, r)
             if factored:
                 fx.visible(v, radii)                        # --compact view: header + count gather right after the forward (no-op otherwise)
-            torch.autograd.backward([color, depth, median, opac], grads)
+            if state.get("loss", a.loss) == "color":
+                torch.autograd.backward([color], grads[:1])    # the other three outputs unused: their gradients ABSENT (NULL), not zeros
+            else:
+                torch.autograd.backward([color, depth, median, opac], grads)
             if last:
                 state["out"] = (color, radii, depth, median, opac)
         if multi and timed:
@@ -732,6 +740,19 @@ def main():
                                       "note": ("gaustudio_amd.options(fast_exp=False) / GSR_FAST_EXP=0: the reproducible 9-instruction exp, every output "
                                                "bit-identical to the CPU oracle (the test suite's mode)") if fast_mode else
                                               ("gaustudio_amd.options(fast_exp=True): v_exp_f32 in both compositing kernels (the library default)")}}
+        if not a.fwd_only and a.loss == "all":
+            for p in params.values():
+                p.grad = None
+            state["loss"] = "color"
+            with mode:
+                cdt, cf, cb = timed_run(lambda timed: step(timed), 24, 8)
+            state.pop("loss")
+            extras["variants"]["loss_color"] = {
+                "steps": 24, "ms_per_step": round(cdt / 24 * 1e3, 4), "value": round(V * H * W / (cdt / 24) / 1e6, 3), "unit": "Mpixels/s",
+                "stage_ms": {"forward": cf, "backward": cb},
+                "note": "the same step with a loss on the colour image alone (--loss color): the gradients of depth / median / opacity are "
+                        "absent -- NULL through the C ABI, no zero planes materialised (the reference reads all four, backward.cu:476-483, "
+                        "and its autograd fills 41 MB of zeros per 1080p step), nothing loaded for them, composite_bwd's colour-only instantiation"}
 
     # instance counts of this rank's view (they drive every composite-stage byte count): the reference-defined
     # num_rendered and the instances actually binned; per-tile list lengths
@@ -791,6 +812,7 @@ def main():
             "config": {"workload": desc, "gaussians": P, "visible": vis, "width": W, "height": H, "sh_degree": D,
                        "num_rendered": R_ref, "instances_binned": R, "tiles": T, "tile_list_length": lists,
                        "views_per_step": world * V, "views_per_rank": V,
+                       "loss": "colour + depth + median + opacity gradients consumed" if a.loss == "all" else "colour gradient only (--loss color)",
                        "camera": (f"ring of {a.rotate_cameras}, a different one every step, Adam update between the steps "
                                   f"({round(opt_ms, 4)} ms, excluded)") if rotating_headline else "static (the same view every step)",
                        "mode": ("fast_exp (library default: v_exp_f32 in the compositing kernels; pinned to the reference's kernels and to the "

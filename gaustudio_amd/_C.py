@@ -102,14 +102,21 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_median_depth, dL_dout_final_opacity, sh, degree, campos, geomBuffer, R,
-                                 binningBuffer, imageBuffer, debug, options=None):
-    """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:123-210 -> torch_binding.cpp RasterizeGaussiansBackward."""
+                                 binningBuffer, imageBuffer, debug, options=None, image_height=-1, image_width=-1):
+    """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:123-210 -> torch_binding.cpp RasterizeGaussiansBackward.
+    An upstream gradient may be ABSENT (None, or the reference's empty tensor): the loss does not use that output, its
+    gradient is zero and nothing is read for it (include/gsrast.h gsr_backward); `image_height` / `image_width` are only
+    needed when all four are absent (the size is otherwise taken from one that is present)."""
+    import torch
+    e = lambda t: torch.Tensor([]) if t is None else t
+    dL_dout_color, dL_dout_depth, dL_dout_median_depth, dL_dout_final_opacity = (
+        e(dL_dout_color), e(dL_dout_depth), e(dL_dout_median_depth), e(dL_dout_final_opacity))
     return native().rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations,
                                                  float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix,
                                                  float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth,
                                                  dL_dout_median_depth, dL_dout_final_opacity, sh, int(degree), campos,
                                                  geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug),
-                                                 _opts(options))
+                                                 _opts(options), int(image_height), int(image_width))
 
 
 def sh_grad_from_colors(means3D, campos, colors, degree, out):

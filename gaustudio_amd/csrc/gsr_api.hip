@@ -771,8 +771,8 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	if (P <= 0) return GSR_OK;   // rasterize_points.cu:171
 	if (!geom_buffer || !image_buffer || !binning_buffer || !scratch || !radii || !means3D)
 		return fail(GSR_ERR_ARG, "gsr_backward: NULL buffer", __FILE__, __LINE__);
-	if (!dL_dpix || !dL_dpix_depth || !dL_dpix_median_depth || !dL_dpix_final_opacity)
-		return fail(GSR_ERR_ARG, "gsr_backward: NULL upstream gradient", __FILE__, __LINE__);
+	// any of the four upstream image gradients may be NULL = "the loss does not use that output" = zero: nothing is loaded for
+	// it (and the caller materialises no zero plane); colour alone takes a compositing kernel specialised on it
 	const bool sh_colors = (parts & GSR_BWD_PART_SH_COLORS) != 0;
 	const int colors_early = ((parts & GSR_BWD_PART_COLORS_EARLY) && sh_colors) ? GSR_PART_COLORS_EARLY : 0;
 	if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || (!dL_dcov3D && cov3D_precomp) || !dL_dscale || !dL_drot ||
@@ -871,6 +871,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 			GsCtl c;
 			HIP_TRY(hipMemcpyAsync(&c, image_buffer + il.ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
 			HIP_TRY(hipStreamSynchronize(s));
+			if (!ro.fast_exp_explicit) ro.fast_exp = (c.opts & GSR_CTL_OPT_FAST_EXP) ? 1 : 0;   // (the host-side memory may have forgotten this forward)
 			if (((c.opts & GSR_CTL_OPT_FAST_EXP) != 0u) != (ro.fast_exp != 0))
 				return fail(GSR_ERR_ARG, "gsr_backward: fast_exp differs from the forward that produced these buffers", __FILE__, __LINE__);
 		}

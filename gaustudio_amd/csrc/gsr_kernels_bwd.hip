@@ -272,12 +272,15 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		if (inside) {
 			const size_t HW = (size_t)H * W;
 			const size_t pix_id = (size_t)W * py + px;
-			dLp0 = dL_dpix[pix_id];
-			dLp1 = dL_dpix[HW + pix_id];
-			dLp2 = dL_dpix[2 * HW + pix_id];
-			dLd = dL_dpix_depth[pix_id];
-			dLm = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
-			dLo = dL_dpix_opacity[pix_id];
+			// an upstream gradient the caller did not supply (NULL: an output the loss does not use) is zero: not loaded
+			if (dL_dpix) {
+				dLp0 = dL_dpix[pix_id];
+				dLp1 = dL_dpix[HW + pix_id];
+				dLp2 = dL_dpix[2 * HW + pix_id];
+			}
+			if (dL_dpix_depth) dLd = dL_dpix_depth[pix_id];
+			if (dL_dpix_median) dLm = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
+			if (dL_dpix_opacity) dLo = dL_dpix_opacity[pix_id];
 			mpos = med_pos[sidx];
 		}
 		// lane = pixel (lx & 7, ly & 7) of the wave's block
@@ -526,7 +529,10 @@ __device__ unsigned long long g_bwd_phase_ticks[GSR_TM_SLOTS * 12];
 #ifndef GSR_BWQ_WAVES
 #define GSR_BWQ_WAVES 4      // waves per SIMD the register allocation is held to (experiment: 5 with GSR_BWQ_BATCH=96)
 #endif
-template <bool FLAGS, bool TSEL, bool FX>
+// CONLY: only the colour gradient is supplied (dL_dpix_depth / _median / _opacity NULL = zero: a colour-only loss, the usual
+// 3DGS training call): their loads, their two FMAs of the step and the four of phase 2 are left out.  The remaining
+// operations are the general kernel's with literal zeros, so the rows are bit-equal to a call with explicit zero planes.
+template <bool FLAGS, bool TSEL, bool FX, bool CONLY>
 __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_BWQ_WAVES, GSR_BWQ_WAVES))) void composite_bwd_quarter_kernel(
     int T, int chunk, int gx, int W, int H, const GsBg bgv, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, const uint32_t* __restrict__ goff,
@@ -572,13 +578,18 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	if (inside) {
 		const size_t HW = (size_t)H * W;
 		const size_t pix_id = (size_t)W * py + px;
-		dLp0 = dL_dpix[pix_id];
-		dLp1 = dL_dpix[HW + pix_id];
-		dLp2 = dL_dpix[2 * HW + pix_id];
-		dLd = dL_dpix_depth[pix_id];
-		dLm = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
-		dLo = dL_dpix_opacity[pix_id];
-		mpos = med_pos[sidx];
+		// an upstream gradient the caller did not supply (NULL: an output the loss does not use) is zero: not loaded
+		if (dL_dpix) {
+			dLp0 = dL_dpix[pix_id];
+			dLp1 = dL_dpix[HW + pix_id];
+			dLp2 = dL_dpix[2 * HW + pix_id];
+		}
+		if (!CONLY) {
+			if (dL_dpix_depth) dLd = dL_dpix_depth[pix_id];
+			if (dL_dpix_median) dLm = dL_dpix_median[pix_id];   // channel 0 only (backward.cu:481-482)
+			if (dL_dpix_opacity) dLo = dL_dpix_opacity[pix_id];
+			mpos = med_pos[sidx];
+		}
 	}
 	float2* slab = s_slab[wv];
 	float* plane = s_plane[wv];
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	{
 		float4* tmp = reinterpret_cast<float4*>(slab);   // 64 pixels x 2 float4 = 2 KiB <= the wave's slab
 		tmp[2 * lane] = make_float4(dLp0, dLp1, dLp2, dLd);
-		tmp[2 * lane + 1] = make_float4(dLo, 0.f, 0.f, 0.f);
+		if (!CONLY) tmp[2 * lane + 1] = make_float4(dLo, 0.f, 0.f, 0.f);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -601,7 +612,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			const float c0 = gp.x, c1 = gp.y, c2 = gp.z, c3 = gp.w;
 			g_pix[sx] = make_float4(r2 == 0 ? c0 : r2 == 1 ? c1 : r2 == 2 ? c2 : c3, r2 == 0 ? c1 : r2 == 1 ? c0 : r2 == 2 ? c3 : c2,
 			                        r2 == 0 ? c2 : r2 == 1 ? c3 : r2 == 2 ? c0 : c1, r2 == 0 ? c3 : r2 == 1 ? c2 : r2 == 2 ? c1 : c0);
-			g_op[sx] = tmp[2 * pl + 1].x;
+			g_op[sx] = CONLY ? 0.f : tmp[2 * pl + 1].x;
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
@@ -744,31 +755,6 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			GSR_APPEND(2, c2)
 			GSR_APPEND(3, c3)
 		}
-#ifdef GSR_BWQ_LIST_TWICE   // sensitivity experiment: the list building once more (same lists again) = its cost in situ
-		c0 = c1 = c2 = c3 = 0;
-		__builtin_amdgcn_wave_barrier();
-#pragma unroll
-		for (int h = 0; h < GSR_BWQ_HALVES; h++) {
-			const int jl = lane + 64 * h;
-			if (64 * h >= cnt) break;
-			uint32_t mk = 0;
-			if (jl < cnt) {
-				if (have_qmask) {
-					const uint32_t m16 = (uint32_t)__builtin_nontemporal_load(&s_qmask[jl]) >> (8 * (wv >> 1) + 2 * (wv & 1));
-					mk = (m16 & 3u) | ((m16 >> 2) & 12u);
-				} else {
-					mk = gs_quarter_mask<2>(sA[jl], sB[jl], fbx, fby, 0xfu);
-				}
-				const int pos = top - 1 - jl;
-				mk &= (pos < qm0 ? 1u : 0u) | (pos < qm1 ? 2u : 0u) | (pos < qm2 ? 4u : 0u) | (pos < qm3 ? 8u : 0u);
-			}
-			asm volatile("" : "+v"(mk));
-			GSR_APPEND(0, c0)
-			GSR_APPEND(1, c1)
-			GSR_APPEND(2, c2)
-			GSR_APPEND(3, c3)
-		}
-#endif
 #undef GSR_APPEND
 		__builtin_amdgcn_wave_barrier();
 		TM(8)
@@ -809,7 +795,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 			const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
 			const float test_T = T_ * rinv;
 			const float w = alpha * test_T;
-			const float cd = FMA(Cc.x, dLp0, FMA(Cc.y, dLp1, FMA(Cc.z, dLp2, FMA(B.z, dLd, dLo))));
+			const float cd = FMA(Cc.x, dLp0, FMA(Cc.y, dLp1, FMA(Cc.z, dLp2, CONLY ? 0.f : FMA(B.z, dLd, dLo))));   // CONLY: dLd = dLo = 0, depth >= 0: that FMA is +0
 			const float diff = cd - S;
 			float dL_dalpha = diff * test_T;
 			if (any_bg) {                                                         // backward.cu:584-587
@@ -874,7 +860,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 					S0 += qv[sx];
 					a0 += t;
 					a2 = FMA(t, dx, a2);
-					a5 = FMA(wv_[sx], g_op[sx], a5);                  // backward.cu:575 (+ :607 below: + sum q)
+					if (!CONLY) a5 = FMA(wv_[sx], g_op[sx], a5);      // backward.cu:575 (+ :607 below: + sum q); CONLY: w * 0 added to +0 stays +0
 					a6 = FMA(wv_[sx], g_pix[sx].x, a6);
 					a7 = FMA(wv_[sx], g_pix[sx].y, a7);
 					a8 = FMA(wv_[sx], g_pix[sx].z, a8);
@@ -1022,12 +1008,16 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, con
 	if (wave_lists) {
 		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_kernel<true, true>); else GSR_LAUNCH_CB(composite_bwd_kernel<true, false>); }
 		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_kernel<false, true>); else GSR_LAUNCH_CB(composite_bwd_kernel<false, false>); }
+	} else if (dL_dpix_depth == nullptr && dL_dpix_median == nullptr && dL_dpix_opacity == nullptr && !tsel) {
+		// colour-only loss: the specialised instantiation (a device that needs TSEL takes the general kernel, which treats NULL as zero)
+		if (fx) { if (flags) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, true, true>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, true, true>); }
+		else { if (flags) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, false, true>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, false, true>); }
 	} else if (fx) {
-		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, true, true>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, true>); }
-		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, true, true>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, true>); }
+		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, true, true, false>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, true, false>); }
+		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, true, true, false>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, true, false>); }
 	} else {
-		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, true, false>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, false>); }
-		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, true, false>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, false>); }
+		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, true, false, false>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, false, false>); }
+		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, true, false, false>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, false, false>); }
 	}
 #undef GSR_LAUNCH_CB
 }

@@ -67,6 +67,20 @@ gsr_options make_options(const std::vector<int>& v)
 	return o;
 }
 
+// The image size of a backward: from whichever upstream gradient is present ([C,H,W]); an ABSENT one (empty tensor: the loss
+// does not use that output -- its gradient is zero, nothing is read for it) carries none, so the adapters may also pass the
+// size explicitly (image_height / image_width, > 0).
+void backward_image_size(const torch::Tensor* const g[4], int image_height, int image_width, int& H, int& W)
+{
+	H = image_height; W = image_width;
+	for (int i = 0; i < 4 && (H <= 0 || W <= 0); i++)
+		if (g[i]->numel() != 0) {
+			TORCH_CHECK(g[i]->ndimension() == 3, "upstream gradients must have dimensions (channels, height, width)");
+			H = (int)g[i]->size(1); W = (int)g[i]->size(2);
+		}
+	TORCH_CHECK(H > 0 && W > 0, "rasterize_gaussians_backward: every upstream gradient is absent and no image_height / image_width was given");
+}
+
 void* current_stream(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 // One-shot output arena for the NEXT backward of ONE specific graph (gaustudio_amd/parallel.py): five caller-owned
@@ -247,13 +261,18 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
                            const torch::Tensor& dL_dout_median_depth, const torch::Tensor& dL_dout_final_opacity,
                            const torch::Tensor& sh_, const int degree, const torch::Tensor& campos_,
                            const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer,
-                           const torch::Tensor& imageBuffer, const bool debug, const std::vector<int>& options)
+                           const torch::Tensor& imageBuffer, const bool debug, const std::vector<int>& options,
+                           const int image_height, const int image_width)
 {
 	require_device(means3D_, "means3D");
 	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
 	const gsr_options opt = make_options(options);
 	const int P = means3D_.size(0);
-	const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+	int H, W;
+	{
+		const torch::Tensor* const g[4] = {&dL_dout_color, &dL_dout_depth, &dL_dout_median_depth, &dL_dout_final_opacity};
+		backward_image_size(g, image_height, image_width, H, W);
+	}
 	const auto means3D = means3D_.contiguous(), colors = colors_.contiguous(), scales = scales_.contiguous();
 	const auto rotations = rotations_.contiguous(), cov3D_precomp = cov3D_precomp_.contiguous(), sh = sh_.contiguous();
 	const auto viewmatrix = viewmatrix_.contiguous(), projmatrix = projmatrix_.contiguous();
@@ -265,8 +284,8 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 	const auto fo = means3D.options().dtype(torch::kFloat32);
 	for (const auto& p : {std::make_pair(&g_color, (int64_t)3), std::make_pair(&g_depth, (int64_t)1),
 	                      std::make_pair(&g_median, (int64_t)3), std::make_pair(&g_op, (int64_t)1)})
-		TORCH_CHECK(p.first->numel() == p.second * H * W && p.first->is_cuda(), "upstream gradients must be device tensors of the "
-		            "rendered image size (", H, "x", W, ")");
+		TORCH_CHECK(p.first->numel() == 0 || (p.first->numel() == p.second * H * W && p.first->is_cuda()), "upstream gradients must be "
+		            "device tensors of the rendered image size (", H, "x", W, "), or empty (absent = zero)");
 	check_rows(colors, P, 3, "colors_precomp");
 	check_rows(scales, P, 3, "scales");
 	check_rows(rotations, P, 4, "rotations");
@@ -427,12 +446,17 @@ RasterizeGaussiansRawBackward(const torch::Tensor& background, const torch::Tens
                               const torch::Tensor& dL_dout_depth, const torch::Tensor& dL_dout_median_depth,
                               const torch::Tensor& dL_dout_final_opacity, const int degree,
                               const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer,
-                              const torch::Tensor& imageBuffer, const bool debug, const std::vector<int>& options)
+                              const torch::Tensor& imageBuffer, const bool debug, const std::vector<int>& options,
+                              const int image_height, const int image_width)
 {
 	require_device(means3D_, "means3D");
 	const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
 	const int P = means3D_.size(0);
-	const int H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+	int H, W;
+	{
+		const torch::Tensor* const g[4] = {&dL_dout_color, &dL_dout_depth, &dL_dout_median_depth, &dL_dout_final_opacity};
+		backward_image_size(g, image_height, image_width, H, W);
+	}
 	const auto means3D = means3D_.contiguous(), f_dc = f_dc_.contiguous(), f_rest = f_rest_.contiguous();
 	const auto scales = raw_scales_.contiguous(), rotations = raw_rotations_.contiguous(), bg = background.contiguous();
 	const auto radii = radii_.contiguous();
@@ -467,7 +491,8 @@ RasterizeGaussiansRawBackward(const torch::Tensor& background, const torch::Tens
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
-	// the reference's positional signatures, plus one optional trailing argument: the per-call options (gsr_options)
+	// the reference's positional signatures, plus optional trailing arguments: the per-call options (gsr_options) and, for the
+	// backwards, the image size (needed only when every upstream gradient is absent = an empty tensor)
 	const std::vector<int> no_opts;
 	m.def("rasterize_gaussians", &RasterizeGaussians, py::arg("background"), py::arg("means3D"), py::arg("colors"),
 	      py::arg("opacity"), py::arg("scales"), py::arg("rotations"), py::arg("scale_modifier"), py::arg("cov3D_precomp"),
@@ -479,7 +504,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 	      py::arg("cov3D_precomp"), py::arg("viewmatrix"), py::arg("projmatrix"), py::arg("tan_fovx"), py::arg("tan_fovy"),
 	      py::arg("dL_dout_color"), py::arg("dL_dout_depth"), py::arg("dL_dout_median_depth"), py::arg("dL_dout_final_opacity"),
 	      py::arg("sh"), py::arg("degree"), py::arg("campos"), py::arg("geomBuffer"), py::arg("R"), py::arg("binningBuffer"),
-	      py::arg("imageBuffer"), py::arg("debug"), py::arg("options") = no_opts);
+	      py::arg("imageBuffer"), py::arg("debug"), py::arg("options") = no_opts, py::arg("image_height") = -1,
+	      py::arg("image_width") = -1);
 	m.def("mark_visible", &markVisible);
 	m.def("set_grad_arena", &set_grad_arena, py::arg("outs"), py::arg("keys") = std::vector<int64_t>(), py::arg("sh_chunks") = 1,
 	      py::arg("hook") = py::none(), py::arg("colors_out") = py::none());
@@ -495,5 +521,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 	      py::arg("scale_modifier"), py::arg("activation_flags"), py::arg("tan_fovx"), py::arg("tan_fovy"),
 	      py::arg("dL_dout_color"), py::arg("dL_dout_depth"), py::arg("dL_dout_median_depth"), py::arg("dL_dout_final_opacity"),
 	      py::arg("degree"), py::arg("geomBuffer"), py::arg("R"), py::arg("binningBuffer"), py::arg("imageBuffer"),
-	      py::arg("debug"), py::arg("options") = no_opts);
+	      py::arg("debug"), py::arg("options") = no_opts, py::arg("image_height") = -1, py::arg("image_width") = -1);
 }

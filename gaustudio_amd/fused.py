@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _C
 from .options import for_forward as _options_for_forward, note_grad_mode as _note_grad_mode
-from .rasterizer import _dense_image_grads, _run_guarded
+from .rasterizer import _image_grads, _run_guarded
 
 ACT_OPACITY_SIGMOID = 1
 ACT_SCALE_EXP = 2
@@ -50,11 +50,11 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     def backward(ctx, g_color, g_radii, g_depth, g_median, g_opacity):
         rs = ctx.raster_settings
         means3D, f_dc, f_rest, raw_scales, raw_rotations, radii, geom, binning, img = ctx.saved_tensors
-        g_color, g_depth, g_median, g_opacity = _dense_image_grads(rs, means3D, g_color, g_depth, g_median, g_opacity)
+        g_color, g_depth, g_median, g_opacity = _image_grads(g_color, g_depth, g_median, g_opacity)
         n = _C.native()
         call = (rs.bg, means3D, radii, f_dc, f_rest, raw_scales, raw_rotations, float(rs.scale_modifier), ctx.act,
                 float(rs.tanfovx), float(rs.tanfovy), g_color, g_depth, g_median, g_opacity, int(rs.sh_degree), geom,
-                int(ctx.num_rendered), binning, img, bool(rs.debug), ctx.gsr_options)
+                int(ctx.num_rendered), binning, img, bool(rs.debug), ctx.gsr_options, int(rs.image_height), int(rs.image_width))
         (g_means2D, g_op, g_means3D, g_fdc, g_frest, g_scales, g_rot) = _run_guarded(
             n.rasterize_gaussians_raw_backward, call, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")

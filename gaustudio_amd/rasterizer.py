@@ -48,13 +48,13 @@ def _run_guarded(fn, args, debug, dump_name, banner):
         raise
 
 
-def _dense_image_grads(rs, like, g_color, g_depth, g_median, g_opacity):
-    """The kernels read all four upstream gradients; the ones autograd did not produce (outputs the loss did not use:
-    set_materialize_grads(False)) are zeros of the output's shape (colour and median [3,H,W], depth and opacity [1,H,W])."""
-    H, W = int(rs.image_height), int(rs.image_width)
-    z = lambda c: torch.zeros((c, H, W), dtype=torch.float32, device=like.device)
-    return (z(3) if g_color is None else g_color, z(1) if g_depth is None else g_depth,
-            z(3) if g_median is None else g_median, z(1) if g_opacity is None else g_opacity)
+def _image_grads(g_color, g_depth, g_median, g_opacity):
+    """Upstream gradients autograd did not produce (outputs the loss did not use: set_materialize_grads(False) hands over None)
+    are passed on as ABSENT -- the reference's empty-tensor convention -- and the library reads nothing for them: no zero
+    planes are materialised (the reference's kernels read all four, backward.cu:476-483, and autograd fills zeros for it:
+    41 MB per 1080p step for a colour-only loss)."""
+    e = _absent()
+    return tuple(e if g is None else g for g in (g_color, g_depth, g_median, g_opacity))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -89,13 +89,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf,
          img_buf) = ctx.saved_tensors
-        grad_out_color, grad_depth, grad_median_depth, grad_final_opacity = _dense_image_grads(
-            rs, means3D, grad_out_color, grad_depth, grad_median_depth, grad_final_opacity)
+        grad_out_color, grad_depth, grad_median_depth, grad_final_opacity = _image_grads(
+            grad_out_color, grad_depth, grad_median_depth, grad_final_opacity)
         # argument order of _C.rasterize_gaussians_backward (rasterize_points.h:40-65)
         call = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth,
                 grad_median_depth, grad_final_opacity, sh, rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered,
-                binning_buf, img_buf, rs.debug, ctx.gsr_options)
+                binning_buf, img_buf, rs.debug, ctx.gsr_options, int(rs.image_height), int(rs.image_width))
         (g_means2D, g_colors, g_opacities, g_means3D, g_cov3D, g_sh, g_scales, g_rotations) = _run_guarded(
             _C.rasterize_gaussians_backward, call, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")

@@ -114,7 +114,11 @@ size_t gsr_image_bytes(int width, int height);
  *   dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6] (may be NULL when cov3D_precomp is NULL: the gradient
  *   of a covariance the operator built itself from scale / rotation has no reader), dL_dsh[P,M,3] (may be NULL if M==0),
  *   dL_dscale[P,3], dL_drot[P,4].
- * Only channel 0 of dL_dpix_median_depth[3,H,W] is read (backward.cu:481-482). */
+ * Only channel 0 of dL_dpix_median_depth[3,H,W] is read (backward.cu:481-482).
+ * Each of dL_dpix[3,H,W], dL_dpix_depth[1,H,W], dL_dpix_median_depth, dL_dpix_final_opacity[1,H,W] may be NULL: the loss does not
+ * use that output, its gradient is zero -- nothing is loaded for it and no zero plane has to be materialised by the caller (the
+ * reference reads all four, backward.cu:476-483, so its binding fills zeros); results are bit-equal to a call with explicit zero
+ * planes.  Colour alone (the other three NULL: the usual 3DGS training loss) runs a compositing kernel specialised on it. */
 int gsr_backward(int P, int D, int M, int R,
                  const float* background,
                  int width, int height,

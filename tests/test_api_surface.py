@@ -34,12 +34,16 @@ def test_operator_signatures_match_reference():
     assert fwd == ["self", "means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"]
     assert list(inspect.signature(g.rasterize_gaussians).parameters) == [
         "means3D", "means2D", "sh", "colors_precomp", "opacities", "scales", "rotations", "cov3Ds_precomp", "raster_settings"]
-    # the reference's positional parameters (rasterize_points.h:18-65), then ONE optional trailing `options` (the
-    # per-call options of include/gsrast.h gsr_options; a reference-style positional call never reaches it)
+    # the reference's positional parameters (rasterize_points.h:18-65), then optional trailing ones a reference-style positional
+    # call never reaches: `options` (the per-call options of include/gsrast.h gsr_options) and, for the backward, the image size
+    # (only needed when every upstream gradient is absent -- round 5: an absent gradient is zero and is not read)
     def positional(fn):
         ps = inspect.signature(fn).parameters
-        assert list(ps)[-1] == "options" and ps["options"].default is None
-        return list(ps)[:-1]
+        names = list(ps)
+        i = names.index("options")
+        assert ps["options"].default is None and names[i + 1:] in ([], ["image_height", "image_width"])
+        assert all(ps[n].default == -1 for n in names[i + 1:])
+        return names[:i]
     assert positional(g._C.rasterize_gaussians) == [
         "background", "means3D", "colors", "opacity", "scales", "rotations", "scale_modifier", "cov3D_precomp", "viewmatrix",
         "projmatrix", "tan_fovx", "tan_fovy", "image_height", "image_width", "sh", "degree", "campos", "prefiltered", "debug"]

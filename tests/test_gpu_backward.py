@@ -109,6 +109,76 @@ def test_backward_zero_rows_for_culled(oracle, D):
     _check(oracle, sc, cam, D, kw)
 
 
+@pytest.mark.parametrize("fast_exp", [False, True])
+def test_null_upstream_gradients_equal_explicit_zeros(oracle, fast_exp):
+    """include/gsrast.h gsr_backward: each of the four upstream image gradients may be NULL = "the loss does not use that
+    output" = zero; nothing is loaded for it.  Every output (and the composite-stage sums) must be BIT-equal to the call with
+    explicit zero planes -- for every subset, in both exp modes, in the short- and the long-list regime, with a non-black
+    background, through the per-quarter kernels (colour alone: the CONLY instantiation) and the per-wave A/B kernel -- and the
+    explicit-zero call is held against the oracle as every other backward is."""
+    import gaustudio_amd
+    cases = [(scenes.make_camera(333, 211), dict(seed=4, sigma_px_median=3.0), 6000, None),
+             (scenes.make_camera(96, 64), dict(seed=5, sigma_px_median=9.0), 9000, torch.tensor([1.0, 0.5, 0.25]))]   # long lists: row flags
+    for cam, skw, P, bg in cases:
+        sc = scenes.make_scene(P, cam, **skw)
+        kw = scene_kwargs(sc, True, False)
+        full = scenes.make_output_grads(cam, seed=3)
+        zeros = [torch.zeros_like(g) for g in full]
+        with gaustudio_amd.options(fast_exp=fast_exp):
+            hs = hip_forward(sc, cam, 3, kw, bg=bg)
+            for keep in ((1, 0, 0, 0), (1, 1, 0, 0), (0, 0, 1, 0), (0, 1, 1, 1), (1, 0, 0, 1), (0, 0, 0, 0)):
+                dense = [g if k else z for g, z, k in zip(full, zeros, keep)]
+                sparse = [g if k else None for g, k in zip(full, keep)]
+                for variant in ({}, dict(bwd_variant=2)) if not fast_exp else ({},):
+                    a = hip_backward_raw(hs, sc, cam, 3, kw, dense, bg=bg, options=dict(variant))
+                    b = hip_backward_raw(hs, sc, cam, 3, kw, sparse, bg=bg, options=dict(variant))
+                    for k in GRAD_KEYS + ("acc",):
+                        assert torch.equal(a[k], b[k]), (keep, variant, k)
+                if keep == (0, 0, 0, 0):
+                    assert all(not to_np(b[k]).any() for k in GRAD_KEYS)
+    if not fast_exp:      # the colour-only loss against the oracle (explicit zeros on the oracle's side)
+        cam, skw, P, bg = cases[0]
+        sc = scenes.make_scene(P, cam, **skw)
+        kw = scene_kwargs(sc, True, False)
+        full = scenes.make_output_grads(cam, seed=3)
+        os_ = oracle_forward(oracle, sc, cam, 3, kw)
+        ob = oracle.backward(os_, full[0].numpy(), *[np.zeros_like(g.numpy()) for g in full[1:]])
+        hs = hip_forward(sc, cam, 3, kw)
+        hb = hip_backward_raw(hs, sc, cam, 3, kw, [full[0], None, None, None])
+        err = np.abs(to_np(hb["acc"]).astype(np.float64) - ob["acc"])
+        assert (err <= 4e-5 * ob["accabs"] + 1e-30).all()
+        fin = oracle.finish_backward(os_, to_np(hb["acc"]))
+        for k in GRAD_KEYS:
+            assert_bits_equal(to_np(hb[k]).reshape(fin[k].shape), fin[k], k)
+
+
+def test_colour_only_loss_through_autograd_materialises_no_zero_planes():
+    """GaussianRasterizer with a loss on the colour image alone: autograd hands the Function None for the three unused outputs
+    (set_materialize_grads(False)); they travel as ABSENT tensors to the C ABI (NULL) -- gradients bit-equal to the same loss
+    with explicit zero gradients on the other outputs, and equal through the fused (raw-parameter) Function too."""
+    from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam = scenes.make_camera(200, 120)
+    sc = scenes.make_scene(3000, cam, seed=8, sigma_px_median=2.5)
+    dev = "cuda"
+    gcol = scenes.make_output_grads(cam, seed=2)[0].to(dev)
+    rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
+                                       cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
+    got = []
+    for explicit in (False, True):
+        leaves = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+        m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        out = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], shs=leaves["shs"],
+                                     scales=leaves["scales"], rotations=leaves["rotations"])
+        if explicit:
+            torch.autograd.backward([out[0], out[2], out[3], out[4]], [gcol] + [torch.zeros_like(out[i]) for i in (2, 3, 4)])
+        else:
+            (out[0] * gcol).sum().backward()
+        got.append({k: v.grad.clone() for k, v in leaves.items()} | {"means2D": m2.grad.clone()})
+    for k in got[0]:
+        assert torch.equal(got[0][k], got[1][k]), k
+    assert float(got[0]["shs"].abs().sum()) > 0
+
+
 def test_autograd_function_end_to_end(oracle):
     """Through GaussianRasterizer / _RasterizeGaussians (the interface gaustudio/renderers/base.py uses):
     9-tuple ordering of backward, CPU `bg`, grad carrier means2D."""

@@ -87,15 +87,28 @@ def test_backward_must_run_in_the_mode_of_its_forward():
     grads = scenes.make_output_grads(cam)
     with gaustudio_amd.options(fast_exp=True):
         fast = hip_forward(sc, cam, 3, kw)
-    with pytest.raises(RuntimeError, match="fast_exp differs from the forward"):
-        hip_backward_raw(fast, sc, cam, 3, kw, grads, debug=True)             # process default: bit-exact mode
-    exact = hip_forward(sc, cam, 3, kw)
-    _C.set_option("fast_exp", 1)
-    try:
+    # a backward that NAMES the other mode is refused (host-side memory of the forward; debug: the forward's own record) ...
+    for dbg in (False, True):
         with pytest.raises(RuntimeError, match="fast_exp differs from the forward"):
-            hip_backward_raw(exact, sc, cam, 3, kw, grads, debug=True)
-    finally:
-        _C.set_option("fast_exp", 0)
+            hip_backward_raw(fast, sc, cam, 3, kw, grads, debug=dbg, options=dict(fast_exp=0))
+    exact = hip_forward(sc, cam, 3, kw)
+    with pytest.raises(RuntimeError, match="fast_exp differs from the forward"):
+        hip_backward_raw(exact, sc, cam, 3, kw, grads, debug=True, options=dict(fast_exp=1))
+    # ... and one that names none (plain gsr_backward, or fast_exp = -1) runs in the mode of ITS FORWARD, whatever the process
+    # default says by then (round 5; it used to take the default and fail)
+    want_fast = hip_backward_raw(fast, sc, cam, 3, kw, grads, options=dict(fast_exp=1))
+    want_exact = hip_backward_raw(exact, sc, cam, 3, kw, grads, options=dict(fast_exp=0))
+    for default in (0, 1):
+        _C.set_option("fast_exp", default)
+        try:
+            for dbg in (False, True):
+                a = hip_backward_raw(fast, sc, cam, 3, kw, grads, debug=dbg)
+                b = hip_backward_raw(exact, sc, cam, 3, kw, grads, debug=dbg)
+                for k in GRAD_KEYS:
+                    assert torch.equal(a[k], want_fast[k]) and torch.equal(b[k], want_exact[k]), (default, dbg, k)
+        finally:
+            _C.set_option("fast_exp", 0)
+    assert not torch.equal(want_fast["dL_dmeans3D"], want_exact["dL_dmeans3D"])
     with pytest.raises(RuntimeError, match="fwd_variant 0"):
         with gaustudio_amd.options(fast_exp=True, fwd_variant=1):
             hip_forward(sc, cam, 3, kw)
@@ -113,6 +126,7 @@ def test_ab_variants_without_a_fast_exp_kernel_run_under_the_default_mode():
     grads = scenes.make_output_grads(cam)
     exact = hip_forward(sc, cam, 3, kw)                                     # suite default: GSR_FAST_EXP=0
     gexact = hip_backward_raw(exact, sc, cam, 3, kw, grads)
+    gwave = hip_backward_raw(exact, sc, cam, 3, kw, grads, options=dict(bwd_variant=2, fast_exp=0))
     _C.set_option("fast_exp", 1)                                            # the shipped process default
     try:
         with gaustudio_amd.options(fwd_variant=1):                          # Python route: options.resolved() decides
@@ -128,8 +142,8 @@ def test_ab_variants_without_a_fast_exp_kernel_run_under_the_default_mode():
         assert torch.equal(out[1], exact["color"])
         st = dict(exact, geom=out[6], binning=out[7], img=out[8], num_rendered=out[0])
         g = hip_backward_raw(st, sc, cam, 3, kw, grads, options=dict(bwd_variant=2))      # fast_exp not named: the forward's mode
-        for k in GRAD_KEYS:
-            assert torch.equal(g[k], gexact[k]) or k == "dL_dcov3D", k
+        for k in GRAD_KEYS:                                                               # (the per-wave kernel sums in another order:
+            assert torch.equal(g[k], gwave[k]), k                                         #  compared with itself in the named exact mode)
         # autograd: forward + backward under the default with the per-wave backward variant
         rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
                                            cam.viewmatrix.to(dev), cam.projmatrix.to(dev), 3, cam.campos.to(dev), False, False)
@@ -139,7 +153,7 @@ def test_ab_variants_without_a_fast_exp_kernel_run_under_the_default_mode():
                                        shs=Pm["shs"], scales=Pm["scales"], rotations=Pm["rotations"])
             assert torch.equal(o[0], exact["color"])
         torch.autograd.backward([o[0], o[2], o[3], o[4]], [t.to(dev) for t in grads])
-        assert torch.equal(Pm["means3D"].grad, gexact["dL_dmeans3D"])
+        assert torch.equal(Pm["means3D"].grad, gwave["dL_dmeans3D"])
     finally:
         _C.set_option("fast_exp", 0)
 

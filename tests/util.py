@@ -137,7 +137,7 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
     e = torch.Tensor([])
     g = lambda k: kw[k].to(dev).contiguous() if k in kw else e
     bg = torch.zeros(3) if bg is None else bg
-    gc, gd, gm, go = [t.to(dev).contiguous() for t in grads]
+    gc, gd, gm, go = [None if t is None else t.to(dev).contiguous() for t in grads]      # None: NULL = absent = zero (include/gsrast.h)
     fo = dict(dtype=torch.float32, device=dev)
     out = dict(dL_dmeans2D=torch.full((P, 3), float("nan"), **fo), dL_dopacity=torch.full((P, 1), float("nan"), **fo),
                dL_dcolors=torch.full((P, 3), float("nan"), **fo), dL_dmeans3D=torch.full((P, 3), float("nan"), **fo),
