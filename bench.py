@@ -55,8 +55,14 @@ WORKLOADS = {
     # an inward ring camera, > 20 % empty tiles, a 1 % tail of 50-60 px splats; per-tile lists p50 ~ 10, p99 ~ 11 k, max ~ 58 k
     "C2-clustered": (300_000, 800, 800, 3, "C2-clustered: 300k Gaussians in 48 clusters inside a ball (Zipf populations, 1 % of the splats with sigma "
                                            "50-60 px), inward ring camera at 11 units, 800x800, SH degree 3, fwd+bwd"),
+    # C4 with the VISIBILITY of a real 360-degree capture (BASELINE config 4 names MipNeRF-360 garden: the cameras stand
+    # INSIDE the scene): 5 M Gaussians in a ball of radius 6, a ring of cameras at radius 2.5 looking through the centre -- a view
+    # sees 0.14-0.19 of the Gaussians (the rest is behind the camera or outside the frustum), the union of 8 views 0.5-0.6
+    "C4-inside": (5_000_000, 1297, 840, 3, "C4-inside: 5M Gaussians in a ball of radius 6 (garden stand-in), one 1297x840 view from a camera "
+                                           "INSIDE the scene (ring of radius 2.5 looking through the centre), SH degree 3, fwd+bwd"),
 }
 CLUSTERED = {"C2-clustered": dict(cam_distance=11.0, ring=5, view=1)}
+INSIDE = {"C4-inside": dict(ball_radius=6.0, cam_radius=2.5, ring=8, sigma=0.008)}
 
 
 def rank_camera(scenes, W, H, rank, world):
@@ -490,6 +496,11 @@ def main():
         sc = scenes.make_clustered_scene(P, W, cam_distance=c["cam_distance"], seed=0)
         ring = scenes.ring_cameras(max(c["ring"], world * V + c["view"]), W, H, radius=c["cam_distance"])
         all_cams = [ring[(c["view"] + g) % len(ring)] for g in range(world * V)]
+    elif a.workload in INSIDE:
+        c = INSIDE[a.workload]
+        sc = scenes.make_ball_scene(P, radius=c["ball_radius"], seed=0, sigma=c["sigma"])
+        ring = scenes.ring_cameras(max(c["ring"], world * V), W, H, radius=c["cam_radius"])
+        all_cams = [ring[g % len(ring)] for g in range(world * V)]
     else:
         cam0 = scenes.make_camera(W, H)
         sc = scenes.make_scene(P, cam0, seed=0)                 # identical on every rank (replicated parameters)
