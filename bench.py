@@ -122,6 +122,7 @@ def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
                 stages[k + "_fwd" if k in ("preprocess", "composite") else k] = {
                     "ms": round(fwd_ms[k], 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1), "frac_hbm": round(gbs / 8000.0, 4)}
     if bwd_ms:
+        survey = {"composite_bwd": R * 44 + HW * 32 + R * 40}      # one reduced update of 10 floats per instance (the design's rows are 48 B)
         b = {"composite_bwd": R * 44 + HW * 32 + R * 48,
              # rows, then per visible Gaussian mean / radius / jacobian (instead of the 192-B coefficient row) / record / scale /
              # rotation / row offsets, and the outputs (dL_dcov3D only exists when covariances were supplied: not here)
@@ -131,6 +132,9 @@ def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
                 gbs = nbytes / (bwd_ms[k] * 1e-3) / 1e9
                 stages[k] = {"ms": round(bwd_ms[k], 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1),
                              "frac_hbm": round(gbs / 8000.0, 4)}
+                if k in survey:
+                    stages[k]["survey_8d_bytes"] = survey[k]
+                    stages[k]["frac_hbm_survey_8d_bytes"] = round(survey[k] / (bwd_ms[k] * 1e-3) / 1e9 / 8000.0, 4)
     return stages
 
 
@@ -774,6 +778,7 @@ def main():
         R_ref = out[0]
         counts = _C.inspect_counts(out[8], W, H)
         R = counts["num_binned"]
+        R_staged = _C.inspect_staged(out[8], W, H)            # what composite_fwd fetched before every pixel of a tile had saturated
         _, ranges = _C.inspect_binning(out[7], out[8], R, W, H)
         lists = list_histogram(ranges)
         vis = int((out[5] > 0).sum().item())
@@ -784,7 +789,11 @@ def main():
         ms_per_step = dt / a.steps * 1e3
         value = world * V * H * W / (dt / a.steps) / 1e6
         comp_ms = fwd_ms["composite"] if fwd_ms else None
-        alg_bytes = R * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8)
+        # SURVEY s8(d) bytes of composite_fwd on the instances the kernel actually STAGED (it stops fetching a tile's list, 256
+        # entries at a time, once every pixel of the tile has saturated: on dense frames -- C4: 3.4 k entries per tile, 99 % of the
+        # pixels saturated after a few hundred -- most of the binned instances are never read; dividing ALL of them by the
+        # kernel time would print a bandwidth the kernel does not have)
+        alg_bytes = R_staged * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8)
         counters = committed_counters(a.workload)
         traffic = a.traffic
         if traffic is None and counters and "composite_fwd" in counters:
@@ -797,10 +806,12 @@ def main():
                     "traffic_upper": (counters or {}).get("composite_fwd", {}).get("traffic_upper_bytes"),
                     "traffic_counters_match_kernel_sources": (counters or {}).get("_matches_kernel_sources"),
                     "traffic_by_mode": (counters or {}).get("by_mode"),
-                    "algorithmic_bytes": alg_bytes, "avg_ms": round(comp_ms, 4),
+                    "algorithmic_bytes": alg_bytes, "avg_ms": round(comp_ms, 4), "instances_staged": R_staged,
+                    "algorithmic_bytes_all_binned_instances": R * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8),
                     "algorithmic_bytes_with_reference_R": R_ref * 44 + T * 8 + H * W * 32 + (0 if a.fwd_only else H * W * 8),
                     "valu": valu_issue(counters, "composite_fwd", comp_ms),
-                    "note": "algorithmic bytes use the instances actually staged (tight binning); `traffic` = FETCH_SIZE + "
+                    "note": "algorithmic bytes use the instances the kernel actually staged (`instances_staged` of the `instances_binned`: "
+                            "tight binning, and a tile stops fetching once all its pixels have saturated); `traffic` = FETCH_SIZE + "
                             "WRITE_SIZE of the committed PMC passes (a PMC pass cannot run inside this process) with the "
                             "access-pattern calibration of profiles/r02_fetch_write_calibration.txt (`traffic_upper` = 2*FETCH + "
                             "WRITE); the kernel is VALU-issue bound (256 pixel evaluations per staged 48-B record): `valu.issue_frac` "
@@ -821,7 +832,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "gaussians": P, "visible": vis, "width": W, "height": H, "sh_degree": D,
-                       "num_rendered": R_ref, "instances_binned": R, "tiles": T, "tile_list_length": lists,
+                       "num_rendered": R_ref, "instances_binned": R, "instances_staged_by_composite_fwd": R_staged, "tiles": T, "tile_list_length": lists,
                        "views_per_step": world * V, "views_per_rank": V,
                        "loss": "colour + depth + median + opacity gradients consumed" if a.loss == "all" else "colour gradient only (--loss color)",
                        "camera": (f"ring of {a.rotate_cameras}, a different one every step, Adam update between the steps "

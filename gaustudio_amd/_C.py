@@ -234,6 +234,15 @@ def inspect_counts(imgBuffer, width, height):
     return dict(num_binned=int(out[0]), max_tile=int(out[1]), num_rendered=int(out[2]), overflow=int(out[3]))
 
 
+def inspect_staged(imgBuffer, width, height):
+    """Instances composite_fwd actually staged for the frame (it stops fetching a tile's list once every pixel has saturated)."""
+    import ctypes
+    L = lib()
+    out = ctypes.c_ulonglong(0)
+    _rc(L, L.gsr_inspect_staged(_ptr(imgBuffer), ctypes.c_int(int(width)), ctypes.c_int(int(height)), ctypes.byref(out), _stream(imgBuffer.device)))
+    return int(out.value)
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible, rasterize_points.cu:212-231 -> torch_binding.cpp markVisible."""
     return native().mark_visible(means3D, viewmatrix, projmatrix)

@@ -636,7 +636,8 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		}
 		launch_composite_fwd(il, width, height, ranges, point_list, recs, out_color, out_depth, out_median_depth,
 		                     out_opacity, final_T, n_contrib, med_pos, ctl, cap,
-		                     long_level >= 2 ? 0xffffffffu : (long_level == 1 ? GSR_SORT_GIANT : GSR_SORT_LDS_MAX), nocull, wave_lists, ro.fast_exp != 0, order, s);
+		                     long_level >= 2 ? 0xffffffffu : (long_level == 1 ? GSR_SORT_GIANT : GSR_SORT_LDS_MAX), nocull, wave_lists, ro.fast_exp != 0, order,
+		                     tile_count /* dead after binning: instances staged per tile, gsr_inspect_staged */, s);
 		STAGE_CHECK("composite_fwd", debug, s);
 		tm.mark();
 		return 0;
@@ -1062,6 +1063,21 @@ int gsr_inspect_counts(const char* image_buffer, int width, int height, uint32_t
 	HIP_TRY(hipMemcpyAsync(&c, image_buffer + il.ctl, sizeof(GsCtl), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	out[0] = c.num_binned; out[1] = c.max_tile_count; out[2] = c.ref_rendered; out[3] = c.err_overflow;
+	return GSR_OK;
+}
+
+int gsr_inspect_staged(const char* image_buffer, int width, int height, unsigned long long* staged_total, void* stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	g_err.clear();
+	if (!image_buffer || !staged_total) return fail(GSR_ERR_ARG, "gsr_inspect_staged: NULL argument", __FILE__, __LINE__);
+	const ImgLayout il(width, height);
+	std::vector<uint32_t> per_tile((size_t)il.T);
+	HIP_TRY(hipMemcpyAsync(per_tile.data(), image_buffer + il.tile_count, sizeof(uint32_t) * (size_t)il.T, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	unsigned long long sum = 0;
+	for (uint32_t v : per_tile) sum += v;
+	*staged_total = sum;
 	return GSR_OK;
 }
 

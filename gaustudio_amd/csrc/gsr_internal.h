@@ -130,7 +130,7 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
                           float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp,
-                          const uint32_t* tile_order, hipStream_t s);
+                          const uint32_t* tile_order, uint32_t* staged_out, hipStream_t s);
 void launch_tile_order_fwd(int T, const uint2* ranges, uint32_t* order, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 
 // --- launchers (gsr_kernels_bwd.hip) ---

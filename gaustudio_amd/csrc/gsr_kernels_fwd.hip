@@ -1703,7 +1703,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ med_pos_out,
-    const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted, const uint32_t* __restrict__ tile_order)
+    const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted, const uint32_t* __restrict__ tile_order,
+    uint32_t* __restrict__ staged_out)
 {
 	__shared__ float4 sA[256];
 	__shared__ float4 sB[256];
@@ -1738,9 +1739,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 	uint32_t med_pos = 0;
 	float med_T = 0.f;
 
+	int staged = 0;   // instances this workgroup staged before every pixel of the tile had saturated (one store at the end: the bench's byte count)
 	for (int base = 0; base < total; base += 256) {
 		if (__syncthreads_and(done)) break;
 		const int cnt = min(256, total - base);
+		staged += cnt;
 		if (tid < cnt) {
 			const uint32_t id = point_list[range.x + base + tid];
 			const GsRec* r = recs + id;
@@ -1828,6 +1831,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 		out_opacity[pix_id] = 1 - T_;
 	}
 	med_pos_out[(size_t)tile * GSR_TILE_PIX + tid] = med_final;
+	if (tid == 0 && staged_out != nullptr) staged_out[tile] = (uint32_t)staged;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1854,7 +1858,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ med_pos_out,
-    GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted, const uint32_t* __restrict__ tile_order)
+    GsCtl* __restrict__ ctl, uint32_t cap, uint32_t max_sorted, const uint32_t* __restrict__ tile_order,
+    uint32_t* __restrict__ staged_out)
 {
 	__shared__ float4 sRec[3 * GSR_FWD_PLANE];   // planes A, B, C (as above), slot 256 of each = the sentinel
 	__shared__ uint16_t sMask[256];
@@ -1895,9 +1900,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 	const char* rec_base = reinterpret_cast<const char*>(sRec);
 	const uint16_t* my_list = &sList[w][q][0];
 
+	int staged = 0;   // instances this workgroup staged before every pixel of the tile had saturated (one store at the end: the bench's byte count)
 	for (int base = 0; base < total; base += 256) {
 		if (__syncthreads_and(done)) break;
 		const int cnt = min(256, total - base);
+		staged += cnt;
 		uint32_t mk = 0;
 		if (tid < cnt) {
 			const uint32_t id = point_list[range.x + base + tid];
@@ -2012,6 +2019,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 		out_opacity[pix_id] = 1 - T_;
 	}
 	med_pos_out[(size_t)tile * GSR_TILE_PIX + slot] = med_final;
+	if (tid == 0 && staged_out != nullptr) staged_out[tile] = (uint32_t)staged;
 }
 
 // Longest-first tile order for composite_fwd on skewed frames (see launch_tile_order in gsr_kernels_bwd.hip for the
@@ -2048,12 +2056,12 @@ void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
                           float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos,
                           GsCtl* ctl_, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp,
-                          const uint32_t* tile_order, hipStream_t s)
+                          const uint32_t* tile_order, uint32_t* staged_out, hipStream_t s)
 {
 	const int chunk = (il.T + 7) / 8;
 #define GSR_LAUNCH_FWD(K)                                                                                              \
 	hipLaunchKernelGGL(K, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges, point_list, recs, out_color, \
-	                   out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted, tile_order)
+	                   out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted, tile_order, staged_out)
 	if (wave_lists) {
 		const GsCtl* ctl = ctl_;
 		if (nocull) GSR_LAUNCH_FWD(composite_fwd_kernel<true>);

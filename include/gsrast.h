@@ -334,6 +334,13 @@ int gsr_inspect_backward_sums(const char* geom_buffer, const char* scratch, int 
  * gsr_forward / gsr_backward calls fail on it) }.  `out` is HOST memory; synchronises the stream. */
 int gsr_inspect_counts(const char* image_buffer, int width, int height, uint32_t out[4], void* stream);
 
+/* Instances composite_fwd actually STAGED for this frame, summed over the tiles: a tile's workgroup stops fetching its list once
+ * every pixel of the tile has saturated (forward.cu:278-285 `done`), 256 entries at a time -- on dense frames (C4: lists of 3.4 k
+ * entries, 99 % of the pixels saturate after a few hundred) that is a fraction of the binned instances, and it is the count the
+ * kernel's byte traffic follows (bench.py's `roofline`).  Left by the kernel in the image buffer's (by then dead) tile counters.
+ * `staged_total` is HOST memory; synchronises the stream.  Valid after a gsr_forward with P > 0 and at least one instance. */
+int gsr_inspect_staged(const char* image_buffer, int width, int height, unsigned long long* staged_total, void* stream);
+
 /* point_list[R] (Gaussian ids, tile-major, depth-sorted; R = instances binned, see gsr_inspect_counts),
  * ranges[T,2] ([start,end) per tile). */
 int gsr_inspect_binning(const char* binning_buffer, const char* image_buffer, int R, int width, int height,

@@ -316,3 +316,28 @@ def test_forward_only_skips_what_only_a_backward_reads_and_refuses_one():
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     b[0].sum().backward()
     assert P["means3D"].grad is not None and bool(torch.isfinite(P["means3D"].grad).all()) and float(P["means3D"].grad.abs().sum()) > 0
+
+
+def test_staged_instance_count_of_composite_fwd():
+    """gsr_inspect_staged: the instances composite_fwd fetched before every pixel of a tile had saturated (bench.py's `roofline` divides
+    THESE bytes by the kernel time).  Bounds per frame: at least every tile's list up to its last contributor (rounded up to the
+    256-entry batches the kernel stages), at most the binned instances; a sparse frame stages everything, a dense one (long
+    lists, opaque splats) a fraction."""
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(320, 200)
+    for P, sigma, want_all in ((3000, 1.5, True), (150000, 6.0, False)):
+        sc = scenes.make_scene(P, cam, seed=3, sigma_px_median=sigma)
+        hs = hip_forward(sc, cam, 1, scene_kwargs(sc, True, False))
+        staged = _C.inspect_staged(hs["img"], cam.width, cam.height)
+        r = hs["ranges"].long()
+        total = (r[:, 1] - r[:, 0])
+        gx = (cam.width + 15) // 16
+        nc = torch.zeros(((cam.height + 15) // 16) * 16, gx * 16, dtype=torch.long, device=total.device)
+        nc[:cam.height, :cam.width] = hs["n_contrib"].long()
+        last = nc.view(-1, 16, gx, 16).permute(0, 2, 1, 3).reshape(-1, 256).max(1).values           # last contributor per tile
+        lower = torch.minimum(total, (last + 255) // 256 * 256)
+        assert int(lower.sum()) <= staged <= hs["num_binned"], (int(lower.sum()), staged, hs["num_binned"])
+        if want_all:
+            assert staged == hs["num_binned"]
+        else:
+            assert staged < 0.8 * hs["num_binned"] and int(total.max()) > 1024
