@@ -592,7 +592,7 @@ def main():
     settled = {"done": False}
     STAGE_STEPS = 12
 
-    def timed_run(fn, steps, warmup):
+    def timed_run(fn, steps, warmup, timed_level=2):
         if not settled["done"]:                              # once per process: the device at its sustained clock (see --settle)
             settled["done"] = True
             for _ in range(max(0, a.settle)):
@@ -605,7 +605,7 @@ def main():
         # boundary (nine per step) cost 3.1 % of a C3 step (1.014 against 0.983 ms, profiles/r04_warmup_ramp.txt), so the stage
         # breakdown `stage_ms` comes from STAGE_STEPS further, untimed, steps behind the timed region; its `composite` entry is
         # the timed steps' own.
-        _C.set_profiling(2)
+        _C.set_profiling(timed_level)
         t0 = time.perf_counter()
         for _ in range(steps):
             fn(True)
@@ -755,6 +755,14 @@ def main():
                                       "note": ("gaustudio_amd.options(fast_exp=False) / GSR_FAST_EXP=0: the reproducible 9-instruction exp, every output "
                                                "bit-identical to the CPU oracle (the test suite's mode)") if fast_mode else
                                               ("gaustudio_amd.options(fast_exp=True): v_exp_f32 in both compositing kernels (the library default)")}}
+        # rounds 1-3 timed the steps WITH HIP events at every stage boundary (nine records per step); kept on the line so that rounds
+        # stay comparable (housekeeping).  The other half of the r03 -> r04 protocol change, the 100 --settle steps,
+        # cannot be undone inside a warm process: profiles/r04_warmup_ramp.txt has it (1.076 ms after 5 warm-up steps, 1.03 after 50+).
+        with mode:
+            ldt, _, _ = timed_run(lambda timed: step(timed), 24, 4, timed_level=1)
+        extras["legacy_protocol_ms"] = {"ms_per_step": round(ldt / 24 * 1e3, 4), "steps": 24,
+                                        "note": "the headline step timed as rounds 1-3 did: stage-boundary events (profiling level 1, nine records "
+                                                "per step) inside the timed region; warm clock (see profiles/r04_warmup_ramp.txt for the --settle part)"}
         if not a.fwd_only and a.loss == "all":
             for p in params.values():
                 p.grad = None

@@ -15,6 +15,7 @@
 //   preprocess_bwd_sh  SH backward (dL/dSH, dL/dmean through the view direction), rows staged through LDS
 //                    (replaces backward.cu:20-139 computeColorFromSH backward)
 #include "gsr_internal.h"
+#include "gsr_bwd_timing.h"
 
 namespace gsr {
 
@@ -511,21 +512,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 // fewer per step, but v_exp_f32 issues at a quarter of their rate; a third mode -- hardware exp after a
 // BIT-EXACT forward, with a re-evaluation by gs_exp wherever opacity * G came within 4e-6 of 1/255 so that the decisions
 // stayed the forward's -- was built, passed the summation-bound tests and measured 0.5346 ms: removed.)
-// Diagnostic build only (make BWD_EXTRA=-DGSR_BWD_TIMING; tools/bwd_phase_timing.py): s_memtime around the phases of a
-// wave's life, accumulated in registers and stored to the wave's own slot at the end.  (A first version added the sums
-// with device atomics to twelve shared words: 420 k same-address atomics per launch stretched every workgroup's tail
-// and made the memory phases look four times as long as they are -- profiles/r03_composite_bwd_phases.txt.)
-#ifdef GSR_BWD_TIMING
-#define GSR_TM_SLOTS 40000
-__device__ unsigned long long g_bwd_phase_ticks[GSR_TM_SLOTS * 12];
-#define TM_DECL unsigned long long tm_last = __builtin_amdgcn_s_memtime(); unsigned long long tm_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
-#define TM(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm_acc[k] += now_ - tm_last; tm_last = now_; }
-#define TM_END { const unsigned w_ = blockIdx.x * 4 + wv; if (lane == 0 && w_ < GSR_TM_SLOTS) { for (int k_ = 0; k_ < 12; k_++) g_bwd_phase_ticks[w_ * 12 + k_] += tm_acc[k_]; } }
-#else
-#define TM_DECL
-#define TM(k)
-#define TM_END
-#endif
+// TM_DECL / TM(k) / TM_END: phase timing of a diagnostic build (gsr_bwd_timing.h); empty in the product
 #ifndef GSR_BWQ_WAVES
 #define GSR_BWQ_WAVES 4      // waves per SIMD the register allocation is held to (experiment: 5 with GSR_BWQ_BATCH=96)
 #endif
@@ -922,19 +909,6 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	}
 	TM_END
 }
-#ifdef GSR_BWD_TIMING
-}  // namespace gsr
-// out: GSR_TM_SLOTS x 12 tick sums (slot = workgroup * 4 + wave); reset: clear them afterwards
-extern "C" int gsr_debug_bwd_phase_ticks(unsigned long long* out, int reset)
-{
-	void* p = nullptr;
-	if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&p, HIP_SYMBOL(gsr::g_bwd_phase_ticks)) != hipSuccess) return -1;
-	if (out && hipMemcpy(out, p, sizeof(unsigned long long) * GSR_TM_SLOTS * 12, hipMemcpyDeviceToHost) != hipSuccess) return -2;
-	if (reset && hipMemset(p, 0, sizeof(unsigned long long) * GSR_TM_SLOTS * 12) != hipSuccess) return -3;
-	return 0;
-}
-namespace gsr {
-#endif
 
 // v_rcp_f32(1.0) == 1.0 (and a few neighbours behave): composite_bwd relies on it to carry dead pixels through
 // without a select on T (TSEL = false).  Checked once per process by gsr_selftest; a failing device gets TSEL = true.
