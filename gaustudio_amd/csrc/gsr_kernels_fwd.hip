@@ -159,6 +159,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	float3 p_orig = {0.f, 0.f, 0.f};
 	float pix_x = 0.f, pix_y = 0.f, conic_x = 0.f, conic_y = 0.f, conic_z = 0.f, depth = 0.f, op_raw = 0.f;
 	float sh[NC * 3];
+	// the coefficient row of this Gaussian (12 x (D+1)^2 B, up to 192): requested EARLY (right after the near-plane test, so that
+	// it is in flight during the covariance arithmetic) or, for a Gaussian that is probably outside the image, only once it has
+	// turned out visible after all -- see `prefetch` below
+	auto load_sh = [&]() {
+		if (RAW) {
+			// split storage (f_dc [P,1,3] + f_rest [P,M-1,3], models/vanilla_sg.py:103-106): no torch.cat copy
+			const float* dcp = shs + 3 * (size_t)idx;
+			const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
+			sh[0] = dcp[0]; sh[1] = dcp[1]; sh[2] = dcp[2];
+#pragma unroll
+			for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
+		} else {
+			const float* shp = shs + (size_t)idx * M * 3;
+			if ((sh_vec4 & 1) && (NC * 3) % 4 == 0) {
+#pragma unroll
+				for (int i = 0; i < NC * 3 / 4; i++) {
+					const float4 v = reinterpret_cast<const float4*>(shp)[i];   // (not nontemporal: a lane's 12 loads share cache lines)
+					sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+			}
+		}
+	};
+	bool prefetch = true;
 	if (idx < P) {
 		do {
 			const float* view = cam->view;
@@ -181,26 +207,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 				break;
 			}
 			if (colors_precomp == nullptr) {
-				if (RAW) {
-					// split storage (f_dc [P,1,3] + f_rest [P,M-1,3], models/vanilla_sg.py:103-106): no torch.cat copy
-					const float* dcp = shs + 3 * (size_t)idx;
-					const float* rp = shs_rest + (size_t)idx * (M - 1) * 3;
-					sh[0] = dcp[0]; sh[1] = dcp[1]; sh[2] = dcp[2];
-#pragma unroll
-					for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
-				} else {
-					const float* shp = shs + (size_t)idx * M * 3;
-					if (sh_vec4 && (NC * 3) % 4 == 0) {
-#pragma unroll
-						for (int i = 0; i < NC * 3 / 4; i++) {
-							const float4 v = reinterpret_cast<const float4*>(shp)[i];   // (not nontemporal: a lane's 12 loads share cache lines)
-							sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
-						}
-					} else {
-#pragma unroll
-						for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
-					}
+				// Round 5: a Gaussian in front of the camera but OUTSIDE the image (a camera inside the scene sees 16 % of a 360-degree
+				// capture; half of the rest is in front of it) used to fetch its 192-B row for nothing -- 40 % of this kernel's bytes at
+				// C4-inside.  The reference has no x / y frustum test (auxiliary.h:147-161: commented out), only the empty tile
+				// rect further down decides, and that needs the covariance.  So this is an ESTIMATE, not a decision: centre +- a
+				// generous footprint (3 sigma of the largest axis under the rotation's norm, doubled for the off-axis Jacobian,
+				// + the 0.3-px^2 blur + a pixel) against the image; if it says "outside", the row is not requested here, and should
+				// the exact path find the Gaussian visible after all it is fetched then (late, correct).  No result bit depends on it
+				// (sh_vec4 bits 1-2: 0 = estimate, 1 = always early (round 4), 2 = always late -- gsr_set_option("sh_prefetch")).
+				const int gate = (sh_vec4 >> 1) & 3;
+				if (gate == 2) prefetch = false;
+				else if (gate == 0 && cov3D_precomp == nullptr) {
+					const float3 sa = gs_act_scale(sc_raw, act);
+					const float smax = fmaxf(fmaxf(fabsf(sa.x), fabsf(sa.y)), fabsf(sa.z)) * fabsf(scale_modifier);
+					const float qn2 = (act & GSR_ACT_ROT_NORMALIZE) ? 1.0f : FMA(q_raw.x, q_raw.x, FMA(q_raw.y, q_raw.y, FMA(q_raw.z, q_raw.z, q_raw.w * q_raw.w)));
+					const float r_est = 6.0f * smax * fmaxf(qn2, 1.0f) * fmaxf(focal_x, focal_y) / p_view.z + 3.0f;
+					const float ex = 0.5f * (FMA(p_proj_x, (float)W, (float)W) - 1.0f), ey = 0.5f * (FMA(p_proj_y, (float)H, (float)H) - 1.0f);
+					prefetch = !(ex + r_est < 0.0f || ex - r_est > (float)W || ey + r_est < 0.0f || ey - r_est > (float)H);
 				}
+				if (prefetch) load_sh();
 			}
 			float cov3D[6];
 			if (cov3D_precomp != nullptr) {
@@ -240,6 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 			depth = p_view.z;
 			vis = true;
 		} while (0);
+		if (vis && !prefetch && colors_precomp == nullptr) load_sh();   // the estimate was wrong (or gate 2): fetched late
 	}
 
 	uint32_t my_tiles = 0, dead = 0;
@@ -333,7 +359,7 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 {
 	const float focal_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:225-226
 	const float focal_x = a.W / (2.0f * a.tan_fovx);
-	const int sh_vec4 = (a.shs != nullptr && ((uintptr_t)a.shs % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0;
+	const int sh_vec4 = ((a.shs != nullptr && ((uintptr_t)a.shs % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0) | ((a.sh_gate & 3) << 1);
 	const int D = a.colors_precomp ? 0 : a.D;
 	dim3 grid((a.P + 255) / 256), block(256);
 #define GSR_LAUNCH_PRE(DEG, RAW)                                                                                   \
