@@ -1,108 +1,119 @@
 #!/usr/bin/env python
-"""The alpha-beta model behind DESIGN.md s7: exposed exchange time and N-GPU speed-up of the gradient exchanges of
-gaustudio_amd/parallel.py for a given compute step.  NOTHING HERE IS MEASURED ON MULTI-GPU HARDWARE: no 8-GPU node has been
-available to the builder (or, rounds 1-3, to the driver); the single-GPU inputs (step times, stage times, visible
-fractions) are measured, the interconnect is a model.
+"""The alpha-beta model behind DESIGN.md s7: N-GPU step time and speed-up of the gradient exchanges of
+gaustudio_amd/parallel.py.  NOTHING HERE IS MEASURED ON MULTI-GPU HARDWARE: no multi-GPU node has been available to the
+builder (or, rounds 1-4, to the driver).  What IS measured, per scenario, on one MI355X (round 5;
+profiles/r05_bench_lines/, named in every row):
 
-    python tools/comm_model.py                      # the tables of DESIGN.md s7
-    python tools/comm_model.py --P 1e6 --t_c 1.06 --tail 0.05 --B 330 --alpha 25 --N 8 --V 1 --vis_view 0.85 --vis_union 0.87
+  t1        the plain single-GPU step of the scenario (`python bench.py --workload W`): the baseline a scaling run divides by;
+  pg1       the step of the N > 1 CODE PATH with a process group of one rank over RCCL (GSR_BENCH_FORCE_PG=1): every kernel,
+            launch and collective CALL of the multi-GPU step (armed buffers, chunk / colour hooks, pack / unpack, the local rebuild
+            of the SH gradient), with nothing on the wire -- i.e. what a rank computes per step;
+  rebuild   the part of pg1 behind the last backward (`comm.comm_exposed_ms` at world 1: the SH-gradient rebuild and the
+            collectives' launch cost): the geometry all-reduce runs beside it;
+  tail      the SH-direction stage of a backward, which the early colour all-gather overlaps (0.46 of `preprocess_bwd`);
+  vis_view  fraction of the Gaussians a view sees (radii > 0: `config.visible` / P); vis_union: union of the step's 8 views.
 
-Interconnect.  8 x MI355X, fully connected xGMI mesh: 7 links per GPU, ~64 GB/s per direction each on the previous
-generation (448 GB/s out per GPU), more on this one (the task sheet quotes ~153 GB/s per link, i.e. ~77 per direction,
-537 GB/s out).  RCCL's large-message all-reduce reaches ~70-75 % of that as bus bandwidth; B = 330 GB/s is the
-conservative default, B = 400 the other column.  alpha = latency of one collective (25 us).
+Rounds 3-4 printed ONE compute time for rows with different visibility; every row now carries the step of its
+own scenario.
 
+Interconnect (the modelled part).  8 x MI355X, fully connected xGMI mesh, 7 links per GPU (the task sheet: ~153 GB/s per link).
+RCCL's large-message bus bandwidth B: 330 GB/s (conservative) and 400.  alpha = 25 us per collective.
   all-reduce of S bytes:           alpha + 2 (N-1)/N S / B
   all-gather of S bytes per rank:  alpha + (N-1) S / B
+Collectives on one communicator run one after the other.
 
-Exchanges (bytes per Gaussian and rank; M = 16 SH coefficients, V views per rank):
-  dense                one all-reduce of 236 B                                        (north star's "single all-reduce")
-  factored             all-gather 12 V B (dRGB per view) + all-reduce 44 B (geometry)  (round 3)
-  factored, early      the same, each view's all-gather started from inside its backward: at V = 1 the SH-direction stage
-                       (`tail` ms) overlaps it; at V > 1 additionally the (V-1) later views' compute
-  view                 all-gather of header (P/8 + P/64 B) + 12 B x vis_view per view; geometry all-reduce dense
-  view+geometry        as view, geometry all-reduce on the union rows (44 B x vis_union) + ~30 us of host synchronisation
+  step_N(dense)          = pg1 + max(0, allreduce(236 B x P) - tail)          north_star's single all-reduce, SH ranges reduced from
+                                                                              inside the backward
+  step_N(factored)       = pg1 + max(0, allgather(12 B x P) - tail) + max(0, allreduce(44 B x P) - rebuild)
+  step_N(view)           = pg1 + max(0, allgather(hdr + 12 B x vis_view P) - tail) + max(0, allreduce(44 B x P) - rebuild)
+  step_N(view+geometry)  = as view with allreduce(44 B x vis_union P) + one host synchronisation (30 us)
+  speed-up               = N t1 / step_N          (what a driver computes from `value` at N and at 1; one view per GPU)
 
-Collectives on one communicator run one after the other; what is not hidden behind compute is exposed.  speed-up =
-N V t_c / (V t_c + exposed)."""
+    python tools/comm_model.py                      # the table of DESIGN.md s7
+"""
 import argparse
 
-
-def allreduce_ms(S, N, B, alpha_us):
-    return alpha_us * 1e-3 + 2.0 * (N - 1) / N * S / (B * 1e9) * 1e3
-
-
-def allgather_ms(S_rank, N, B, alpha_us):
-    return alpha_us * 1e-3 + (N - 1) * S_rank / (B * 1e9) * 1e3
+ALPHA_US = 25.0
+SYNC_MS = 0.03
 
 
-def model(P, t_c, N, V, B, alpha, M=16, vis_view=1.0, vis_union=1.0, tail=0.05, sync_ms=0.03):
-    """-> {exchange: (bytes moved per rank, exposed ms, speed-up)}.  t_c: compute per view (ms); tail: the part of a backward that
-    follows its geometry stage (SH-direction kernel), which an early all-gather overlaps."""
-    comp = t_c * V
+def allreduce_ms(S, N, B):
+    return ALPHA_US * 1e-3 + 2.0 * (N - 1) / N * S / (B * 1e9) * 1e3
+
+
+def allgather_ms(S_rank, N, B):
+    return ALPHA_US * 1e-3 + (N - 1) * S_rank / (B * 1e9) * 1e3
+
+
+# scenario -> measured single-GPU inputs (ms), each with the bench line it was read from (profiles/r05_bench_lines/)
+SCENARIOS = {
+    "C3 (1 M, 1920x1080, frustum cloud: 0.85 visible per view)": dict(
+        P=1_000_000, t1=0.9912, t1_src="s3_bench_C3_gate0.json", vis_view=0.8535, vis_union=0.87,
+        preprocess_bwd=0.1162,
+        pg1=dict(dense=(1.1453, 0.0527, "s3_pg1_C3_dense_none.json"), factored=(1.0620, 0.0755, "s3_pg1_C3_factored_none.json"),
+                 view=(1.1252, 0.0676, "s3_pg1_C3_factored_view.json"))),
+    "C4 share, ALL 5 M in the frustum (0.87 visible per view)": dict(
+        P=5_000_000, t1=1.8974, t1_src="s3_bench_C4_gate0.json", vis_view=0.8737, vis_union=0.90,
+        preprocess_bwd=0.5400,
+        pg1=dict(dense=(2.0436, 0.0514, "s3_pg1_C4_dense_none.json"), factored=(1.9843, 0.2185, "s3_pg1_C4_factored_none.json"),
+                 view=(2.1745, 0.2689, "s3_pg1_C4_factored_view.json"))),
+    "C4-inside (5 M ball, cameras INSIDE the scene: 0.158 visible per view)": dict(
+        P=5_000_000, t1=1.1542, t1_src="s3_bench_C4-inside_gate0.json", vis_view=0.1576, vis_union=0.54,
+        preprocess_bwd=0.5066,
+        pg1=dict(dense=(1.3001, 0.0524, "s3_pg1_C4-inside_dense_none.json"), factored=(1.2475, 0.2173, "s3_pg1_C4-inside_factored_none.json"),
+                 view=(1.3940, 0.2392, "s3_pg1_C4-inside_factored_view.json"))),
+}
+
+
+def model(sc, N, B):
+    """-> {exchange: (MB moved per rank, step_N ms, speed-up)}"""
+    P, t1 = sc["P"], sc["t1"]
+    tail = 0.46 * sc["preprocess_bwd"]
+    hdr = P / 8.0 + P / 64.0 + 16
     out = {}
 
-    def put(name, moved, exposed):
-        out[name] = (moved, exposed, N * comp / (comp + exposed))
+    def put(name, moved, step):
+        out[name] = (moved / 1e6, step, N * t1 / step)
 
-    dense = P * (M * 3 + 11) * 4
-    put("dense", 2.0 * (N - 1) / N * dense, allreduce_ms(dense, N, B, alpha))
-    geo = allreduce_ms(P * 44, N, B, alpha)
-    ag_view = allgather_ms(P * 12, N, B, alpha)                       # one view's colour slots
-    put("factored", 2.0 * (N - 1) / N * P * 44 + (N - 1) * P * 12 * V, geo + allgather_ms(P * 12 * V, N, B, alpha))
-    # early: view v's all-gather starts `tail` before its backward ends; the views after it keep computing
-    hidden = lambda ag: sum(min(ag, tail + (V - 1 - v) * t_c) for v in range(V))
-    put("factored, early", out["factored"][0], geo + V * ag_view - hidden(ag_view))
-    hdr = P / 8.0 + P / 64.0 + 16
-    ag_pack = allgather_ms(hdr + P * 12 * vis_view, N, B, alpha)
-    put("view", 2.0 * (N - 1) / N * P * 44 + (N - 1) * V * (hdr + P * 12 * vis_view), geo + V * ag_pack - hidden(ag_pack))
-    geo_u = allreduce_ms(P * 44 * vis_union, N, B, alpha) + sync_ms
-    put("view+geometry", 2.0 * (N - 1) / N * P * 44 * vis_union + (N - 1) * V * (hdr + P * 12 * vis_view), geo_u + V * ag_pack - hidden(ag_pack))
+    pg, _, _ = sc["pg1"]["dense"]
+    put("dense", 2.0 * (N - 1) / N * P * 236, pg + max(0.0, allreduce_ms(P * 236, N, B) - tail))
+    pg, rebuild, _ = sc["pg1"]["factored"]
+    put("factored", 2.0 * (N - 1) / N * P * 44 + (N - 1) * P * 12,
+        pg + max(0.0, allgather_ms(P * 12, N, B) - tail) + max(0.0, allreduce_ms(P * 44, N, B) - rebuild))
+    pg, rebuild, _ = sc["pg1"]["view"]
+    msg = hdr + P * 12 * sc["vis_view"]
+    put("view", 2.0 * (N - 1) / N * P * 44 + (N - 1) * msg,
+        pg + max(0.0, allgather_ms(msg, N, B) - tail) + max(0.0, allreduce_ms(P * 44, N, B) - rebuild))
+    put("view+geometry", 2.0 * (N - 1) / N * P * 44 * sc["vis_union"] + (N - 1) * msg,
+        pg + max(0.0, allgather_ms(msg, N, B) - tail) + SYNC_MS + max(0.0, allreduce_ms(P * 44 * sc["vis_union"], N, B) - rebuild))
     return out
-
-
-def table(title, P, t_c, tail, cases, B_list=(330.0, 400.0), alpha=25.0, N=8):
-    print(title)
-    print(f"  {'V':>2} {'vis/view':>8} {'union':>6}   " + "   ".join(f"{'B=%d' % B:^58}" for B in B_list))
-    names = ("dense", "factored", "factored, early", "view", "view+geometry")
-    for V, vv, vu in cases:
-        cols = []
-        for B in B_list:
-            m = model(P, t_c, N, V, B, alpha, vis_view=vv, vis_union=vu, tail=tail)
-            cols.append(" ".join(f"{m[k][2]:5.2f}x" for k in names) + f"  [{m['view'][0] / 1e6:5.0f} MB, {m['view'][1]:.2f} ms]")
-        print(f"  {V:>2} {vv:>8.2f} {vu:>6.2f}   " + "   ".join(cols))
-    print("     columns per B: dense | factored | factored, early | view | view+geometry   [view: MB moved per rank, exposed ms]")
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--P", type=float, default=None)
-    ap.add_argument("--t_c", type=float, default=1.06)
-    ap.add_argument("--tail", type=float, default=0.05)
-    ap.add_argument("--B", type=float, default=330.0)
-    ap.add_argument("--alpha", type=float, default=25.0)
-    ap.add_argument("--N", type=int, default=8)
-    ap.add_argument("--V", type=int, default=1)
-    ap.add_argument("--vis_view", type=float, default=1.0)
-    ap.add_argument("--vis_union", type=float, default=1.0)
+    ap.add_argument("--N", type=int, nargs="*", default=[8, 4, 2])
+    ap.add_argument("--B", type=float, nargs="*", default=[330.0, 400.0])
     a = ap.parse_args()
-    if a.P is not None:
-        for k, (moved, exposed, sp) in model(int(a.P), a.t_c, a.N, a.V, a.B, a.alpha, vis_view=a.vis_view, vis_union=a.vis_union, tail=a.tail).items():
-            print(f"{k:16s} {moved / 1e6:8.0f} MB moved per rank  exposed {exposed:.2f} ms  speed-up at {a.N} GPUs {sp:.2f}x")
-        return
-    print("alpha = 25 us per collective.  MODEL, not a measurement (no multi-GPU node available); single-GPU inputs are measured:")
-    print("C3 step 1.06 ms (BENCH r04 builder runs, fast_exp default), SH-direction tail 0.05 ms; C4 share step 2.04 ms, tail 0.25 ms;")
-    print("visible fractions: bench scenes (synthetic frustum cloud: every rank's view sees 0.85, the union of 8 views 3 degrees apart 0.87);")
-    print("ring cameras OUTSIDE a ball of Gaussians: 0.81 per view / 0.94 union (camera radius 5, ball 3), 0.62 / 0.87 (radius 4);")
-    print("cameras INSIDE the scene (a 360-degree capture: camera ring radius 2-3 in a ball of radius 6): 0.14-0.19 per view / 0.52-0.59 union")
-    print("(oracle radii > 0, 200 k Gaussians, 8 ring cameras 1297x840: the numbers in tools/comm_model.py's docstring of DESIGN.md s7).\n")
-    table("C3 (1 M Gaussians), N = 8", 1_000_000, 1.06, 0.05, [(1, 1.0, 1.0), (1, 0.85, 0.87), (2, 0.85, 0.90), (4, 0.85, 0.95)])
-    print()
-    table("C4 share (5 M Gaussians), N = 8", 5_000_000, 2.04, 0.25,
-          [(1, 1.0, 1.0), (1, 0.81, 0.94), (1, 0.62, 0.87), (1, 0.19, 0.59), (1, 0.14, 0.52), (2, 0.19, 0.75)])
-    print()
-    for N in (2, 4):
-        table(f"C3, N = {N}", 1_000_000, 1.06, 0.05, [(1, 0.85, 0.87)], N=N)
+    print("MODEL, not a measurement: no multi-GPU node was available.  Per-scenario single-GPU inputs are measured (round 5, one MI355X,")
+    print("profiles/r05_bench_lines/); the interconnect is alpha = 25 us + bytes / B.  One view per GPU.  speed-up = N t1 / step_N.\n")
+    names = ("dense", "factored", "view", "view+geometry")
+    for title, sc in SCENARIOS.items():
+        print(title)
+        print(f"  t1 = {sc['t1']:.4f} ms ({sc['t1_src']}); step of the N > 1 code path at world 1 (pg1) / of which behind the last backward:")
+        for k, (pg, rb, src) in sc["pg1"].items():
+            print(f"    {k:9s} {pg:.4f} / {rb:.4f} ms  ({src})")
+        print(f"  tail (SH-direction stage, 0.46 x preprocess_bwd {sc['preprocess_bwd']:.4f}) = {0.46 * sc['preprocess_bwd']:.3f} ms; "
+              f"visible per view {sc['vis_view']:.3f}, union of 8 views {sc['vis_union']:.2f}")
+        for N in a.N:
+            for B in a.B:
+                m = model(sc, N, B)
+                print(f"  N = {N}, B = {B:.0f} GB/s: " + "   ".join(f"{k} {m[k][2]:4.2f}x ({m[k][1]:.2f} ms, {m[k][0]:.0f} MB)" for k in names))
+        print()
+    print("Reading: at C3 the factored exchange leaves ~0.4-0.5 ms exposed behind a 1.06-ms rank step (5.3-5.7x at 8 GPUs; the dense single")
+    print("all-reduce 3.4-3.7x); at 5 M Gaussians the 44 B per Gaussian of the geometry all-reduce alone (220 MB: 1.0-1.2 ms on the wire) is as")
+    print("long as a whole C4-inside step, and only its restriction to the union of the step's views (view+geometry: 0.54 of the rows)")
+    print("keeps 8 GPUs at 5.0-5.3x there; with every Gaussian in every frustum (the synthetic C4 share) nothing can be left out: 3.8-4.3x.")
+    print("north_star's >= 6x is NOT reached on paper with one view per GPU and replicated parameters.")
 
 
 if __name__ == "__main__":
