@@ -157,7 +157,15 @@ struct BwdArgs {
 //   row: 0,1 dL_dmean2D.xy | 2,3,4 dL_dconic a,b,c | 5 dL_dopacity | 6,7,8 dL_dcolor | 9 dL_ddepth | 10,11 unused
 #define GSR_ROW_STRIDE 12
 #define GSR_FLAG_AVG 1024   // average tile list length above which the backward uses per-row validity flags
-#define GSR_SUM_SLAB 160   // rows per LDS slab of preprocess_bwd's cooperative row fetch (7.5 KiB per wave)
+#ifndef GSR_SUM_SLAB
+// rows per LDS slab of preprocess_bwd's cooperative row fetch: 4.5 KiB per wave.  Round 5: 160 -> 96 -- the kernel is bound by
+// the latency of a workgroup's dependent chain (row fetch -> sums -> cov2D / cov3D backward) times the generations of workgroups a
+// CU holds, not by bytes (C4-inside: 0.64 GB in 0.28 ms; compacting the visible Gaussians of a block into fewer waves and wide
+// transposed output stores were both built and measured: +13 % / no change), so LDS per workgroup = occupancy is what moves it:
+// 5 -> 8 workgroups per CU; preprocess_bwd 0.1164 -> 0.1098 ms (C3), 0.539 -> 0.493 (C4), 0.507 -> 0.484 (C4-inside); 64 / 80
+// measured the same within 1 %, 32 worse (profiles/r05_preprocess_bwd_experiments.txt)
+#define GSR_SUM_SLAB 96
+#endif
 // scratch: [bg f32 x 4][rows f32 x R*12]
 struct BwdLayout {
 	size_t bg, flags, rows, total;

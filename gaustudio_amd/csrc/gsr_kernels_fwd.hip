@@ -139,7 +139,10 @@ __device__ __forceinline__ uint32_t gs_sh_to_rgb(const float* sh, float3 p_orig,
 // instructions of covariance / conic / rect arithmetic (measured at C3: 92 us with the row loaded where it is
 // used, 88 us staged wave-cooperatively through LDS, 71 us like this).
 template <int D, bool RAW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void preprocess_fwd_kernel(
+#ifndef GSR_PRE_WAVES
+#define GSR_PRE_WAVES 4   // waves per SIMD the register allocation is held to (5: measured in round 5)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAVES, GSR_PRE_WAVES))) void preprocess_fwd_kernel(
     int P, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, int act_arg, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
