@@ -6,6 +6,7 @@ test_gpu_forward._adversarial_scene, each through
   * backward sums inside the oracle's fp32 summation bounds, per-Gaussian stage bit-exact given the sums.
 usage: python tests/tools/fuzz_campaign.py [--n 150] [--first 100]      (test infrastructure: imports oracle/)"""
 import argparse, os, sys, time, traceback
+os.environ.setdefault("GSR_FAST_EXP", "0")   # the reproducible mode (as tests/conftest.py): the one the CPU oracle pins to the bit; set before libgsrast.so loads
 import numpy as np, torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
