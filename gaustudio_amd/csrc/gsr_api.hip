@@ -147,7 +147,6 @@ std::atomic<int> g_opt_fwd_variant{env_int("GSR_FWD_VARIANT", 0)}; // 0: per-qua
 std::atomic<int> g_opt_bwd_variant{env_int("GSR_BWD_VARIANT", -1)};   // -1: from gsr_selftest; bit 0: select on T
 std::atomic<int> g_opt_speculative{env_int("GSR_SPECULATIVE", 1)}; // launch binning + compositing before R is known
 std::atomic<int> g_opt_tile_order{env_int("GSR_TILE_ORDER", 1)};   // backward of a skewed frame: tiles longest walk first (0: always XCD-banded)
-std::atomic<int> g_opt_sh_prefetch{env_int("GSR_SH_PREFETCH", 0)};   // preprocess_fwd's SH-row request: 0 estimate-gated, 1 always early, 2 always late (A/B; no result bit)
 std::atomic<int> g_opt_band_lo{0}, g_opt_band_hi{0};               // tile rows [lo, hi) this process renders (hi <= 0: all)
 // exp on the transcendental unit (v_exp_f32) in both compositing kernels.  DEFAULT ON since round 4: pinned directly against the
 // reference's kernels and the CPU oracle (tests/test_gpu_ref.py, tests/test_gpu_fastexp_oracle.py), it differs from the
@@ -564,7 +563,6 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	a.tight = ro.tight != 0;
 	a.band_lo = ro.band_lo > 0 ? ro.band_lo : 0;
 	a.band_hi = ro.band_hi;
-	a.sh_gate = g_opt_sh_prefetch.load();
 
 	tm.mark();
 	uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + gl.tiles_touched);
@@ -1006,7 +1004,6 @@ int gsr_set_option(const char* name, int value)
 	else if (n == "speculative") g_opt_speculative.store(value);
 	else if (n == "fast_exp") g_opt_fast_exp.store(value != 0);
 	else if (n == "tile_order") g_opt_tile_order.store(value != 0);
-	else if (n == "sh_prefetch") g_opt_sh_prefetch.store(value < 0 || value > 2 ? 0 : value);
 	else if (n == "roctx") g_opt_roctx.store(value != 0);
 	else if (n == "tile_row_lo") g_opt_band_lo.store(value > 0 ? value : 0);
 	else if (n == "tile_row_hi") g_opt_band_hi.store(value);
@@ -1029,7 +1026,6 @@ int gsr_get_option(const char* name)
 	if (n == "speculative") return g_opt_speculative.load();
 	if (n == "fast_exp") return g_opt_fast_exp.load();
 	if (n == "tile_order") return g_opt_tile_order.load();
-	if (n == "sh_prefetch") return g_opt_sh_prefetch.load();
 	if (n == "roctx") return g_opt_roctx.load() != 0 && roctx().push != nullptr;
 	if (n == "tile_row_lo") return g_opt_band_lo.load();
 	if (n == "tile_row_hi") return g_opt_band_hi.load();

@@ -95,7 +95,6 @@ struct FwdArgs {
 	int act;                 // f1: GSR_ACT_* flags
 	int tight;               // 1: bin into the tight rect (gs_tight_rect); 0: the reference's square (A/B, debugging)
 	int band_lo, band_hi;    // only tile rows [band_lo, band_hi) are binned (tile-grid sharding of one view); hi <= 0: all
-	int sh_gate;             // SH-row request of preprocess_fwd: 0 = early unless the Gaussian is probably outside the image, 1 = always early, 2 = always late
 };
 
 // --- launchers (gsr_kernels_fwd.hip) ---

@@ -134,14 +134,12 @@ __device__ __forceinline__ uint32_t gs_sh_to_rgb(const float* sh, float3 p_orig,
 
 // RAW: the f1 interface (raw attributes: activations in-kernel, SH in two tensors).  A compile-time switch:
 // as a run-time one it cost the standard path 40 us at C3.
-// Memory-level parallelism is arranged by hand: every per-Gaussian input of the geometry is requested up front,
-// and the 192-B SH row is requested right after the near-plane test so that it is in flight during the ~300
-// instructions of covariance / conic / rect arithmetic (measured at C3: 92 us with the row loaded where it is
-// used, 88 us staged wave-cooperatively through LDS, 71 us like this).
-template <int D, bool RAW>
+// Memory-level parallelism is arranged by hand: every per-Gaussian input of the geometry is requested up front; the
+// 192-B SH row only once the Gaussian is known to be visible (see `load_sh` below).
 #ifndef GSR_PRE_WAVES
-#define GSR_PRE_WAVES 4   // waves per SIMD the register allocation is held to (5: measured in round 5)
+#define GSR_PRE_WAVES 4   // waves per SIMD the register allocation is held to (round 5: 5 gains 0.015 ms at C4-inside and loses at C3 / C4, 6 spills)
 #endif
+template <int D, bool RAW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAVES, GSR_PRE_WAVES))) void preprocess_fwd_kernel(
     int P, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -162,9 +160,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
 	float3 p_orig = {0.f, 0.f, 0.f};
 	float pix_x = 0.f, pix_y = 0.f, conic_x = 0.f, conic_y = 0.f, conic_z = 0.f, depth = 0.f, op_raw = 0.f;
 	float sh[NC * 3];
-	// the coefficient row of this Gaussian (12 x (D+1)^2 B, up to 192): requested EARLY (right after the near-plane test, so that
-	// it is in flight during the covariance arithmetic) or, for a Gaussian that is probably outside the image, only once it has
-	// turned out visible after all -- see `prefetch` below
+	// the coefficient row of this Gaussian (12 x (D+1)^2 B, up to 192) is requested only once the Gaussian has turned out VISIBLE
+	// (round 5).  Rounds 2-4 requested it right after the near-plane test so that it was in flight during the covariance arithmetic
+	// (71 against 92 us at C3 in round 2); since the kernel also forms the SH-direction Jacobian (round 4: 115 VGPRs, held to 4 waves per
+	// SIMD) the late request is the faster one everywhere -- preprocess C3 0.0691 -> 0.0683 ms, C4 0.344 -> 0.339 -- and a Gaussian in
+	// front of the camera but outside the image (a camera inside the scene sees 16 % of a 360-degree capture; half of the rest is in
+	// front of it; the reference has no x / y frustum test, auxiliary.h:147-161) no longer fetches 192 B for nothing: C4-inside
+	// 0.262 -> 0.169 ms (profiles/r05_preprocess_fwd_experiments.txt: early / estimate-gated / late, 4-7 waves per SIMD)
 	auto load_sh = [&]() {
 		if (RAW) {
 			// split storage (f_dc [P,1,3] + f_rest [P,M-1,3], models/vanilla_sg.py:103-106): no torch.cat copy
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
 			for (int i = 3; i < NC * 3; i++) sh[i] = rp[i - 3];
 		} else {
 			const float* shp = shs + (size_t)idx * M * 3;
-			if ((sh_vec4 & 1) && (NC * 3) % 4 == 0) {
+			if (sh_vec4 && (NC * 3) % 4 == 0) {
 #pragma unroll
 				for (int i = 0; i < NC * 3 / 4; i++) {
 					const float4 v = reinterpret_cast<const float4*>(shp)[i];   // (not nontemporal: a lane's 12 loads share cache lines)
@@ -187,7 +189,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
 			}
 		}
 	};
-	bool prefetch = true;
 	if (idx < P) {
 		do {
 			const float* view = cam->view;
@@ -208,27 +209,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
 			if (p_view.z <= 0.2f) {
 				if (prefiltered) ctl->err_prefiltered = 1;
 				break;
-			}
-			if (colors_precomp == nullptr) {
-				// Round 5: a Gaussian in front of the camera but OUTSIDE the image (a camera inside the scene sees 16 % of a 360-degree
-				// capture; half of the rest is in front of it) used to fetch its 192-B row for nothing -- 40 % of this kernel's bytes at
-				// C4-inside.  The reference has no x / y frustum test (auxiliary.h:147-161: commented out), only the empty tile
-				// rect further down decides, and that needs the covariance.  So this is an ESTIMATE, not a decision: centre +- a
-				// generous footprint (3 sigma of the largest axis under the rotation's norm, doubled for the off-axis Jacobian,
-				// + the 0.3-px^2 blur + a pixel) against the image; if it says "outside", the row is not requested here, and should
-				// the exact path find the Gaussian visible after all it is fetched then (late, correct).  No result bit depends on it
-				// (sh_vec4 bits 1-2: 0 = estimate, 1 = always early (round 4), 2 = always late -- gsr_set_option("sh_prefetch")).
-				const int gate = (sh_vec4 >> 1) & 3;
-				if (gate == 2) prefetch = false;
-				else if (gate == 0 && cov3D_precomp == nullptr) {
-					const float3 sa = gs_act_scale(sc_raw, act);
-					const float smax = fmaxf(fmaxf(fabsf(sa.x), fabsf(sa.y)), fabsf(sa.z)) * fabsf(scale_modifier);
-					const float qn2 = (act & GSR_ACT_ROT_NORMALIZE) ? 1.0f : FMA(q_raw.x, q_raw.x, FMA(q_raw.y, q_raw.y, FMA(q_raw.z, q_raw.z, q_raw.w * q_raw.w)));
-					const float r_est = 6.0f * smax * fmaxf(qn2, 1.0f) * fmaxf(focal_x, focal_y) / p_view.z + 3.0f;
-					const float ex = 0.5f * (FMA(p_proj_x, (float)W, (float)W) - 1.0f), ey = 0.5f * (FMA(p_proj_y, (float)H, (float)H) - 1.0f);
-					prefetch = !(ex + r_est < 0.0f || ex - r_est > (float)W || ey + r_est < 0.0f || ey - r_est > (float)H);
-				}
-				if (prefetch) load_sh();
 			}
 			float cov3D[6];
 			if (cov3D_precomp != nullptr) {
@@ -268,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
 			depth = p_view.z;
 			vis = true;
 		} while (0);
-		if (vis && !prefetch && colors_precomp == nullptr) load_sh();   // the estimate was wrong (or gate 2): fetched late
+		if (vis && colors_precomp == nullptr) load_sh();
 	}
 
 	uint32_t my_tiles = 0, dead = 0;
@@ -362,7 +342,7 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 {
 	const float focal_y = a.H / (2.0f * a.tan_fovy);   // rasterizer_impl.cu:225-226
 	const float focal_x = a.W / (2.0f * a.tan_fovx);
-	const int sh_vec4 = ((a.shs != nullptr && ((uintptr_t)a.shs % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0) | ((a.sh_gate & 3) << 1);
+	const int sh_vec4 = (a.shs != nullptr && ((uintptr_t)a.shs % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0;
 	const int D = a.colors_precomp ? 0 : a.D;
 	dim3 grid((a.P + 255) / 256), block(256);
 #define GSR_LAUNCH_PRE(DEG, RAW)                                                                                   \

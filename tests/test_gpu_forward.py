@@ -437,24 +437,19 @@ def test_c4_inside_view_bit_exact_vs_oracle(oracle, view):
     _check(oracle, sc, cam, 3, kw)
 
 
-@pytest.mark.parametrize("gate", [0, 1, 2])
-def test_sh_row_request_gating_changes_no_bit(oracle, gate):
-    """Round 5: preprocess_fwd requests a Gaussian's 192-B SH row early only if the Gaussian is PROBABLY inside the image (an estimate
-    from its centre and largest axis; the reference has no x / y frustum test, auxiliary.h:147-161) and late -- after the exact path
-    found it visible -- otherwise.  gsr_set_option("sh_prefetch", 0 | 1 | 2) = estimate-gated (default) | always early (round 4) |
-    always late (every visible Gaussian takes the late path): all three bit-identical to the oracle, on a view from INSIDE a ball
-    (84 % culled, half of them in front of the camera) and on the frustum cloud, also with unnormalised quaternions and a scale
-    modifier (the estimate uses |q|^2 and the modifier) and through the raw-attribute (fused) interface."""
-    from gaustudio_amd import _C
-    with _with_options(sh_prefetch=gate):
-        assert _C.get_option("sh_prefetch") == gate
-        W, H = 640, 400
-        sc = scenes.make_ball_scene(120_000, radius=6.0, seed=1, sigma=0.02)
-        cam = scenes.ring_cameras(8, W, H, radius=2.5)[5]
-        kw = scene_kwargs(sc, True, False)
-        compare_forward_exact(hip_forward(sc, cam, 3, kw), oracle_forward(oracle, sc, cam, 3, kw))
-        sc2 = sc._replace(rotations=(sc.rotations * torch.linspace(0.3, 3.0, sc.rotations.shape[0])[:, None]).contiguous())
-        kw2 = scene_kwargs(sc2, True, False)
-        compare_forward_exact(hip_forward(sc2, cam, 2, kw2, scale_modifier=2.5), oracle_forward(oracle, sc2, cam, 2, kw2, 2.5))
-        _run(oracle, 20000, 333, 211, 3, seed=4, sigma_px=3.0)
-        _run(oracle, 20000, 333, 211, 1, seed=5, sigma_px=40.0)       # footprints far larger than the estimate's margin would suggest
+def test_inside_camera_late_sh_request_bit_exact(oracle):
+    """Round 5: preprocess_fwd requests a Gaussian's 192-B SH row only once the Gaussian has turned out visible (rounds 2-4: right
+    after the near-plane test -- a Gaussian in front of the camera but outside the image fetched it for nothing; the reference has
+    no x / y frustum test, auxiliary.h:147-161).  A view from INSIDE a ball (84 % culled, half of them in front of the camera), also
+    with unnormalised quaternions and a scale modifier, and footprints from sub-pixel to a third of the image: bit-identical to the
+    oracle."""
+    W, H = 640, 400
+    sc = scenes.make_ball_scene(120_000, radius=6.0, seed=1, sigma=0.02)
+    cam = scenes.ring_cameras(8, W, H, radius=2.5)[5]
+    kw = scene_kwargs(sc, True, False)
+    compare_forward_exact(hip_forward(sc, cam, 3, kw), oracle_forward(oracle, sc, cam, 3, kw))
+    sc2 = sc._replace(rotations=(sc.rotations * torch.linspace(0.3, 3.0, sc.rotations.shape[0])[:, None]).contiguous())
+    kw2 = scene_kwargs(sc2, True, False)
+    compare_forward_exact(hip_forward(sc2, cam, 2, kw2, scale_modifier=2.5), oracle_forward(oracle, sc2, cam, 2, kw2, 2.5))
+    _run(oracle, 20000, 333, 211, 3, seed=4, sigma_px=3.0)
+    _run(oracle, 20000, 333, 211, 1, seed=5, sigma_px=40.0)
