@@ -1114,9 +1114,20 @@ __device__ __forceinline__ void gs_partition_segment(const uint64_t* __restrict_
 	__syncthreads();
 }
 
-__global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __restrict__ ranges,
+// held to 4 waves per SIMD (128 VGPRs, no spill; left alone the compiler takes 151 -> 3 waves): with the two length classes below
+// C4's sort 0.1937 -> 0.1648 ms (profiles/r05_radix_sort_experiments.txt; 5 / 6 waves: 72-76 B of scratch, 0.173 / 0.1645)
+#ifndef GSR_RADIX_WAVES
+#define GSR_RADIX_WAVES 4
+#endif
+#define GSR_RADIX_ATTR __attribute__((amdgpu_waves_per_eu(GSR_RADIX_WAVES, GSR_RADIX_WAVES)))
+// RK: keys a thread holds in registers (lists of up to 256 RK keys are cut without re-reading them).  Round 5: two instantiations,
+// launched one after the other, each taking the lists of ITS length class (lo < n <= hi) -- 16 for lists up to 4096 keys (the C4 regime:
+// every tile ~3.4 k), 32 beyond.  With 32 for everything the kernel needed 76 VGPRs (6 waves per SIMD); a list's cut is one long
+// dependent chain (load -> min / max -> histogram -> scan -> scatter -> bucket sorts), so the workgroups a CU can hold set the pace.
+template <int RK>
+__global__ __launch_bounds__(256) GSR_RADIX_ATTR void tile_radix_sort_kernel(const uint2* __restrict__ ranges,
                                                               uint64_t* __restrict__ keys, uint64_t* __restrict__ keys2,
-                                                              uint32_t* __restrict__ point_list, uint32_t lo,
+                                                              uint32_t* __restrict__ point_list, uint32_t lo, uint32_t hi,
                                                               GsSortQ* __restrict__ q, uint2* __restrict__ seg_items, uint32_t seg_cap,
                                                               const GsCtl* __restrict__ ctl, uint32_t cap)
 {
@@ -1126,7 +1137,7 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 	if (ctl->num_binned > cap || ctl->max_tile_count <= lo) return;   // see bin_scatter_kernel; no long list at all
 	const uint2 range = ranges[blockIdx.x];
 	const uint32_t n = range.y - range.x;
-	if (n <= lo) return;
+	if (n <= lo || n > hi) return;
 	if (q != nullptr && (n > GSR_PART_REGS || ctl->n_long < GSR_SORT_MANY)) return;   // the queue pipeline's (tile_sort_kernel entered it)
 	if (q == nullptr && ctl->max_tile_count > GSR_SORT_GIANT) return;   // launched for the wrong regime: the host re-launches with the pipeline
 	const int tid = threadIdx.x, wv = tid >> 6;
@@ -1146,7 +1157,6 @@ __global__ __launch_bounds__(256) void tile_radix_sort_kernel(const uint2* __res
 		__syncthreads();
 		// lists of up to 256 * RK keys are held in registers (RK independent loads per thread in flight at once): the
 		// three sweeps below -- min/max, histogram, scatter -- then cost no further memory round trips
-		constexpr int RK = 32;
 		const bool in_regs = n <= 256u * RK;
 		uint64_t kreg[RK];
 		if (in_regs) {
@@ -1647,6 +1657,9 @@ struct SortQueueLayout {
 };
 size_t sort_queue_bytes(size_t R, int T) { return SortQueueLayout(R, T).total; }
 
+#ifndef GSR_RADIX_RK_SHORT
+#define GSR_RADIX_RK_SHORT 16   // the per-list kernel's register-resident key count for the shorter class of long lists (x 256 keys)
+#endif
 void launch_tile_sort(int T, bool with_short, int long_level, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
                       uint32_t* point_list, char* queue, size_t R, const GsCtl* ctl, uint32_t cap, hipStream_t s)
 {
@@ -1660,9 +1673,12 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 		if (with_short)
 			hipLaunchKernelGGL(tile_sort_kernel, dim3((T + 3) / 4), dim3(256), 0, s, T, ranges, keys, point_list, ctl, cap, (GsSortQ*)nullptr,
 			                   (uint4*)nullptr, 0u, (uint64_t*)nullptr);
-		if (long_level == 1)
-			hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, GSR_SORT_LDS_MAX, (GsSortQ*)nullptr,
-			                   (uint2*)nullptr, 0u, ctl, cap);
+		if (long_level == 1) {
+			hipLaunchKernelGGL(tile_radix_sort_kernel<GSR_RADIX_RK_SHORT>, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, GSR_SORT_LDS_MAX,
+			                   256u * GSR_RADIX_RK_SHORT, (GsSortQ*)nullptr, (uint2*)nullptr, 0u, ctl, cap);
+			hipLaunchKernelGGL(tile_radix_sort_kernel<32>, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, 256u * GSR_RADIX_RK_SHORT,
+			                   0xffffffffu, (GsSortQ*)nullptr, (uint2*)nullptr, 0u, ctl, cap);
+		}
 		return;
 	}
 	const SortQueueLayout ql(R, T);
@@ -1680,7 +1696,10 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 	// per-list kernel (throughput: 0.19 ms for C4's 4346 lists against 0.34 ms through the queues); a cut of it that overflows
 	// (depths piled up) becomes a segment of the pipeline.  With few long lists (clustered scene: 341) that kernel would be a
 	// latency -- its longest list, alone on a CU, 42 us -- in front of a pipeline that takes them in its stride: it leaves at once.
-	hipLaunchKernelGGL(tile_radix_sort_kernel, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, GSR_SORT_LDS_MAX, q, seg_items, seg_cap, ctl, cap);
+	hipLaunchKernelGGL(tile_radix_sort_kernel<GSR_RADIX_RK_SHORT>, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, GSR_SORT_LDS_MAX,
+	                   256u * GSR_RADIX_RK_SHORT, q, seg_items, seg_cap, ctl, cap);
+	hipLaunchKernelGGL(tile_radix_sort_kernel<32>, dim3(T), dim3(256), 0, s, ranges, keys, keys2, point_list, 256u * GSR_RADIX_RK_SHORT, 0xffffffffu, q,
+	                   seg_items, seg_cap, ctl, cap);
 	hipLaunchKernelGGL(slice_hist_kernel, dim3(512), dim3(GSR_PART_THREADS), 0, s, keys, keys2, point_list, q, slice_items, slice_cap, rows, ctl, cap);
 	hipLaunchKernelGGL(slice_scatter_kernel, dim3(512), dim3(GSR_PART_THREADS), 0, s, keys, keys2, point_list, q, slice_items, slice_cap, rows,
 	                   sort_items, sort_cap, seg_items, seg_cap, ctl, cap);
