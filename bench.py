@@ -105,7 +105,7 @@ def cpu_baseline(sc, cam, D, grads, budget_s=30.0):
             "sample": f"CPU restatement of the reference kernels (oracle/gsr_oracle.c, OpenMP x{threads}): fwd+bwd on {what}"}
 
 
-def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
+def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only, R_staged=None):
     """Achieved algorithmic GB/s of every stage against the 8 TB/s HBM roofline (BASELINE.md s4 byte counts; the
     records are 64 B here instead of the reference's 48 B of SoA fields, counted as written).  R = instances binned."""
     sh = 12 * (D + 1) ** 2
@@ -113,9 +113,11 @@ def stage_roofline(P, P_vis, R, T, H, W, D, fwd_ms, bwd_ms, fwd_only):
     HW = H * W
     stages = {}
     if fwd_ms:
-        b = {"preprocess": P * (12 + 12 + 16 + 4 + sh) + P_vis * (64 + 4 + 4 + (0 if fwd_only else jac)),
+        Rs = R if R_staged is None else R_staged       # composite_fwd: the instances it actually staged (gsr_inspect_staged)
+        # preprocess: the geometry inputs of every Gaussian, the SH row of the VISIBLE ones only (requested late since round 5)
+        b = {"preprocess": P * (12 + 12 + 16 + 4) + P_vis * sh + P_vis * (64 + 4 + 4 + (0 if fwd_only else jac)),
              "scatter": R * 8 + P_vis * 64, "sort": R * 12,
-             "composite": R * 44 + T * 8 + HW * 32 + (0 if fwd_only else HW * 8)}
+             "composite": Rs * 44 + T * 8 + HW * 32 + (0 if fwd_only else HW * 8)}
         for k, nbytes in b.items():
             if fwd_ms.get(k):
                 gbs = nbytes / (fwd_ms[k] * 1e-3) / 1e9
@@ -851,7 +853,7 @@ def main():
                                "bit-exact (reproducible exp: every output bit-identical to the CPU oracle; --exact / GSR_FAST_EXP=0)",
                        "parallelism": par},
             "stage_ms": {"forward": fwd_ms, "backward": bwd_ms},
-            "stage_roofline": stage_roofline(P, vis, R, T, H, W, D, fwd_ms, bwd_ms, a.fwd_only),
+            "stage_roofline": stage_roofline(P, vis, R, T, H, W, D, fwd_ms, bwd_ms, a.fwd_only, R_staged),
             "roofline": roof,
         }
         line.update(extras)
