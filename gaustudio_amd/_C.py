@@ -172,6 +172,24 @@ def unpack_rows(hdr, src, src_stride, col0, dst):
                                  ctypes.c_int(int(col0)), _ptr(dst), _stream(dst.device)))
 
 
+def pack_geometry(hdr, g_means3D, g_opacity, g_scales, g_rotations, rows, flag):
+    """rows[r, 0:11] = [means3D 3 | opacity 1 | scales 3 | rotations 4] gradients of the r-th Gaussian of the header; flag (int32[1],
+    cleared by the caller) |= 1 when a Gaussian outside the header has a non-zero value."""
+    L = lib()
+    P = g_means3D.shape[0]
+    with torch.cuda.device(rows.device):
+        _rc(L, L.gsr_pack_geometry(ctypes.c_int(P), _ptr(hdr), _ptr(g_means3D), _ptr(g_opacity), _ptr(g_scales), _ptr(g_rotations),
+                                   _ptr(rows), _ptr(flag), _stream(rows.device)))
+
+
+def unpack_geometry(hdr, rows, g_means3D, g_opacity, g_scales, g_rotations):
+    L = lib()
+    P = g_means3D.shape[0]
+    with torch.cuda.device(rows.device):
+        _rc(L, L.gsr_unpack_geometry(ctypes.c_int(P), _ptr(hdr), _ptr(rows), _ptr(g_means3D), _ptr(g_opacity), _ptr(g_scales),
+                                     _ptr(g_rotations), _stream(rows.device)))
+
+
 def sh_grad_from_packed(means3D, campos, msgs, offsets, degree, out):
     """sh_grad_from_colors reading N = offsets.numel() packed messages (header + rows of 3 floats, message r at word offsets[r] of the
     int32 tensor msgs) instead of dense colours."""

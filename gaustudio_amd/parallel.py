@@ -239,6 +239,16 @@ class _HipPacked:
         _C.unpack_rows(hdr, src, src_stride, col0, dst)
 
     @staticmethod
+    def pack_geometry(hdr, views, rows, flag):
+        from . import _C
+        _C.pack_geometry(hdr, views["means3D"], views["opacities"], views["scales"], views["rotations"], rows, flag)
+
+    @staticmethod
+    def unpack_geometry(hdr, rows, views):
+        from . import _C
+        _C.unpack_geometry(hdr, rows, views["means3D"], views["opacities"], views["scales"], views["rotations"])
+
+    @staticmethod
     def sh_from_packed(means3D, campos, msgs, offsets, D, out):
         from . import _C
         _C.sh_grad_from_packed(means3D, campos, msgs, offsets, D, out)
@@ -337,6 +347,8 @@ class FactoredGradExchange:
         else:
             self.colors = torch.zeros((self.V, self.world, self.P, 3), dtype=torch.float32, device=dev)     # view-major
         self.sh_grad = torch.empty((self.P, self.M, 3), dtype=torch.float32, device=dev)
+        self._geo_rows = None     # compact="view+geometry": persistent [P, 11] buffer of packed geometry rows (allocated on first use)
+        self._kf = None
         self.stats = {"steps": 0, "rows_exchanged": 0, "early_allgathers": 0, "color_rows_sent": 0, "geometry_rows": 0}
         self._count_works = {}    # local view -> work handle of the all-gather of its visible count
         self._seen = set()        # local views whose radii arrived (visible())
@@ -594,35 +606,30 @@ def _exchange_by_view_impl(self, campos_all, D, views, multi):
         # outside the union raise a flag, the ranks agree on it (4-byte MAX all-reduce, read back together with the row count: no
         # extra host synchronisation), and a flagged step sums the whole dense block instead (`geometry_fallbacks` in payload()).
         self._pk.union_index(P, msgs, offsets, self.hdr_union, self._scratch)
-        live = torch.zeros(P, dtype=torch.bool, device=dev)
-        for r in GEOMETRY_ROLES:
-            live |= (views[r].reshape(P, -1) != 0).any(dim=1)
-        kf = torch.stack([self.hdr_union[0], (live & ~_header_mask(self.hdr_union, P)).any().to(torch.int32)])
+        # ONE pass packs the four tensors' rows of the union into the persistent [P, 11] buffer (sized for the worst case: the host
+        # does not know K yet) and raises the flag for a non-zero row outside the union; then ONE host synchronisation reads K and
+        # the agreed flag together
+        if self._geo_rows is None:
+            self._geo_rows = torch.empty((P, 11), dtype=torch.float32, device=dev)
+            self._kf = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._kf.zero_()
+        self._pk.pack_geometry(self.hdr_union, views, self._geo_rows, self._kf[1:2])
+        self._kf[0:1].copy_(self.hdr_union[0:1])
         if multi:
-            dist.all_reduce(kf[1:2], op=dist.ReduceOp.MAX, group=self.group)
-        K, outside = (int(x) for x in kf.tolist())      # host synchronisation: the all-reduce below is sized by it
+            dist.all_reduce(self._kf[1:2], op=dist.ReduceOp.MAX, group=self.group)
+        K, outside = (int(x) for x in self._kf.tolist())      # host synchronisation: the all-reduce below is sized by it
         if outside:
             self.stats["geometry_fallbacks"] = self.stats.get("geometry_fallbacks", 0) + 1
             self.stats["geometry_rows"] += P
             if multi:
                 dist.all_reduce(self.geo, op=dist.ReduceOp.SUM, group=self.group)
-            K = 0
         else:
             self.stats["geometry_rows"] += K
-        if K > 0:
-            rows = torch.empty((K, 11), dtype=torch.float32, device=dev)
-            col = 0
-            for r in GEOMETRY_ROLES:
-                n = views[r].reshape(P, -1).shape[1]
-                self._pk.pack_rows(self.hdr_union, views[r].reshape(P, -1), rows.view(-1), 11, col)
-                col += n
-            if multi:
-                dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
-            col = 0
-            for r in GEOMETRY_ROLES:
-                n = views[r].reshape(P, -1).shape[1]
-                self._pk.unpack_rows(self.hdr_union, rows.view(-1), 11, col, views[r].reshape(P, -1))
-                col += n
+            if K > 0:
+                rows = self._geo_rows[:K]
+                if multi:
+                    dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=self.group)
+                self._pk.unpack_geometry(self.hdr_union, rows, views)
     if w2 is not None:
         w2.wait()
     for r in GEOMETRY_ROLES:
@@ -634,15 +641,6 @@ def _exchange_by_view_impl(self, campos_all, D, views, multi):
 
 
 FactoredGradExchange._exchange_by_view = _exchange_by_view_impl
-
-
-def _header_mask(hdr: torch.Tensor, P: int):
-    """bool[P] from the bit mask of a visibility header (include/gsrast.h: 4 words, (P + 255) / 256 block bases, (P + 31) / 32
-    mask words, bit i of word w = Gaussian 32 w + i)."""
-    nb, nw = (P + 255) // 256, (P + 31) // 32
-    words = hdr[4 + nb:4 + nb + nw].to(torch.int64) & 0xFFFFFFFF
-    bits = (words[:, None] >> torch.arange(32, device=hdr.device, dtype=torch.int64)[None, :]) & 1
-    return bits.reshape(-1)[:P].bool()
 
 
 def _all_gather_in_place(buf: torch.Tensor, rank: int, V: int, group):

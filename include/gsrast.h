@@ -205,6 +205,15 @@ int gsr_union_index(int P, int N, const uint32_t* msgs, const unsigned long long
                     void* stream);
 int gsr_pack_rows(int P, int C, const uint32_t* hdr, const float* in, float* out, int out_stride, int col0, void* stream);
 int gsr_unpack_rows(int P, int C, const uint32_t* hdr, const float* in, int in_stride, int col0, float* out, void* stream);
+/* The geometry block of the exchange ([means3D 3 | opacity 1 | scales 3 | rotations 4] = 11 floats per Gaussian, four tensors) in one
+ * pass each way: gsr_pack_geometry writes rows[r * 11 ..] = the 11 floats of the r-th Gaussian of `hdr` (rows must hold hdr[0] rows)
+ * and ORs 1 into *flag_outside (device word, cleared by the caller) when a Gaussian OUTSIDE the header has a non-zero value -- a
+ * gradient the rasterizer cannot have produced (it writes zeros for culled Gaussians): the caller must then exchange the dense
+ * block; gsr_unpack_geometry copies the rows back (other Gaussians untouched). */
+int gsr_pack_geometry(int P, const uint32_t* hdr, const float* g_means3D, const float* g_opacity, const float* g_scales,
+                      const float* g_rotations, float* rows, uint32_t* flag_outside, void* stream);
+int gsr_unpack_geometry(int P, const uint32_t* hdr, const float* rows, float* g_means3D, float* g_opacity, float* g_scales,
+                        float* g_rotations, void* stream);
 int gsr_sh_grad_from_packed(int P, int D, int M, int N, const float* means3D, const float* campos, const uint32_t* msgs,
                             const unsigned long long* msg_offsets, float* dL_dsh, void* stream);
 

@@ -76,6 +76,29 @@ class TorchPacked:
         dst.reshape(P, C)[vis] = src[:K * src_stride].view(K, src_stride)[:, col0:col0 + C]
 
     @classmethod
+    def pack_geometry(cls, hdr, views, rows, flag):
+        """csrc/gsr_comm.hip pack_geometry_kernel: rows[r] = [means3D 3 | opacity 1 | scales 3 | rotations 4] of the r-th Gaussian of the
+        header; flag |= 1 when a Gaussian outside the header has a non-zero value."""
+        P = views["means3D"].shape[0]
+        vis = cls._mask(hdr, P)
+        allv = torch.cat([views[r].reshape(P, -1) for r in ("means3D", "opacities", "scales", "rotations")], dim=1)
+        K = int(vis.sum())
+        rows[:K] = allv[vis]
+        if bool((allv[~vis] != 0).any()):
+            flag |= 1
+
+    @classmethod
+    def unpack_geometry(cls, hdr, rows, views):
+        P = views["means3D"].shape[0]
+        vis = cls._mask(hdr, P)
+        K = int(vis.sum())
+        col = 0
+        for r in ("means3D", "opacities", "scales", "rotations"):
+            v = views[r].reshape(P, -1)
+            v[vis] = rows[:K, col:col + v.shape[1]]
+            col += v.shape[1]
+
+    @classmethod
     def sh_from_packed(cls, means3D, campos, msgs, offsets, D, out):
         P = means3D.shape[0]
         Hw = cls.header_words(P)

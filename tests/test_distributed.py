@@ -667,6 +667,25 @@ def test_packed_messages_hip_vs_torch(P):
         rows = torch.zeros((K, 11), device=dev)
         _C.pack_rows(hu, geo, rows.view(-1), 11, 7)
         assert torch.equal(rows[:, 7:11], geo[T._mask(hu, P)]) and float(rows[:, :7].abs().sum()) == 0.0
+    # the geometry block in one pass each way (round 5): HIP == torch restatement, flag only for non-zero rows OUTSIDE the header
+    gv = dict(means3D=torch.randn(P, 3, generator=g).to(dev), opacities=torch.randn(P, 1, generator=g).to(dev),
+              scales=torch.randn(P, 3, generator=g).to(dev), rotations=torch.randn(P, 4, generator=g).to(dev))
+    um = T._mask(hu, P)
+    for k in gv:
+        gv[k] = (gv[k] * um[:, None]).contiguous()                      # rasterizer-like: zero rows outside the union
+    rows_h, rows_t = torch.full((P, 11), 7.0, device=dev), torch.full((P, 11), 7.0, device=dev)
+    fl_h, fl_t = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    _C.pack_geometry(hu, gv["means3D"], gv["opacities"], gv["scales"], gv["rotations"], rows_h, fl_h)
+    T.pack_geometry(hu, gv, rows_t, fl_t)
+    assert torch.equal(rows_h, rows_t) and int(fl_h) == 0 == int(fl_t)
+    back = {k: torch.full_like(v, 3.0) for k, v in gv.items()}
+    _C.unpack_geometry(hu, rows_h, back["means3D"], back["opacities"], back["scales"], back["rotations"])
+    for k in gv:
+        assert torch.equal(back[k][um], gv[k][um]) and bool((back[k][~um] == 3.0).all()), k
+    if int((~um).sum()) > 0:                                            # a regulariser's gradient on a Gaussian no view sees
+        gv["scales"][int(torch.nonzero(~um)[0]), 2] = 0.5
+        _C.pack_geometry(hu, gv["means3D"], gv["opacities"], gv["scales"], gv["rotations"], rows_h, fl_h)
+        assert int(fl_h) == 1
     # rebuild: packed == dense, bit for bit, at every degree
     means = torch.randn(P, 3, generator=g).to(dev)
     campos = (torch.randn(N, 3, generator=g) * 4 + 15).to(dev)
