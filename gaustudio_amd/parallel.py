@@ -349,6 +349,7 @@ class FactoredGradExchange:
         self.sh_grad = torch.empty((self.P, self.M, 3), dtype=torch.float32, device=dev)
         self._geo_rows = None     # compact="view+geometry": persistent [P, 11] buffer of packed geometry rows (allocated on first use)
         self._kf = None
+        self._kf_host = None
         self.stats = {"steps": 0, "rows_exchanged": 0, "early_allgathers": 0, "color_rows_sent": 0, "geometry_rows": 0}
         self._count_works = {}    # local view -> work handle of the all-gather of its visible count
         self._seen = set()        # local views whose radii arrived (visible())
@@ -598,26 +599,36 @@ def _exchange_by_view_impl(self, campos_all, D, views, multi):
     offsets = self._off_dev
     msgs = self.msgs.view(-1)
     campos = campos_all.detach().to(dev, torch.float32)[self._order].contiguous()
-    self._pk.sh_from_packed(self.p["means3D"].detach(), campos, msgs, offsets, D, self.sh_grad)
+    kf_ev = None
     if self.union_geometry:
         # rows with a non-zero RASTERIZER geometry gradient anywhere in the step = the OR of the gathered masks (identical on
         # every rank).  PRECONDITION of summing only those rows: no other loss term put a gradient on a row outside the union
-        # (a scale / opacity regulariser does: ADVICE r4) -- checked here: rows of this rank's geometry block that are non-zero
-        # outside the union raise a flag, the ranks agree on it (4-byte MAX all-reduce, read back together with the row count: no
-        # extra host synchronisation), and a flagged step sums the whole dense block instead (`geometry_fallbacks` in payload()).
-        self._pk.union_index(P, msgs, offsets, self.hdr_union, self._scratch)
+        # (a scale / opacity regulariser does: ADVICE r4) -- checked: rows of this rank's geometry block that are non-zero outside the
+        # union raise a flag, the ranks agree on it (4-byte MAX all-reduce), and a flagged step sums the whole dense block instead
+        # (`geometry_fallbacks` in payload()).
         # ONE pass packs the four tensors' rows of the union into the persistent [P, 11] buffer (sized for the worst case: the host
-        # does not know K yet) and raises the flag for a non-zero row outside the union; then ONE host synchronisation reads K and
-        # the agreed flag together
+        # does not know K yet) and raises the flag; K and the agreed flag travel to pinned host memory behind an EVENT, and all of
+        # this is enqueued IN FRONT of the SH-gradient rebuild below: the host then waits for that event only -- while the device
+        # still rebuilds -- instead of draining the stream (round 5: a full synchronisation here cost ~0.6 ms of idle device per step)
+        self._pk.union_index(P, msgs, offsets, self.hdr_union, self._scratch)
         if self._geo_rows is None:
             self._geo_rows = torch.empty((P, 11), dtype=torch.float32, device=dev)
             self._kf = torch.zeros(2, dtype=torch.int32, device=dev)
+            self._kf_host = torch.zeros(2, dtype=torch.int32, pin_memory=self._cuda)
         self._kf.zero_()
         self._pk.pack_geometry(self.hdr_union, views, self._geo_rows, self._kf[1:2])
         self._kf[0:1].copy_(self.hdr_union[0:1])
         if multi:
             dist.all_reduce(self._kf[1:2], op=dist.ReduceOp.MAX, group=self.group)
-        K, outside = (int(x) for x in self._kf.tolist())      # host synchronisation: the all-reduce below is sized by it
+        self._kf_host.copy_(self._kf, non_blocking=True)
+        if self._cuda:
+            kf_ev = torch.cuda.Event()
+            kf_ev.record()
+    self._pk.sh_from_packed(self.p["means3D"].detach(), campos, msgs, offsets, D, self.sh_grad)
+    if self.union_geometry:
+        if kf_ev is not None:
+            kf_ev.synchronize()                               # the 8-byte copy only; the rebuild kernel is still running
+        K, outside = (int(x) for x in self._kf_host.tolist())
         if outside:
             self.stats["geometry_fallbacks"] = self.stats.get("geometry_fallbacks", 0) + 1
             self.stats["geometry_rows"] += P
