@@ -26,7 +26,7 @@ Collectives on one communicator run one after the other.
                                                                               inside the backward
   step_N(factored)       = pg1 + max(0, allgather(12 B x P) - tail) + max(0, allreduce(44 B x P) - rebuild)
   step_N(view)           = pg1 + max(0, allgather(hdr + 12 B x vis_view P) - tail) + max(0, allreduce(44 B x P) - rebuild)
-  step_N(view+geometry)  = as view with allreduce(44 B x vis_union P) + one host synchronisation (30 us)
+  step_N(view+geometry)  = its own pg1 + the view gather + max(0, allreduce(44 B x vis_union P) - rebuild)
   speed-up               = N t1 / step_N          (what a driver computes from `value` at N and at 1; one view per GPU)
 
     python tools/comm_model.py                      # the table of DESIGN.md s7
@@ -48,20 +48,21 @@ def allgather_ms(S_rank, N, B):
 # scenario -> measured single-GPU inputs (ms), each with the bench line it was read from (profiles/r05_bench_lines/)
 SCENARIOS = {
     "C3 (1 M, 1920x1080, frustum cloud: 0.85 visible per view)": dict(
-        P=1_000_000, t1=0.9912, t1_src="s3_bench_C3_gate0.json", vis_view=0.8535, vis_union=0.87,
-        preprocess_bwd=0.1162,
-        pg1=dict(dense=(1.1453, 0.0527, "s3_pg1_C3_dense_none.json"), factored=(1.0620, 0.0755, "s3_pg1_C3_factored_none.json"),
-                 view=(1.1252, 0.0676, "s3_pg1_C3_factored_view.json"))),
+        P=1_000_000, t1=0.9778, t1_src="final_bench_c3.json", vis_view=0.8535, vis_union=0.87,
+        preprocess_bwd=0.1101,
+        pg1=dict(dense=(1.1453, 0.0527, "s3_pg1_C3_dense_none.json"), factored=(1.0555, 0.0741, "s5_pg1_C3_factored_none.json"),
+                 view=(1.1207, 0.0675, "s5_pg1_C3_factored_view.json"), view_geometry=(1.2642, 0.0675, "s5_pg1_C3_factored_view+geometry.json"))),
     "C4 share, ALL 5 M in the frustum (0.87 visible per view)": dict(
-        P=5_000_000, t1=1.8974, t1_src="s3_bench_C4_gate0.json", vis_view=0.8737, vis_union=0.90,
-        preprocess_bwd=0.5400,
-        pg1=dict(dense=(2.0436, 0.0514, "s3_pg1_C4_dense_none.json"), factored=(1.9843, 0.2185, "s3_pg1_C4_factored_none.json"),
-                 view=(2.1745, 0.2689, "s3_pg1_C4_factored_view.json"))),
+        P=5_000_000, t1=1.8093, t1_src="final_bench_C4.json", vis_view=0.8737, vis_union=0.90,
+        preprocess_bwd=0.4954,
+        pg1=dict(dense=(2.0436, 0.0514, "s3_pg1_C4_dense_none.json"), factored=(1.9192, 0.2228, "s5_pg1_C4_factored_none.json"),
+                 view=(2.0950, 0.2702, "s5_pg1_C4_factored_view.json"), view_geometry=(2.3994, 0.2702, "s5_pg1_C4_factored_view+geometry.json"))),
     "C4-inside (5 M ball, cameras INSIDE the scene: 0.158 visible per view)": dict(
-        P=5_000_000, t1=1.1542, t1_src="s3_bench_C4-inside_gate0.json", vis_view=0.1576, vis_union=0.54,
-        preprocess_bwd=0.5066,
-        pg1=dict(dense=(1.3001, 0.0524, "s3_pg1_C4-inside_dense_none.json"), factored=(1.2475, 0.2173, "s3_pg1_C4-inside_factored_none.json"),
-                 view=(1.3940, 0.2392, "s3_pg1_C4-inside_factored_view.json"))),
+        P=5_000_000, t1=1.1303, t1_src="final_bench_C4-inside.json", vis_view=0.1576, vis_union=0.54,
+        preprocess_bwd=0.4843,
+        pg1=dict(dense=(1.3001, 0.0524, "s3_pg1_C4-inside_dense_none.json"), factored=(1.2314, 0.2231, "s5_pg1_C4-inside_factored_none.json"),
+                 view=(1.3644, 0.2378, "s5_pg1_C4-inside_factored_view.json"),
+                 view_geometry=(1.5452, 0.2378, "s5_pg1_C4-inside_factored_view+geometry.json"))),
 }
 
 
@@ -84,8 +85,12 @@ def model(sc, N, B):
     msg = hdr + P * 12 * sc["vis_view"]
     put("view", 2.0 * (N - 1) / N * P * 44 + (N - 1) * msg,
         pg + max(0.0, allgather_ms(msg, N, B) - tail) + max(0.0, allreduce_ms(P * 44, N, B) - rebuild))
+    # view+geometry: its own world-1 step (union header, one-pass pack / unpack of the geometry rows, the event-synchronised read-back of
+    # the row count: all inside pg1); the union all-reduce is enqueued in front of the SH rebuild and runs beside it (`rebuild` = the
+    # view path's)
+    pg, rebuild, _ = sc["pg1"]["view_geometry"]
     put("view+geometry", 2.0 * (N - 1) / N * P * 44 * sc["vis_union"] + (N - 1) * msg,
-        pg + max(0.0, allgather_ms(msg, N, B) - tail) + SYNC_MS + max(0.0, allreduce_ms(P * 44 * sc["vis_union"], N, B) - rebuild))
+        pg + max(0.0, allgather_ms(msg, N, B) - tail) + max(0.0, allreduce_ms(P * 44 * sc["vis_union"], N, B) - rebuild))
     return out
 
 
@@ -110,11 +115,10 @@ def main():
                 print(f"  N = {N}, B = {B:.0f} GB/s: " + "   ".join(f"{k} {m[k][2]:4.2f}x ({m[k][1]:.2f} ms, {m[k][0]:.0f} MB)" for k in names))
         print()
     print("Reading: at C3 the factored exchange leaves ~0.4-0.5 ms exposed behind a 1.06-ms rank step (5.3-5.7x at 8 GPUs; the dense single")
-    print("all-reduce 3.4-3.7x); at 5 M Gaussians the 44 B per Gaussian of the geometry all-reduce alone (220 MB: 1.0-1.2 ms on the wire) is as")
-    print("long as a whole C4-inside step, and only its restriction to the union of the step's views (view+geometry: 0.54 of the rows)")
-    print("keeps 8 GPUs at 5.0-5.3x there; with every Gaussian in every frustum (the synthetic C4 share) nothing can be left out: 3.8-4.3x.")
-    print("north_star's >= 6x is NOT reached on paper with one view per GPU and replicated parameters.")
-
+    print("all-reduce 3.3-3.6x); at 5 M Gaussians the 44 B per Gaussian of the geometry all-reduce alone (220 MB: 1.0-1.2 ms on the wire) is as")
+    print("long as a whole C4-inside step: there its restriction to the union of the step's views (view+geometry: 0.54 of the rows, +0.18 ms of")
+    print("machinery per step at world 1) is the best form, 4.5-4.9x; with every Gaussian in every frustum (the synthetic C4 share) nothing can")
+    print("be left out: 3.7-4.2x.  north_star's >= 6x is NOT reached on paper with one view per GPU and replicated parameters.")
 
 if __name__ == "__main__":
     main()
