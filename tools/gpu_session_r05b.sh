@@ -1,4 +1,5 @@
 #!/bin/bash
+# (one-off of round 5; GSR_SH_PREFETCH was the A/B switch of the estimate-gated SH request, since replaced by the late-only request and removed)
 # Round-5 session b: the SH-request gating A/B and the world-1 (FORCE_PG) lines of the N > 1 code path that feed tools/comm_model.py.
 name="${1:-r05b}"; out="gpurun_out/$name"; mkdir -p "$out"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
