@@ -147,6 +147,7 @@ std::atomic<int> g_opt_fwd_variant{env_int("GSR_FWD_VARIANT", 0)}; // 0: per-qua
 std::atomic<int> g_opt_bwd_variant{env_int("GSR_BWD_VARIANT", -1)};   // -1: from gsr_selftest; bit 0: select on T
 std::atomic<int> g_opt_speculative{env_int("GSR_SPECULATIVE", 1)}; // launch binning + compositing before R is known
 std::atomic<int> g_opt_tile_order{env_int("GSR_TILE_ORDER", 1)};   // backward of a skewed frame: tiles longest walk first (0: always XCD-banded)
+std::atomic<int> g_opt_bininfo{env_int("GSR_BININFO", 1)};         // binning passes read the 16-B binning record instead of the 64-B one (A/B; no result bit)
 std::atomic<int> g_opt_band_lo{0}, g_opt_band_hi{0};               // tile rows [lo, hi) this process renders (hi <= 0: all)
 // exp on the transcendental unit (v_exp_f32) in both compositing kernels.  DEFAULT ON since round 4: pinned directly against the
 // reference's kernels and the CPU oracle (tests/test_gpu_ref.py, tests/test_gpu_fastexp_oracle.py), it differs from the
@@ -569,12 +570,13 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	uint32_t* bsums = reinterpret_cast<uint32_t*>(geom + gl.bsums);
 	uint32_t* refsums = reinterpret_cast<uint32_t*>(geom + gl.refsums);
 	uint32_t* Hm = reinterpret_cast<uint32_t*>(img + hm_off);
-	launch_preprocess_fwd(a, cam, il, radii, recs, ro.forward_only ? nullptr : reinterpret_cast<float*>(geom + gl.shjac), tiles_touched, bsums, refsums,
+	uint4* binfo = (lds_bin && g_opt_bininfo.load() != 0) ? reinterpret_cast<uint4*>(geom + gl.binfo) : nullptr;
+	launch_preprocess_fwd(a, cam, il, radii, recs, ro.forward_only ? nullptr : reinterpret_cast<float*>(geom + gl.shjac), binfo, tiles_touched, bsums, refsums,
 	                      lds_bin ? nullptr : tile_count, ctl, s);
 	STAGE_CHECK("preprocess_fwd", debug, s);
 	tm.mark();
 	if (lds_bin) {
-		launch_bin_hist(P, il.gx, il.T, tiles_touched, recs, Hm, tile_count, s);
+		launch_bin_hist(P, il.gx, il.T, tiles_touched, recs, binfo, Hm, tile_count, s);
 		STAGE_CHECK("bin_hist", debug, s);
 	}
 	GsCtl* host = pinned_ctl();
@@ -610,7 +612,7 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 		uint32_t* point_list = reinterpret_cast<uint32_t*>(bin + bl.point_list);
 		if (cap > 0) {
 			if (lds_bin) {
-				launch_bin_scatter2(P, il.gx, il.T, tiles_touched, recs, Hm, ranges, keys, bsums, goff, ctl, cap, s);
+				launch_bin_scatter2(P, il.gx, il.T, tiles_touched, recs, binfo, Hm, ranges, keys, bsums, goff, ctl, cap, s);
 				goff_done = true;
 			}
 			else
@@ -1004,6 +1006,7 @@ int gsr_set_option(const char* name, int value)
 	else if (n == "speculative") g_opt_speculative.store(value);
 	else if (n == "fast_exp") g_opt_fast_exp.store(value != 0);
 	else if (n == "tile_order") g_opt_tile_order.store(value != 0);
+	else if (n == "bininfo") g_opt_bininfo.store(value != 0);
 	else if (n == "roctx") g_opt_roctx.store(value != 0);
 	else if (n == "tile_row_lo") g_opt_band_lo.store(value > 0 ? value : 0);
 	else if (n == "tile_row_hi") g_opt_band_hi.store(value);
@@ -1026,6 +1029,7 @@ int gsr_get_option(const char* name)
 	if (n == "speculative") return g_opt_speculative.load();
 	if (n == "fast_exp") return g_opt_fast_exp.load();
 	if (n == "tile_order") return g_opt_tile_order.load();
+	if (n == "bininfo") return g_opt_bininfo.load();
 	if (n == "roctx") return g_opt_roctx.load() != 0 && roctx().push != nullptr;
 	if (n == "tile_row_lo") return g_opt_band_lo.load();
 	if (n == "tile_row_hi") return g_opt_band_hi.load();

@@ -16,7 +16,7 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // goff_apply finishes the scan inside each block -- no separate multi-kernel scan.
 #define GSR_PRE_BLOCK 256
 struct GeomLayout {
-	size_t cam, recs, tiles_touched, goff, bsums, refsums, shjac, total;
+	size_t cam, recs, tiles_touched, goff, bsums, refsums, shjac, binfo, total;
 	size_t nblk;
 	explicit GeomLayout(size_t P)
 	{
@@ -30,7 +30,10 @@ struct GeomLayout {
 		// d(rgb) / d(view direction) of every visible Gaussian's SH colour, 9 floats: left by preprocess_fwd for the SH
 		// backward (gs_sh_dir_jacobian), which then does not read the 192-B coefficient rows again
 		shjac = refsums + align_up(sizeof(uint32_t) * (nblk + 1));
-		total = shjac + align_up(sizeof(float) * 9 * P);
+		// 16-B binning record {rect min, rect max, clamp | dead corners, depth bits}: what the two binning passes need of a Gaussian,
+		// two per 32-B sector instead of two sectors of the 64-B record (round 5)
+		binfo = shjac + align_up(sizeof(float) * 9 * P);
+		total = binfo + align_up(sizeof(uint4) * P);
 	}
 };
 
@@ -102,7 +105,7 @@ struct FwdArgs {
 // host knows the instance count and leave without touching memory when ctl->num_binned exceeds it (the host then
 // re-allocates and re-launches; gsr_api.hip forward_impl).
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
-void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs, float* shjac,
+void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs, float* shjac, uint4* binfo,
                            uint32_t* tiles_touched, uint32_t* bsums, uint32_t* refsums, uint32_t* tile_count,
                            GsCtl* ctl, hipStream_t s);
 void launch_tile_scan(int T, uint32_t* tile_count, uint2* ranges, int nblk, uint32_t* bsums, const uint32_t* refsums,
@@ -115,9 +118,9 @@ void launch_bin_scatter(int P, int gx, const int* radii, const uint32_t* tiles_t
 int bin_chunks(int P, int T);
 size_t bin_hist_bytes(int P, int T);
 bool bin_lds_path_ok(int T);
-void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
+void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, const uint4* binfo, uint32_t* Hm,
                      uint32_t* tile_count, hipStream_t s);
-void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
+void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, const uint4* binfo, uint32_t* Hm,
                          const uint2* ranges, uint64_t* keys, const uint32_t* bsums, uint32_t* goff, const GsCtl* ctl, uint32_t cap, hipStream_t s);
 // long_level: 0 = no list beyond GSR_SORT_LDS_MAX, 1 = lists up to GSR_SORT_GIANT keys (one workgroup per tile), 2 = longer ones too
 #define GSR_PART_REGS 8192u     // keys a 1024-thread workgroup holds in registers: a slice of the queue pipeline; the longest list of the per-list kernel

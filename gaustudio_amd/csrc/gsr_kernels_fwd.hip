@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
     const float* __restrict__ shs_rest, int act_arg, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const GsCam* __restrict__ cam, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int gx, int gy, int prefiltered, int sh_vec4, int tight, int band_lo, int band_hi, int* __restrict__ radii,
-    GsRec* __restrict__ recs, float* __restrict__ shjac,
+    GsRec* __restrict__ recs, float* __restrict__ shjac, uint4* __restrict__ binfo,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ bsums, uint32_t* __restrict__ refsums,
     uint32_t* __restrict__ tile_count, GsCtl* __restrict__ ctl)
 {
@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
 		rec.q3 = make_uint4((uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16),
 		                    clamped | (dead << GSR_Q3Z_DEAD_SHIFT), my_tiles);
 		recs[idx] = rec;
+		if (binfo != nullptr) binfo[idx] = make_uint4(rec.q3.x, rec.q3.y, rec.q3.z, (uint32_t)__float_as_int(depth));
 	}
 	if (idx < P) {
 		radii[idx] = vis ? mr : 0;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
 		              [&](int x, int y, uint32_t, uint32_t) { atomicAdd(&tile_count[y * gx + x], 1u); });
 }
 
-void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs, float* shjac,
+void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& il, int* radii, GsRec* recs, float* shjac, uint4* binfo,
                            uint32_t* tiles_touched, uint32_t* bsums, uint32_t* refsums, uint32_t* tile_count,
                            GsCtl* ctl, hipStream_t s)
 {
@@ -349,7 +350,7 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 	hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, RAW>), grid, block, 0, s, a.P, a.M, a.means3D, a.scales,        \
 	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.shs_rest, a.act, a.cov3D_precomp,       \
 	                   a.colors_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, focal_x, focal_y, il.gx, il.gy,     \
-	                   a.prefiltered, sh_vec4, a.tight, a.band_lo, a.band_hi > 0 ? a.band_hi : il.gy, radii, recs, shjac,   \
+	                   a.prefiltered, sh_vec4, a.tight, a.band_lo, a.band_hi > 0 ? a.band_hi : il.gy, radii, recs, shjac, binfo,   \
 	                   tiles_touched, bsums, refsums, tile_count, ctl)
 #define GSR_LAUNCH_PRE_D(RAW)                          \
 	switch (D) {                                       \
@@ -600,7 +601,7 @@ void launch_bin_scatter(int P, int gx, const int* radii, const uint32_t* tiles_t
 template <bool SCATTER>
 __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int chunk, int gx, int T,
                                                         const uint32_t* __restrict__ tiles_touched,
-                                                        const GsRec* __restrict__ recs,
+                                                        const GsRec* __restrict__ recs, const uint4* __restrict__ binfo,
                                                         uint32_t* __restrict__ Hm, const uint2* __restrict__ ranges,
                                                         uint64_t* __restrict__ keys, const uint32_t* __restrict__ bsums,
                                                         uint32_t* __restrict__ goff, const GsCtl* __restrict__ ctl,
@@ -646,9 +647,16 @@ __global__ __launch_bounds__(GSR_BIN_THREADS) void bin_chunk_kernel(int P, int c
 		uint32_t dbs[NB];
 #pragma unroll
 		for (int u = 0; u < NB; u++) {
-			const GsRec* r = recs + (vis[u] ? idxs[u] : spare);
-			q3s[u] = r->q3;
-			dbs[u] = SCATTER ? (uint32_t)__float_as_int(r->q1.z) : 0u;
+			const int at = vis[u] ? idxs[u] : spare;
+			if (binfo != nullptr) {   // the 16-B binning record: rect, dead corners and depth in one half sector
+				const uint4 b = binfo[at];
+				q3s[u] = b;
+				dbs[u] = b.w;
+			} else {
+				const GsRec* r = recs + at;
+				q3s[u] = r->q3;
+				dbs[u] = SCATTER ? (uint32_t)__float_as_int(r->q1.z) : 0u;
+			}
 		}
 #pragma unroll
 		for (int u = 0; u < NB; u++) {
@@ -714,19 +722,19 @@ static void set_dyn_lds(const void* fn, size_t bytes)
 	if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
+void launch_bin_hist(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, const uint4* binfo, uint32_t* Hm,
                      uint32_t* tile_count, hipStream_t s)
 {
 	const int G = bin_chunks(P, T);
 	const int chunk = ((P + G - 1) / G + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS * GSR_BIN_THREADS;
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<false>, lds);
-	hipLaunchKernelGGL(bin_chunk_kernel<false>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
+	hipLaunchKernelGGL(bin_chunk_kernel<false>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, binfo, Hm,
 	                   (const uint2*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const GsCtl*)nullptr, 0u);
 	hipLaunchKernelGGL(bin_colscan_kernel, dim3((T + 63) / 64), dim3(64 * GSR_COLSCAN_Q), 0, s, G, T, Hm, tile_count);
 }
 
-void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, uint32_t* Hm,
+void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, const GsRec* recs, const uint4* binfo, uint32_t* Hm,
                          const uint2* ranges, uint64_t* keys, const uint32_t* bsums, uint32_t* goff, const GsCtl* ctl,
                          uint32_t cap, hipStream_t s)
 {
@@ -734,7 +742,7 @@ void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, co
 	const int chunk = ((P + G - 1) / G + GSR_BIN_THREADS - 1) / GSR_BIN_THREADS * GSR_BIN_THREADS;
 	const size_t lds = (size_t)T * sizeof(uint32_t);
 	set_dyn_lds((const void*)bin_chunk_kernel<true>, lds);
-	hipLaunchKernelGGL(bin_chunk_kernel<true>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, Hm,
+	hipLaunchKernelGGL(bin_chunk_kernel<true>, dim3(G), dim3(GSR_BIN_THREADS), lds, s, P, chunk, gx, T, tiles_touched, recs, binfo, Hm,
 	                   ranges, keys, bsums, goff, ctl, cap);
 }
 
