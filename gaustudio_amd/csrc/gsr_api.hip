@@ -570,8 +570,9 @@ static int forward_impl(const gsr_options* opt, gsr_alloc_fn geometry_alloc, voi
 	uint32_t* bsums = reinterpret_cast<uint32_t*>(geom + gl.bsums);
 	uint32_t* refsums = reinterpret_cast<uint32_t*>(geom + gl.refsums);
 	uint32_t* Hm = reinterpret_cast<uint32_t*>(img + hm_off);
-	uint4* binfo = (lds_bin && g_opt_bininfo.load() != 0) ? reinterpret_cast<uint4*>(geom + gl.binfo) : nullptr;
-	launch_preprocess_fwd(a, cam, il, radii, recs, ro.forward_only ? nullptr : reinterpret_cast<float*>(geom + gl.shjac), binfo, tiles_touched, bsums, refsums,
+	uint4* binfo_w = reinterpret_cast<uint4*>(geom + gl.binfo);   // always written: the SH backward reads its clamp word
+	const uint4* binfo = (lds_bin && g_opt_bininfo.load() != 0) ? binfo_w : nullptr;   // read by the binning passes (A/B)
+	launch_preprocess_fwd(a, cam, il, radii, recs, ro.forward_only ? nullptr : reinterpret_cast<float*>(geom + gl.shjac), binfo_w, tiles_touched, bsums, refsums,
 	                      lds_bin ? nullptr : tile_count, ctl, s);
 	STAGE_CHECK("preprocess_fwd", debug, s);
 	tm.mark();
@@ -798,6 +799,9 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + bl.point_list);
 	const BwdLayout wl((size_t)P, (size_t)(R > 0 ? R : 0));
 	const uint32_t* goff = reinterpret_cast<const uint32_t*>(geom_buffer + gl.goff);   // scanned by the forward
+	// the clamp bits of every visible Gaussian (word 2 of its 16-B binning record, which the forward always writes): what the SH stage
+	// needs of the record -- a quarter sector instead of a 32-B sector of the 64-B record per Gaussian
+	const uint32_t* clampw = reinterpret_cast<const uint32_t*>(geom_buffer + gl.binfo) + 2;
 	float* bg_dev = reinterpret_cast<float*>(scratch + wl.bg);
 	float* rows = reinterpret_cast<float*>(scratch + wl.rows);
 	uint8_t* row_flags = reinterpret_cast<uint8_t*>(scratch + wl.flags);
@@ -825,7 +829,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	}
 	if (!(parts & GSR_BWD_PART_MAIN)) {
 		// SH stage alone over a Gaussian range (the caller interleaves a collective per chunk, gaustudio_amd/parallel.py)
-		launch_preprocess_bwd(a, cam, recs, reinterpret_cast<const float*>(geom_buffer + gl.shjac), goff, rows, nullptr, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
+		launch_preprocess_bwd(a, cam, recs, clampw, reinterpret_cast<const float*>(geom_buffer + gl.shjac), goff, rows, nullptr, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D,
 		                      dL_dsh, dL_dsh_rest, dL_dscale, dL_drot, GSR_PART_SH | (sh_colors ? GSR_PART_SH_COLORS : 0) | colors_early, sh_g0, sh_g1, s);
 		STAGE_CHECK("preprocess_bwd_sh", debug, s);
 		return GSR_OK;
@@ -895,7 +899,7 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 		STAGE_CHECK("composite_bwd", debug, s);
 	}
 	tm.mark();
-	launch_preprocess_bwd(a, cam, recs, reinterpret_cast<const float*>(geom_buffer + gl.shjac), goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+	launch_preprocess_bwd(a, cam, recs, clampw, reinterpret_cast<const float*>(geom_buffer + gl.shjac), goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
 	                      dL_dsh_rest, dL_dscale, dL_drot,
 	                      GSR_PART_GEOM | ((parts & GSR_BWD_PART_SH) ? GSR_PART_SH : 0) | (sh_colors ? GSR_PART_SH_COLORS : 0) | colors_early,
 	                      sh_g0, sh_g1, s);

@@ -206,7 +206,7 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, con
 #define GSR_PART_SH 2
 #define GSR_PART_SH_COLORS 4   // with GSR_PART_SH: the factored form (dRGB into dL_dcolor in place, dL_dsh untouched)
 #define GSR_PART_COLORS_EARLY 8   // the GEOMETRY kernel leaves dRGB (clamp-masked) in dL_dcolor; the COLORS SH kernel then does not write it
-void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const float* shjac, const uint32_t* goff,
+void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* clampw, const float* shjac, const uint32_t* goff,
                            const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
                            float* dL_drot, int parts, int sh_g0, int sh_g1, hipStream_t s);

@@ -1307,7 +1307,7 @@ constexpr int gs_sh_row_floats(int deg, bool split)
 template <int D, bool SPLIT, bool COLORS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
     int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shjac,
-    const GsCam* __restrict__ cam, const GsRec* __restrict__ recs,
+    const GsCam* __restrict__ cam, const uint32_t* __restrict__ clampw,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_rest, int write_colors)
 {
@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 			for (int k = 0; k < 9; k++) J[k] = 0.f;
 		}
 		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
+		gs_sh_backward<D>(m, cam, clampw[(size_t)idx * 4], dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
 #define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
 		if (COLORS) {
 			if (write_colors) {   // (0: the geometry stage left dRGB already and a collective may be reading the slot by now)
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_coop_kernel(
 template <int D, int MS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_wide_kernel(
     int g_base, int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shjac,
-    const GsCam* __restrict__ cam, const GsRec* __restrict__ recs, const float* __restrict__ dL_dcolor,
+    const GsCam* __restrict__ cam, const uint32_t* __restrict__ clampw, const float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh)
 {
 	extern __shared__ __attribute__((aligned(16))) float sh_slab[];
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_wide_kernel(
 		if (D > 0) gs_load_shjac(shjac, P, idx, J);
 		else { for (int k = 0; k < 9; k++) J[k] = 0.f; }
 		const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-		gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
+		gs_sh_backward<D>(m, cam, clampw[(size_t)idx * 4], dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
 #pragma unroll
 		for (int i = 0; i < NC * 3; i++) row[i] = dc[i / 3] * dRGB[i % 3];
 #pragma unroll
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_wide_kernel(
 template <int D, bool SPLIT, bool COLORS>
 __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
     int g_base, int P, int M, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ shjac,
-    const GsCam* __restrict__ cam, int sh_vec4, const GsRec* __restrict__ recs,
+    const GsCam* __restrict__ cam, int sh_vec4, const uint32_t* __restrict__ clampw,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmeans, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_rest, int write_colors)
 {
@@ -1448,7 +1448,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 	if (D > 0) gs_load_shjac(shjac, P, idx, J);
 	else { for (int k = 0; k < 9; k++) J[k] = 0.f; }
 	const float3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
-	gs_sh_backward<D>(m, cam, recs[idx].q3.z, dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
+	gs_sh_backward<D>(m, cam, clampw[(size_t)idx * 4], dL_dcolor + 3 * (size_t)idx, J, dc, dRGB, dmean_sh);
 #define OSH(i) (dc[(i) / 3] * dRGB[(i) % 3])
 	if (COLORS) {
 		if (write_colors) {
@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_sh_kernel(
 	for (int i = 0; i < 3; i++) dL_dmeans[3 * (size_t)idx + i] += dmean_sh[i];
 }
 
-void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const float* shjac, const uint32_t* goff,
+void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs, const uint32_t* clampw, const float* shjac, const uint32_t* goff,
                            const float* rows, const uint8_t* row_flags, float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
                            float* dL_drot, int parts, int sh_g0, int sh_g1, hipStream_t s)
@@ -1511,7 +1511,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	if (a.shs != nullptr) {
 #define GSR_LAUNCH_SH(DEG)                                                                                       \
 	hipLaunchKernelGGL((preprocess_bwd_sh_kernel<DEG, SPLIT, COLORS>), grid, block, 0, s, sh_g0, sh_end, a.M, a.means3D, a.radii, shjac, \
-	                   cam, sh_vec4, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
+	                   cam, sh_vec4, clampw, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
 #define GSR_LAUNCH_SH_D()                        \
 		switch (a.D) {                            \
 			case 0: GSR_LAUNCH_SH(0); break;      \
@@ -1531,12 +1531,12 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 #define GSR_LAUNCH_SHC(DEG, SPL, COL)                                                                             \
 	hipLaunchKernelGGL((preprocess_bwd_sh_coop_kernel<DEG, SPL, COL>), grid, block,                                  \
 	                   sizeof(float) * 256 * gs_row_stride<gs_sh_row_floats(DEG, SPL)>(), s, sh_g0, sh_end, \
-	                   a.means3D, a.radii, shjac, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
+	                   a.means3D, a.radii, shjac, cam, clampw, dL_dcolor, dL_dmean3D, dL_dsh, dL_dsh_rest, write_colors)
 		// stored rows wider than the active degree ([P,16,3] storage while the degree is still being raised): the wide kernel
 		const bool wide = !colors && !split && a.M == 16 && NCd < 16 && (sh_g0 % 256 == 0) && ((uintptr_t)dL_dsh % 16 == 0);
 #define GSR_LAUNCH_SHW(DEG)                                                                                            \
 	hipLaunchKernelGGL((preprocess_bwd_sh_wide_kernel<DEG, 16>), grid, block, sizeof(float) * 256 * gs_row_stride<48>(), s, sh_g0, \
-	                   sh_end, a.means3D, a.radii, shjac, cam, recs, dL_dcolor, dL_dmean3D, dL_dsh)
+	                   sh_end, a.means3D, a.radii, shjac, cam, clampw, dL_dcolor, dL_dmean3D, dL_dsh)
 		if (wide) {
 			switch (a.D) {
 				case 0: GSR_LAUNCH_SHW(0); break;
