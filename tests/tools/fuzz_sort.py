@@ -5,6 +5,7 @@ two thin sheets), with and without MANY long lists in the frame -- forward BIT-E
 ranges, n_contrib, images), i.e. every list in (depth, id) order.
 usage: python tests/tools/fuzz_sort.py [--n 60] [--first 0]"""
 import argparse, os, sys, time, traceback
+os.environ.setdefault("GSR_FAST_EXP", "0")   # the reproducible mode (as tests/conftest.py), set before libgsrast.so loads
 import numpy as np, torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
