@@ -33,6 +33,10 @@ ALPHA_MIN = 1.0 / 255.0
 WIN_ALPHA = 5.0e-6       # |alpha * 255 - 1|            (largest observed margin 1.79e-6)
 WIN_T = 1.2e-5           # |T (1 - alpha) / 1e-4 - 1|   (largest observed 4.51e-6)
 WIN_POWER = 2.0e-6       # |power| / (|a dx^2| + |b dx dy| + |c dy^2|): no event of this kind has ever been observed; ~16 ulp of the terms
+# round 6: the median test `T > 0.5 && T (1 - alpha) < 0.5` (forward.cu:366-374).  T is a product of up to hundreds of fp32 factors
+# (1 - alpha), each carrying the implementations' exp() difference.  Largest margin of an attributed event observed over C1-C5 in both
+# modes and between the reference's two builds: see profiles/r06_parity.json (`max_margin.median`).
+WIN_MEDIAN = float(__import__("os").environ.get("GSR_WIN_MEDIAN", "2.0e-5"))     # |T (1 - alpha) / 0.5 - 1|
 MAX_LEAVES = 256
 
 
@@ -49,10 +53,40 @@ def _records(st, ids):
     return g("means2D"), g("conic_opacity"), g("rgb"), g("depths")
 
 
-def _explore(n, power, mag, alpha_raw, alpha, rgb, dep, include):
+def _explore(n, power, mag, alpha_raw, alpha, rgb, dep, include, ids=None):
+    """Decision tree of one pixel.  A leaf = (values, events); values = [r, g, b, depth, opacity] and, when `ids` is given,
+    + [median depth, median weight, median id] (forward.cu:366-374, 392-394).  The median test `T > 0.5 && T (1 - alpha) < 0.5`
+    is a fourth data-dependent decision: where T (1 - alpha) lies inside WIN_MEDIAN of 0.5 one implementation records THIS
+    contributor and the other the NEXT one (whose T is that same product) -- both branches are explored (`med` mode 1 = the
+    next contributor fires whatever float64 says, mode 2 = it does not)."""
     leaves = []
+    with_med = ids is not None
 
-    def rec(i, T, c0, c1, c2, d, events):
+    def leaf(c0, c1, c2, d, T, med, events):
+        v = [c0, c1, c2, d, 1.0 - T]
+        if with_med:
+            v += [med[0], med[1], med[2]]
+        leaves.append((np.array(v), tuple(events)))
+
+    def med_step(i, T, test_T, med, events):
+        """-> (med after contributor i on the default branch, [(med, events) of the alternative branch] or [])."""
+        if not with_med:
+            return med, []
+        md, mw, mid, mode = med
+        fired = (dep[i], alpha[i] * T, float(ids[i]), 0)
+        if mode == 1:
+            return fired, []
+        if mode == 2:
+            return (md, mw, mid, 0), []
+        fire = T > 0.5 and test_T < 0.5
+        alt = []
+        margin = abs(test_T / 0.5 - 1.0)
+        if margin < WIN_MEDIAN and T > 0.5 * (1.0 + WIN_MEDIAN):
+            ev = list(events) + [(i, "median", margin)]
+            alt = [((md, mw, mid, 1), ev)] if fire else [((fired[0], fired[1], fired[2], 2), ev)]
+        return (fired if fire else med), alt
+
+    def rec(i, T, c0, c1, c2, d, med, events):
         while i < n:
             if len(leaves) >= MAX_LEAVES:
                 return
@@ -63,16 +97,16 @@ def _explore(n, power, mag, alpha_raw, alpha, rgb, dep, include):
             if inc is None:                                            # in one implementation's list only
                 rec2 = list(events) + [(i, "radius", 0.0)]
                 # branch A: absent
-                _cont(i + 1, T, c0, c1, c2, d, rec2)
+                rec(i + 1, T, c0, c1, c2, d, med, rec2)
                 # branch B (fall through): present
             # --- power > 0 ---
             p_skip = power[i] > 0.0
             p_margin = abs(power[i]) / mag[i] if mag[i] > 1e-200 else np.inf
             if p_margin < WIN_POWER:
                 if p_skip:   # alternative: treat as not skipped -> needs the rest of the body; handled by flipping below
-                    _body(i, T, c0, c1, c2, d, list(events) + [(i, "power", p_margin)], force_alpha=None)
+                    _body(i, T, c0, c1, c2, d, med, list(events) + [(i, "power", p_margin)], force_alpha=None)
                 else:
-                    _cont(i + 1, T, c0, c1, c2, d, list(events) + [(i, "power", p_margin)])
+                    rec(i + 1, T, c0, c1, c2, d, med, list(events) + [(i, "power", p_margin)])
             if p_skip:
                 i += 1
                 continue
@@ -81,9 +115,9 @@ def _explore(n, power, mag, alpha_raw, alpha, rgb, dep, include):
             a_margin = abs(alpha_raw[i] / ALPHA_MIN - 1.0)
             if a_margin < WIN_ALPHA:
                 if a_skip:
-                    _body(i, T, c0, c1, c2, d, list(events) + [(i, "alpha", a_margin)], force_alpha=True)
+                    _body(i, T, c0, c1, c2, d, med, list(events) + [(i, "alpha", a_margin)], force_alpha=True)
                 else:
-                    _cont(i + 1, T, c0, c1, c2, d, list(events) + [(i, "alpha", a_margin)])
+                    rec(i + 1, T, c0, c1, c2, d, med, list(events) + [(i, "alpha", a_margin)])
             if a_skip:
                 i += 1
                 continue
@@ -94,45 +128,50 @@ def _explore(n, power, mag, alpha_raw, alpha, rgb, dep, include):
             if t_margin < WIN_T:
                 if t_stop:
                     # alternative: not done -> apply and go on
-                    _apply_and_go(i, T, test_T, c0, c1, c2, d, list(events) + [(i, "T", t_margin)])
+                    _apply_and_go(i, T, test_T, c0, c1, c2, d, med, list(events) + [(i, "T", t_margin)])
                 else:
-                    leaves.append((np.array([c0, c1, c2, d, 1.0 - T]), tuple(events) + ((i, "T", t_margin),)))
+                    leaf(c0, c1, c2, d, T, med, list(events) + [(i, "T", t_margin)])
             if t_stop:
-                leaves.append((np.array([c0, c1, c2, d, 1.0 - T]), tuple(events)))
+                leaf(c0, c1, c2, d, T, med, events)
                 return
             w = alpha[i] * T
             c0 += rgb[i, 0] * w
             c1 += rgb[i, 1] * w
             c2 += rgb[i, 2] * w
             d += dep[i] * w
+            med, alt = med_step(i, T, test_T, med, events)
+            for m2, ev2 in alt:
+                rec(i + 1, test_T, c0, c1, c2, d, m2, ev2)
             T = test_T
             i += 1
-        leaves.append((np.array([c0, c1, c2, d, 1.0 - T]), tuple(events)))
+        leaf(c0, c1, c2, d, T, med, events)
 
-    def _cont(i, T, c0, c1, c2, d, events):
-        rec(i, T, c0, c1, c2, d, events)
-
-    def _apply_and_go(i, T, test_T, c0, c1, c2, d, events):
+    def _apply_and_go(i, T, test_T, c0, c1, c2, d, med, events):
         w = alpha[i] * T
-        rec(i + 1, test_T, c0 + rgb[i, 0] * w, c1 + rgb[i, 1] * w, c2 + rgb[i, 2] * w, d + dep[i] * w, events)
+        args = (i + 1, test_T, c0 + rgb[i, 0] * w, c1 + rgb[i, 1] * w, c2 + rgb[i, 2] * w, d + dep[i] * w)
+        m1, alt = med_step(i, T, test_T, med, events)
+        for m2, ev2 in alt:
+            rec(*args, m2, ev2)
+        rec(*args, m1, events)
 
-    def _body(i, T, c0, c1, c2, d, events, force_alpha):
+    def _body(i, T, c0, c1, c2, d, med, events, force_alpha):
         # the instance is evaluated although the default decision skipped it: alpha test (unless forced), T test, apply
         if force_alpha is None and alpha[i] < ALPHA_MIN:
-            rec(i + 1, T, c0, c1, c2, d, events)
+            rec(i + 1, T, c0, c1, c2, d, med, events)
             return
         test_T = T * (1.0 - alpha[i])
         if test_T < 1e-4:
-            leaves.append((np.array([c0, c1, c2, d, 1.0 - T]), tuple(events)))
+            leaf(c0, c1, c2, d, T, med, events)
             return
-        _apply_and_go(i, T, test_T, c0, c1, c2, d, events)
+        _apply_and_go(i, T, test_T, c0, c1, c2, d, med, events)
 
-    rec(0, 1.0, 0.0, 0.0, 0.0, 0.0, [])
+    rec(0, 1.0, 0.0, 0.0, 0.0, 0.0, (15.0, 0.0, 0.0, 0), [])
     return leaves
 
 
 def attribute_pixel(st, tile, px, py, val_a, val_b, tol_a, tol_b, maybe_ids=(), extra_ids=()):
-    """val_* = (r, g, b, depth, opacity) of the two implementations at pixel (px, py) of `tile`; tol_* = per-channel
+    """val_* = (r, g, b, depth, opacity[, median depth, median weight, median id]) of the two implementations at pixel
+    (px, py) of `tile`; tol_* = per-channel
     absolute tolerances for matching a replay leaf to them (the replay is float64, the implementations accumulate in
     fp32).  maybe_ids: Gaussians of the list whose membership is undecided (their radii differ between the
     implementations); extra_ids: Gaussians NOT in this list that the other implementation may have binned here.
@@ -152,8 +191,8 @@ def attribute_pixel(st, tile, px, py, val_a, val_b, tol_a, tol_b, maybe_ids=(), 
         ms = set(int(i) for i in maybe_ids)
         include = [None if (int(g) in ms) else inc for g, inc in zip(ids, include)]
     xy, co, rgb, dep = _records(st, ids)
-    leaves = _explore(len(ids), *_terms(xy, co, float(px), float(py)), rgb, dep, include)
     va, vb = np.asarray(val_a, np.float64), np.asarray(val_b, np.float64)
+    leaves = _explore(len(ids), *_terms(xy, co, float(px), float(py)), rgb, dep, include, ids if len(va) == 8 else None)
     hit_a = [k for k, (v, _) in enumerate(leaves) if np.all(np.abs(v - va) <= tol_a)]
     hit_b = [k for k, (v, _) in enumerate(leaves) if np.all(np.abs(v - vb) <= tol_b)]
     best = None
@@ -183,14 +222,17 @@ def _terms(xy, co, px, py):
 
 
 def attribute_images(st, W, H, imgs_a, imgs_b, tol=1e-5, depth_scale=1.0, radii_b=None, max_pixels=4000, tol_a=None, radii_a=None):
-    """imgs_* = dict(color[3,H,W], depth[1,H,W], opacity[1,H,W]) as numpy arrays of implementations A (the one `st`
-    was decoded from) and B.  Every pixel with a channel differing by more than `tol` is attributed.
+    """imgs_* = dict(color[3,H,W], depth[1,H,W], opacity[1,H,W][, median[3,H,W]]) as numpy arrays of implementations A (the
+    one `st` was decoded from) and B.  Every pixel with a channel differing by more than `tol` is attributed.  With `median`
+    in both dicts the three median channels (depth, weight, Gaussian id; forward.cu:366-374, 392-394) are compared and
+    replayed like the other five: a differing median id is a flagged pixel that needs a `median` (or earlier) event.
     tol_a / radii_a: when A is NOT the implementation `st` was decoded from either (two builds of the reference compared
     with each other, replayed from this library's records), A's values are matched with tolerance tol_a like B's, and a
     Gaussian whose integer radius differs between ANY two of (st, A, B) has undecided list membership.
     Returns dict(flagged, attributed, unattributed=[...], by_kind, max_margin, events=[...])."""
-    a = np.concatenate([imgs_a["color"], imgs_a["depth"], imgs_a["opacity"]], 0).astype(np.float64)   # [5,H,W]
-    b = np.concatenate([imgs_b["color"], imgs_b["depth"], imgs_b["opacity"]], 0).astype(np.float64)
+    keys = ["color", "depth", "opacity"] + (["median"] if ("median" in imgs_a and "median" in imgs_b) else [])
+    a = np.concatenate([np.asarray(imgs_a[k]) for k in keys], 0).astype(np.float64)   # [5 or 8,H,W]
+    b = np.concatenate([np.asarray(imgs_b[k]) for k in keys], 0).astype(np.float64)
     bad = (np.abs(a - b) > tol).any(0)
     ys, xs = np.nonzero(bad)
     gx = (W + 15) // 16
@@ -215,6 +257,8 @@ def attribute_images(st, W, H, imgs_a, imgs_b, tol=1e-5, depth_scale=1.0, radii_
     # fp32 accumulation noise of the implementations against the float64 replay: colour/opacity values are O(1), depth
     # is in scene units
     tol_leaf = np.array([4e-6, 4e-6, 4e-6, 4e-6 * max(depth_scale, 1.0), 4e-6])
+    if a.shape[0] == 8:       # median depth: one Gaussian's depth (scene units); weight: alpha * T; id: an integer, exact
+        tol_leaf = np.concatenate([tol_leaf, [4e-6 * max(depth_scale, 1.0), 4e-6, 0.5]])
     for y, x in zip(ys.tolist(), xs.tolist()):
         tile = (y // 16) * gx + (x // 16)
         ids = tile_list(st, tile)

@@ -141,3 +141,89 @@ def test_attribute_images_on_oracle_with_a_planted_flip():
         at.WIN_ALPHA = old
     assert rep["flagged"] == 2 and rep["attributed"] == 1 and len(rep["unattributed"]) == 1
     assert rep["unattributed"][0]["pixel"] == [3, 3] and rep["by_kind"] == {"alpha": 1}
+
+
+def test_replay_default_leaf_reproduces_the_oracle_median_channels():
+    """Round 6: with the tile's ids handed over the leaf also carries (median depth, median weight, median id) -- forward.cu:366-374 --
+    and the default leaf is the oracle's pixel in all eight channels; pixels that never cross T = 0.5 keep (15, 0, 0)."""
+    dense, cam = _oracle_state()
+    sparse, _ = _oracle_state(P=250)
+    gx = (cam.width + 15) // 16
+    rng = np.random.default_rng(1)
+    crossed = 0
+    for k in range(200):
+        st = dense if k % 2 else sparse
+        x, y = int(rng.integers(0, cam.width)), int(rng.integers(0, cam.height))
+        tile = (y // 16) * gx + x // 16
+        ids = at.tile_list(st, tile)
+        xy, co, rgb, dep = at._records(st, ids)
+        leaves = at._explore(len(ids), *at._terms(xy, co, float(x), float(y)), rgb, dep, None, ids)
+        want = np.array([st["color"][0, y, x], st["color"][1, y, x], st["color"][2, y, x], st["depth"][0, y, x], st["opacity"][0, y, x],
+                         st["median"][0, y, x], st["median"][1, y, x], st["median"][2, y, x]], np.float64)
+        default = [v for v, e in leaves if not e]
+        assert len(default) == 1
+        d = np.abs(default[0] - want)
+        assert d[:7].max() <= 4e-6 * max(1.0, np.abs(want[:7]).max()) and d[7] == 0.0, (x, y, default[0], want)
+        crossed += want[6] > 0
+        if want[6] == 0:
+            assert want[5] == 15.0 and want[7] == 0.0
+    assert 20 <= crossed <= 195          # the scene exercises both outcomes
+
+
+def _pixel8(alphas, rgb, depths, ids, fire_at):
+    v = _pixel(alphas, rgb, depths)
+    T, med = 1.0, [15.0, 0.0, 0.0]
+    for k, (a, dep, i) in enumerate(zip(alphas, depths, ids)):
+        if k == fire_at:
+            med = [dep, a * T, float(i)]
+        T *= 1 - a
+    return np.concatenate([v, med])
+
+
+def test_median_crossing_inside_its_window_is_attributed_either_way():
+    """T (1 - alpha) within WIN_MEDIAN of 0.5 at the first Gaussian: one implementation records the first Gaussian as the median,
+    the other the second (whose T is that product).  Both are leaves; a median id with no such event is not attributed."""
+    tol = np.concatenate([np.full(7, 4e-6), [0.5]])
+    for a0 in (0.5 * (1 + 4e-6), 0.5 * (1 - 4e-6)):            # test_T just below / just above 0.5
+        st = _hand_state(0.3)
+        st["conic_opacity"][0, 3] = a0
+        al = [float(st["conic_opacity"][k, 3]) for k in range(3)]
+        assert abs((1 - al[0]) / 0.5 - 1) < at.WIN_MEDIAN
+        rgb, dep = st["rgb"].astype(np.float64), st["depths"].astype(np.float64)
+        first = _pixel8(al, rgb, dep, [0, 1, 2], 0)
+        second = _pixel8(al, rgb, dep, [0, 1, 2], 1)
+        third = _pixel8(al, rgb, dep, [0, 1, 2], 2)
+        res = at.attribute_pixel(st, 0, 5, 5, first, second, tol, tol)
+        assert res["attributed"] and res["kinds"] == ["median"] and res["events"][0][0] == 0 and res["events"][0][2] < at.WIN_MEDIAN
+        assert at.attribute_pixel(st, 0, 5, 5, second, first, tol, tol)["attributed"]
+        assert not at.attribute_pixel(st, 0, 5, 5, first, third, tol, tol)["attributed"]      # the third Gaussian is never the median
+        assert not at.attribute_pixel(st, 0, 5, 5, first, first, tol, tol)["attributed"]
+    # well outside the window: the second Gaussian as median is a bug, not a flip
+    st = _hand_state(0.3)
+    st["conic_opacity"][0, 3] = 0.51
+    al = [float(st["conic_opacity"][k, 3]) for k in range(3)]
+    rgb, dep = st["rgb"].astype(np.float64), st["depths"].astype(np.float64)
+    assert not at.attribute_pixel(st, 0, 5, 5, _pixel8(al, rgb, dep, [0, 1, 2], 0), _pixel8(al, rgb, dep, [0, 1, 2], 1), tol, tol)["attributed"]
+    # the "forced next" branch with no next contributor: the median stays unset in that implementation
+    st = _hand_state(0.3)
+    st["conic_opacity"][0, 3] = 0.5 * (1 + 4e-6)
+    st["ranges"] = np.array([[0, 1]], np.uint32)
+    al = [float(st["conic_opacity"][0, 3])]
+    a = _pixel8(al, rgb[:1], dep[:1], [0], 0)
+    b = _pixel8(al, rgb[:1], dep[:1], [0], None)
+    assert at.attribute_pixel(st, 0, 5, 5, a, b, tol, tol)["attributed"]
+
+
+def test_attribute_images_with_median_flags_a_differing_median_id():
+    st, cam = _oracle_state()
+    W, H = cam.width, cam.height
+    imgs_a = dict(color=st["color"], depth=st["depth"], opacity=st["opacity"], median=st["median"])
+    imgs_b = {k: v.copy() for k, v in imgs_a.items()}
+    st_t = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) and k in ("radii", "means2D") else v) for k, v in st.items()}
+    ys, xs = np.nonzero(st["median"][1] > 0)
+    y, x = int(ys[len(ys) // 2]), int(xs[len(xs) // 2])
+    imgs_b["median"][2, y, x] += 1.0                          # a wrong median id, all other channels equal
+    rep = at.attribute_images(st_t, W, H, imgs_a, imgs_b, tol=1e-5, depth_scale=20.0)
+    assert rep["flagged"] == 1 and rep["attributed"] == 0 and rep["unattributed"][0]["pixel"] == [x, y]
+    rep = at.attribute_images(st_t, W, H, imgs_a, imgs_a, tol=1e-5, depth_scale=20.0)
+    assert rep["flagged"] == 0

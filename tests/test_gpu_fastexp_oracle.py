@@ -80,10 +80,10 @@ def fast_vs_oracle(oracle, sc, cam, D, kw, scale_modifier=1.0, bg=None, seed=1, 
             assert np.array_equal(to_np(fs[k]), os_[k]), k
         return {"num_rendered": 0}
     _prefix_bit_equal(fs, os_)                                                        # (1)
-    a = {k: to_np(fs[k]) for k in ("color", "depth", "opacity")}
-    b = {k: os_[k] for k in ("color", "depth", "opacity")}
+    a = {k: to_np(fs[k]) for k in ("color", "depth", "opacity", "median")}     # round 6: the median channels are attributed too
+    b = {k: os_[k] for k in ("color", "depth", "opacity", "median")}
     stats = {"num_rendered": int(os_["num_rendered"])}
-    for k in a:
+    for k in ("color", "depth", "opacity"):
         d = np.abs(a[k].astype(np.float64) - b[k].astype(np.float64))
         stats[k] = {"over_1e-5": int((d > 1e-5).sum()), "values": int(d.size), "max_abs": float(d.max())}
     rep = attribution.attribute_images(fs, W, H, a, b, tol=1e-5, depth_scale=depth_scale)                 # (2)
