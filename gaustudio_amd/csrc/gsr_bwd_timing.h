@@ -11,7 +11,7 @@ namespace gsr { __device__ unsigned long long g_bwd_phase_ticks[GSR_TM_SLOTS * 1
 #define TM(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm_acc[k] += now_ - tm_last; tm_last = now_; }
 #define TM_END { const unsigned w_ = blockIdx.x * 4 + wv; if (lane == 0 && w_ < GSR_TM_SLOTS) { for (int k_ = 0; k_ < 12; k_++) g_bwd_phase_ticks[w_ * 12 + k_] += tm_acc[k_]; } }
 // out: GSR_TM_SLOTS x 12 tick sums (slot = workgroup * 4 + wave); reset: clear them afterwards
-extern "C" inline int gsr_debug_bwd_phase_ticks(unsigned long long* out, int reset)
+extern "C" __attribute__((used, visibility("default"))) int gsr_debug_bwd_phase_ticks(unsigned long long* out, int reset)
 {
 	void* p = nullptr;
 	if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&p, HIP_SYMBOL(gsr::g_bwd_phase_ticks)) != hipSuccess) return -1;

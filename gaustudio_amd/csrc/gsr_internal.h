@@ -129,7 +129,7 @@ void launch_bin_scatter2(int P, int gx, int T, const uint32_t* tiles_touched, co
 #define GSR_SORT_GIANT 8192u
 #endif
 void launch_tile_sort(int T, bool with_short, int long_level, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
-                      uint32_t* point_list, char* queue, size_t R, const GsCtl* ctl, uint32_t cap, hipStream_t s);
+                      uint32_t* point_list, char* queue, size_t R, GsCtl* ctl, uint32_t cap, uint32_t* host_err, hipStream_t s);
 void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges, const uint32_t* point_list,
                           const GsRec* recs, float* out_color, float* out_depth, float* out_median,
                           float* out_opacity, float* final_T, uint32_t* n_contrib, uint32_t* med_pos, GsCtl* ctl, uint32_t cap, uint32_t max_sorted, bool nocull, bool wave_lists, bool fast_exp,

@@ -163,6 +163,7 @@ void launch_inspect_sums(int P, const int* radii, const GsRec* recs, const uint3
 #define GSR_PLANE_STRIDE 10   // floats per instance in a wave's plane of sums
 #define GSR_TAB_ROW 17        // float4 per pixel row of the constants table: 8 pixels x 2 + 1 pad (rows on distinct banks)
 
+#ifdef GSR_AB_VARIANTS   // the per-wave (8x8) walk: superseded by the per-quarter kernel below, kept for A/B builds only (make AB=1)
 // Phase 2: the wave's slab holds (q, w) of `n` pairs; writes their ten sums into the wave's plane.
 //   sums: 0 M10 = sum q dx, 1 M01 = sum q dy, 2 M20, 3 M11, 4 M02, 5 sum (w dL_dopacity + q), 6..8 sum w dL_dpixel[c],
 //         9 sum w dL_ddepth + (median gradient of the pixels whose median this Gaussian is)
@@ -472,6 +473,8 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 		part_cur = part_next;
 	}
 }
+
+#endif   // GSR_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
 // composite_bwd with per-quarter instance lists (the default; the kernel above is kept as variant bit 1 for A/B).
@@ -979,10 +982,15 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, con
 	hipLaunchKernelGGL((__VA_ARGS__), dim3(chunk * 8), dim3(GSR_BWD_THREADS), 0, s, il.T, chunk, il.gx, W, H, bg,  \
 	                   ranges, point_list, recs, goff, final_T, n_contrib, med_pos, dL_dpix, dL_dpix_depth, dL_dpix_median, \
 	                   dL_dpix_opacity, rows, row_flags, ctl)
+#ifdef GSR_AB_VARIANTS
 	if (wave_lists) {
 		if (flags) { if (tsel) GSR_LAUNCH_CB(composite_bwd_kernel<true, true>); else GSR_LAUNCH_CB(composite_bwd_kernel<true, false>); }
 		else { if (tsel) GSR_LAUNCH_CB(composite_bwd_kernel<false, true>); else GSR_LAUNCH_CB(composite_bwd_kernel<false, false>); }
-	} else if (dL_dpix_depth == nullptr && dL_dpix_median == nullptr && dL_dpix_opacity == nullptr && !tsel) {
+	} else
+#else
+	(void)wave_lists;   // refused by gsr_backward in a build without GSR_AB_VARIANTS
+#endif
+	if (dL_dpix_depth == nullptr && dL_dpix_median == nullptr && dL_dpix_opacity == nullptr && !tsel) {
 		// colour-only loss: the specialised instantiation (a device that needs TSEL takes the general kernel, which treats NULL as zero)
 		if (fx) { if (flags) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, true, true>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, true, true>); }
 		else { if (flags) GSR_LAUNCH_CB(composite_bwd_quarter_kernel<true, false, false, true>); else GSR_LAUNCH_CB(composite_bwd_quarter_kernel<false, false, false, true>); }

@@ -1613,8 +1613,9 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(uint64_t* __restrict__
                                                           uint32_t* __restrict__ point_list, const GsSortQ* __restrict__ q,
                                                           const uint2* __restrict__ sort_items, uint32_t sort_cap,
                                                           const uint2* __restrict__ fall_items, uint32_t fall_cap,
-                                                          const GsCtl* __restrict__ ctl, uint32_t cap, uint32_t* __restrict__ err_dst)
+                                                          const GsCtl* ctl, uint32_t cap, uint32_t* err_dst, uint32_t* host_err)
 {
+	// (ctl and err_dst point into the same control block: neither is __restrict__)
 	__shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave running offsets
 	__shared__ uint32_t s_tot[4];
 	__shared__ uint32_t s_maxrun;
@@ -1622,8 +1623,12 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(uint64_t* __restrict__
 	if (nb_ > cap || mt_ <= GSR_SORT_LDS_MAX) return;
 	// the pipeline's overflow flag (a SortQueueLayout bound violated: items were dropped, point_list is not sorted) is final
 	// here -- every kernel that can raise it ran before this one: mirrored into the frame's control words (bit 1 of
-	// err_overflow), where debug-mode calls and gsr_inspect_counts see it
-	if (blockIdx.x == 0 && threadIdx.x == 0 && q->err != 0u) atomicOr(err_dst, 2u);
+	// err_overflow), where debug-mode calls and gsr_inspect_counts see it, and into the device's sticky host word, which the NEXT
+	// gsr_forward / gsr_backward of the process checks on entry: a non-debug run fails loudly too, one call late
+	if (blockIdx.x == 0 && threadIdx.x == 0 && q->err != 0u) {
+		atomicOr(err_dst, 2u);
+		if (host_err != nullptr) *host_err = 2u;
+	}
 	const uint32_t nf = min(nfq_, fall_cap);
 	for (uint32_t it = blockIdx.x; it < nf; it += gridDim.x) {
 		const uint2 sg = fall_items[it];
@@ -1670,7 +1675,7 @@ size_t sort_queue_bytes(size_t R, int T) { return SortQueueLayout(R, T).total; }
 #define GSR_RADIX_RK_SHORT 16   // the per-list kernel's register-resident key count for the shorter class of long lists (x 256 keys)
 #endif
 void launch_tile_sort(int T, bool with_short, int long_level, const uint2* ranges, uint64_t* keys, uint64_t* keys2,
-                      uint32_t* point_list, char* queue, size_t R, const GsCtl* ctl, uint32_t cap, hipStream_t s)
+                      uint32_t* point_list, char* queue, size_t R, GsCtl* ctl, uint32_t cap, uint32_t* host_err, hipStream_t s)
 {
 	// <= GSR_SORT_LDS_MAX keys: register bitonic network, one wave per tile (tile_sort_kernel).
 	// long_level 1 (lists up to GSR_SORT_GIANT keys, e.g. the C4 regime: every tile ~3.7 k): one 256-thread workgroup per tile
@@ -1716,7 +1721,7 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 	hipLaunchKernelGGL(segment_partition_kernel, dim3(128), dim3(GSR_PART_THREADS), 0, s, keys, keys2, q, sort_items, sort_cap,
 	                   seg_items, &q->n_seg, seg_cap, fall_items, &q->n_fall, ctl, cap);
 	hipLaunchKernelGGL(bucket_sort_kernel, dim3(2048), dim3(256), 0, s, keys, keys2, point_list, q, sort_items, sort_cap, fall_items, seg_cap, ctl, cap,
-	                   const_cast<uint32_t*>(&ctl->err_overflow));
+	                   &ctl->err_overflow, host_err);
 }
 
 
@@ -1734,6 +1739,7 @@ void launch_tile_sort(int T, bool with_short, int long_level, const uint2* range
 // same records from the same 4 MiB L2.
 // NOCULL (debugging / parity A/B, gsr_set_option("cull", 0)): every staged instance is evaluated by every wave and
 // the pcut pre-test is replaced by the domain bound of gs_exp -- the culling must not change a single bit.
+#ifdef GSR_AB_VARIANTS   // the per-wave (8x8) walk: superseded by the per-quarter kernel below, kept for A/B builds only (make AB=1)
 template <bool NOCULL>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(
     int T, int chunk, int gx, int W, int H, const uint2* __restrict__ ranges,
@@ -1870,6 +1876,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 	med_pos_out[(size_t)tile * GSR_TILE_PIX + tid] = med_final;
 	if (tid == 0 && staged_out != nullptr) staged_out[tile] = (uint32_t)staged;
 }
+
+#endif   // GSR_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
 // composite_fwd with per-quarter instance lists.  In the kernel above a wave (one 8x8 pixel block) walks every staged
@@ -2099,11 +2107,14 @@ void launch_composite_fwd(const ImgLayout& il, int W, int H, const uint2* ranges
 #define GSR_LAUNCH_FWD(K)                                                                                              \
 	hipLaunchKernelGGL(K, dim3(chunk * 8), dim3(256), 0, s, il.T, chunk, il.gx, W, H, ranges, point_list, recs, out_color, \
 	                   out_depth, out_median, out_opacity, final_T, n_contrib, med_pos, ctl, cap, max_sorted, tile_order, staged_out)
+#ifdef GSR_AB_VARIANTS
 	if (wave_lists) {
 		const GsCtl* ctl = ctl_;
 		if (nocull) GSR_LAUNCH_FWD(composite_fwd_kernel<true>);
 		else GSR_LAUNCH_FWD(composite_fwd_kernel<false>);
-	} else {
+	} else
+#endif
+	{   // (a build without GSR_AB_VARIANTS refuses fwd_variant 1 in gsr_forward: wave_lists is false here)
 		GsCtl* ctl = ctl_;
 		if (fast_exp) {
 			if (nocull) GSR_LAUNCH_FWD((composite_fwd_quarter_kernel<true, true>));

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .options import for_forward as _options_for_forward, note_grad_mode as _note_grad_mode
+from .options import clear_grad_mode as _clear_grad_mode, for_forward as _options_for_forward, note_grad_mode as _note_grad_mode
 from .rasterizer import _image_grads, _run_guarded
 
 ACT_OPACITY_SIGMOID = 1
@@ -72,5 +72,8 @@ class FusedGaussianRasterizer(nn.Module):
         f_dc = f_dc.reshape(P, 1, 3)
         f_rest = f_rest.reshape(P, -1, 3)
         _note_grad_mode(torch.is_grad_enabled())
-        return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, raw_opacities.reshape(P, 1), raw_scales,
-                                            raw_rotations, self.raster_settings, self.activations)
+        try:
+            return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, raw_opacities.reshape(P, 1), raw_scales,
+                                                raw_rotations, self.raster_settings, self.activations)
+        finally:
+            _clear_grad_mode()

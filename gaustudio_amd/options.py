@@ -84,6 +84,12 @@ def note_grad_mode(enabled: bool):
     _tls.grad_enabled = bool(enabled)
 
 
+def clear_grad_mode():
+    """The wrappers' `finally`: a forward that raised before reading the note must not leave it behind for the next direct
+    Function.apply of this thread (a stale False would make that training forward forward_only)."""
+    _tls.grad_enabled = None
+
+
 def take_grad_mode():
     """The grad mode noted for THIS call (True when the Function was applied directly, without the wrapper)."""
     g = getattr(_tls, "grad_enabled", None)

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from .options import for_forward as _options_for_forward, note_grad_mode as _note_grad_mode
+from .options import clear_grad_mode as _clear_grad_mode, for_forward as _options_for_forward, note_grad_mode as _note_grad_mode
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -108,8 +108,11 @@ class _RasterizeGaussians(torch.autograd.Function):
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     _note_grad_mode(torch.is_grad_enabled())      # torch.no_grad(): a forward-only call (nothing kept for a backward)
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+    try:
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings)
+    finally:
+        _clear_grad_mode()                        # (the note is one-shot; a forward that raised early must not leave it behind)
 
 
 def _absent():

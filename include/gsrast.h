@@ -222,16 +222,21 @@ int gsr_sh_grad_from_packed(int P, int D, int M, int N, const float* means3D, co
  * same terms in another order); they exist for A/B measurements and parity tests:
  *   "tight_binning" 1|0  bin each Gaussian into the tight sub-rect of the reference's getRect square (default 1);
  *   "cull"          1|0  block-level culling + pcut pre-test in composite_fwd (default 1);
- *   "fwd_variant"   0 = composite_fwd with per-quarter (4x4 pixel) instance lists (default), 1 = per-wave (8x8) walk;
+ *   "fwd_variant"   0 = composite_fwd with per-quarter (4x4 pixel) instance lists (default), 1 = per-wave (8x8) walk
+ *                        (A/B builds only, see "ab_variants");
  *   "speculative"   1|0  enqueue binning + compositing before the host has read the instance count (default 1);
  *   "bwd_variant"   -1 = auto (gsr_selftest), bit 0 = keep the select on T in composite_bwd, bit 1 = the per-wave
- *                        (8x8) kernel instead of the per-quarter one;
+ *                        (8x8) kernel instead of the per-quarter one (A/B builds only);
+ *   "ab_variants"   read-only: 1 if the superseded per-wave compositing kernels were compiled in (csrc/Makefile AB=1).  The
+ *                        shipped library is built without them: asking for fwd_variant 1 / bwd_variant bit 1 is then GSR_ERR_ARG;
  *   "fast_exp"      0|1  process default of gsr_options.fast_exp (below);
  *   "tile_order"    1|0  (GSR_TILE_ORDER) backward of a SKEWED frame (longest tile list > 1024 entries and > 4x the mean): run
  *                        the tiles longest walk first instead of in XCD bands (two small extra launches; changes no result bit);
  *   "roctx"         0|1  (GSR_ROCTX) wrap every stage of gsr_forward / gsr_backward in a roctx range ("gsr.preprocess_fwd",
  *                        "gsr.scan", ... ) for rocprofv3 --marker-trace timelines; the marker library is dlopen()ed, get
  *                        returns 1 only if it was found;
+ *   "forget_forwards" (set only) drop the host-side memory of which mode each live forward ran in: the next gsr_backward of such buffers
+ *                        reads the forward's own 4-byte control word from the image buffer instead (tests; always correct, one small sync);
  *   "bin_capacity"  n    binning capacity (instances) assumed by the next gsr_forward on the current device
  *                        (0 = forget; tests use a small n to force the re-allocate-and-relaunch path);
  *   "tile_row_lo", "tile_row_hi"  tile-grid sharding of ONE view across processes: only the 16-pixel

@@ -87,6 +87,28 @@ def test_no_cpu_fallback_and_shape_error():
         r.markVisible(m)
 
 
+def test_a_forward_that_raises_early_leaves_no_stale_grad_mode_note(monkeypatch):
+    """the wrappers note the caller's grad mode in a one-shot thread-local that Function.forward consumes.  A forward that
+    raises BEFORE consuming it (here: the options lookup fails) under torch.no_grad() must not leave `False` behind -- the next direct
+    `_RasterizeGaussians.apply` on this thread would silently become forward_only and its backward be refused."""
+    import sys
+    from gaustudio_amd import rasterizer as gr
+    go = sys.modules["gaustudio_amd.options"]          # (the package re-exports the class `options` under the module's name)
+    r = _rasterizer()
+    m, o = torch.zeros(2, 3), torch.zeros(2, 1)
+
+    def boom(_needs):
+        raise RuntimeError("options lookup failed")
+    monkeypatch.setattr(gr, "_options_for_forward", boom)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="options lookup failed"):
+        r(m, m, o, shs=torch.zeros(2, 1, 3), scales=torch.ones(2, 3), rotations=torch.ones(2, 4))
+    assert go.take_grad_mode() is True          # nothing noted: a direct Function.apply counts as "grad enabled"
+    monkeypatch.undo()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="ROCm devices only"):     # consumed inside: nothing left either
+        r(m, m, o, shs=torch.zeros(2, 1, 3), scales=torch.ones(2, 3), rotations=torch.ones(2, 4))
+    assert go.take_grad_mode() is True
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "gaustudio_amd")
     for base, _, files in os.walk(pkg):

@@ -17,7 +17,7 @@ import gaustudio_amd
 from gaustudio_amd import _C, scenes
 
 import attribution
-from util import hip_backward_raw, hip_forward, scene_kwargs, to_np
+from util import ab_variants, hip_backward_raw, hip_forward, scene_kwargs, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -111,7 +111,7 @@ def test_backward_must_run_in_the_mode_of_its_forward():
         finally:
             _C.set_option("fast_exp", 0)
     assert not torch.equal(want_fast["dL_dmeans3D"], want_exact["dL_dmeans3D"])
-    with pytest.raises(RuntimeError, match="fwd_variant 0"):
+    with pytest.raises(RuntimeError, match="fwd_variant 0" if ab_variants() else "not in this build"):
         with gaustudio_amd.options(fast_exp=True, fwd_variant=1):
             hip_forward(sc, cam, 3, kw)
 
@@ -122,6 +122,8 @@ def test_ab_variants_without_a_fast_exp_kernel_run_under_the_default_mode():
     way to the variant: the call runs in the reproducible mode, bit-identical to the per-quarter kernels in that mode, and its
     backward follows the forward's recorded mode."""
     from gaustudio_diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    if not ab_variants():
+        pytest.skip("libgsrast.so is the shipped build: the per-wave A/B kernels are compiled only with `make -C gaustudio_amd/csrc AB=1`")
     cam = scenes.make_camera(160, 96)
     sc = scenes.make_scene(3000, cam, seed=2)
     kw = scene_kwargs(sc, True, False)

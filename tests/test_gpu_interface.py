@@ -299,11 +299,14 @@ def test_forward_only_skips_what_only_a_backward_reads_and_refuses_one():
     # the refusal also covers the SH stage alone (parts without MAIN reads the jacobians the forward did not keep) ...
     with pytest.raises(RuntimeError, match="forward_only"):
         hip_backward_raw(fo, sc, cam, 3, kw, scenes.make_output_grads(cam), options={}, parts=2)
-    # ... and does not depend on the host-side memory of recent forwards (64 entries, keyed by the image buffer): after 70 other
-    # forwards the entry is gone; a debug backward reads the forward's own record in the image buffer
+    # ... and does not depend on the host-side memory of the forwards: with that memory dropped, a backward (debug or not) reads the
+    # forward's own record in the image buffer (round 6; rounds 4-5 kept 64 entries and only a debug backward looked at the device)
     keep = [hip_forward(scenes.make_scene(64, cam, seed=s), cam, 0, scene_kwargs(scenes.make_scene(64, cam, seed=s), True, False))["img"] for s in range(70)]
     with pytest.raises(RuntimeError, match="forward_only"):
         hip_backward_raw(fo, sc, cam, 3, kw, scenes.make_output_grads(cam), debug=True)
+    _C.set_option("forget_forwards", 1)
+    with pytest.raises(RuntimeError, match="forward_only"):
+        hip_backward_raw(fo, sc, cam, 3, kw, scenes.make_output_grads(cam))
     del keep
     # through autograd: a no_grad render followed by a differentiable one of the same rasterizer object
     rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
@@ -341,3 +344,46 @@ def test_staged_instance_count_of_composite_fwd():
             assert staged == hs["num_binned"]
         else:
             assert staged < 0.8 * hs["num_binned"] and int(total.max()) > 1024
+
+
+def test_plain_c_abi_backward_follows_its_forwards_mode_with_100_forwards_outstanding():
+    """VERDICT r5 #7 / ADVICE r5: a plain-C-ABI caller (gsr_forward / gsr_backward, no gsr_options) that mixes the two exp modes in
+    one process through the process default and keeps 100 forwards alive before running their backwards: every backward runs in
+    ITS forward's mode whatever the process default says by then -- from the host-side map (one entry per live image buffer; it
+    was a 64-entry ring that silently fell back to the process default) and, with the map dropped, from the forward's own 4-byte
+    control word in the image buffer.  Gradients bit-equal to the per-mode references."""
+    from gaustudio_amd import _C
+    cam = scenes.make_camera(160, 96)
+    sc = scenes.make_scene(3000, cam, seed=2)
+    kw = scene_kwargs(sc, True, False)
+    grads = scenes.make_output_grads(cam)
+    keys = ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations")
+    old = _C.get_option("fast_exp")
+    try:
+        want = {}
+        for mode in (0, 1):
+            _C.set_option("fast_exp", mode)
+            st = hip_forward(sc, cam, 3, kw)
+            want[mode] = hip_backward_raw(st, sc, cam, 3, kw, grads, options=dict(fast_exp=mode))
+        assert not torch.equal(want[0]["dL_dmeans3D"], want[1]["dL_dmeans3D"])
+        rng = np.random.default_rng(0)
+        modes = [int(m) for m in rng.integers(0, 2, 100)]
+        states = []
+        for m in modes:                                         # 100 forwards, interleaved modes, all kept alive
+            _C.set_option("fast_exp", m)
+            states.append(hip_forward(sc, cam, 3, kw))          # rasterize_gaussians without options -> plain gsr_forward
+        assert len({int(s["img"].data_ptr()) for s in states}) == 100
+        for forget in (False, True):
+            for i in (list(range(100)) if not forget else [0, 1, 2, 50, 98, 99]):
+                if forget:
+                    _C.set_option("forget_forwards", 1)         # the map does not know this buffer: the control word is read
+                _C.set_option("fast_exp", 1 - modes[i])         # the process default now says the OTHER mode
+                g = hip_backward_raw(states[i], sc, cam, 3, kw, grads)     # plain gsr_backward, no options, no debug
+                for k in keys:
+                    assert torch.equal(g[k], want[modes[i]][k]), (forget, i, modes[i], k)
+        # naming the other mode explicitly is still an error, map or no map
+        _C.set_option("forget_forwards", 1)
+        with pytest.raises(RuntimeError, match="fast_exp differs"):
+            hip_backward_raw(states[0], sc, cam, 3, kw, grads, options=dict(fast_exp=1 - modes[0]))
+    finally:
+        _C.set_option("fast_exp", old)

@@ -62,6 +62,13 @@ def hip_forward(sc, cam, D, kw, scale_modifier=1.0, bg=None, prefiltered=False, 
     return st
 
 
+def ab_variants():
+    """Were the superseded per-wave compositing kernels (fwd_variant 1, bwd_variant bit 1) compiled into libgsrast.so?  The shipped
+    library is built without them (csrc/Makefile AB=1 adds them); the tests run their A/B legs only where they exist."""
+    from gaustudio_amd import _C
+    return _C.get_option("ab_variants") == 1
+
+
 def to_np(t):
     return t.detach().cpu().numpy()
 
