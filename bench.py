@@ -27,6 +27,7 @@ import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -404,6 +405,32 @@ def self_launch(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def other_workloads(names, steps=10, warmup=3, settle=30, exact=False, fast=False):
+    """{name: {ms_per_step, value, unit, steps, stage_ms, roofline_frac}} of `python bench.py --workload <name> --no-extras ...` run as
+    child processes (one at a time, after the headline's timed region; the parent's GPU work is finished and synchronised)."""
+    out = {}
+    for name in names:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", str(warmup),
+               "--settle", str(settle), "--no-extras", "--no-cpu-baseline", "--no-ref-ab"] + (["--exact"] if exact else []) + (["--fast-exp"] if fast else [])
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not rows:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            j = json.loads(rows[-1])
+            out[name] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"], "steps": j["steps"], "warmup": j["warmup"],
+                         "settle_steps": j.get("settle_steps"), "stage_ms": j.get("stage_ms"),
+                         "composite_fwd_frac_of_hbm": (j.get("roofline") or {}).get("frac"),
+                         "instances_binned": j["config"].get("instances_binned"), "visible": j["config"].get("visible"),
+                         "workload": j["config"]["workload"], "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:  # noqa: BLE001  (never take the headline down)
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -778,6 +805,11 @@ def main():
                 "note": "the same step with a loss on the colour image alone (--loss color): the gradients of depth / median / opacity are "
                         "absent -- NULL through the C ABI, no zero planes materialised (the reference reads all four, backward.cu:476-483, "
                         "and its autograd fills 41 MB of zeros per 1080p step), nothing loaded for them, composite_bwd's colour-only instantiation"}
+
+    if not multi and not a.no_extras and not rotating_headline and a.workload == "C3" and not a.fwd_only and a.loss == "all":
+        # the 8-GPU configurations on the driver's clock too.  One view of C4 / C4-inside / C5 each, a handful of steps
+        # behind the headline, each in a child process of this very script (its own scene, its own settle steps; `--no-extras` there)
+        extras["other_workloads"] = other_workloads(("C4", "C4-inside", "C5"), exact=a.exact, fast=a.fast_exp)
 
     # instance counts of this rank's view (they drive every composite-stage byte count): the reference-defined
     # num_rendered and the instances actually binned; per-tile list lengths
