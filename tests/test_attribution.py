@@ -184,7 +184,7 @@ def test_median_crossing_inside_its_window_is_attributed_either_way():
     """T (1 - alpha) within WIN_MEDIAN of 0.5 at the first Gaussian: one implementation records the first Gaussian as the median,
     the other the second (whose T is that product).  Both are leaves; a median id with no such event is not attributed."""
     tol = np.concatenate([np.full(7, 4e-6), [0.5]])
-    for a0 in (0.5 * (1 + 4e-6), 0.5 * (1 - 4e-6)):            # test_T just below / just above 0.5
+    for a0 in (0.5 * (1 + 1.2e-7), 0.5 * (1 - 1.2e-7)):            # test_T just below / just above 0.5
         st = _hand_state(0.3)
         st["conic_opacity"][0, 3] = a0
         al = [float(st["conic_opacity"][k, 3]) for k in range(3)]
@@ -196,6 +196,10 @@ def test_median_crossing_inside_its_window_is_attributed_either_way():
         res = at.attribute_pixel(st, 0, 5, 5, first, second, tol, tol)
         assert res["attributed"] and res["kinds"] == ["median"] and res["events"][0][0] == 0 and res["events"][0][2] < at.WIN_MEDIAN
         assert at.attribute_pixel(st, 0, 5, 5, second, first, tol, tol)["attributed"]
+        # the reference's hole (forward.cu:368): T (1 - alpha) == 0.5 exactly fires at neither contributor -> the pixel keeps (15, 0, 0)
+        never = _pixel8(al, rgb, dep, [0, 1, 2], None)
+        res = at.attribute_pixel(st, 0, 5, 5, first, never, tol, tol)
+        assert res["attributed"] and set(res["kinds"]) <= {"median", "median_exact_half"} and "median_exact_half" in res["kinds"]
         assert not at.attribute_pixel(st, 0, 5, 5, first, third, tol, tol)["attributed"]      # the third Gaussian is never the median
         assert not at.attribute_pixel(st, 0, 5, 5, first, first, tol, tol)["attributed"]
     # well outside the window: the second Gaussian as median is a bug, not a flip
@@ -206,7 +210,7 @@ def test_median_crossing_inside_its_window_is_attributed_either_way():
     assert not at.attribute_pixel(st, 0, 5, 5, _pixel8(al, rgb, dep, [0, 1, 2], 0), _pixel8(al, rgb, dep, [0, 1, 2], 1), tol, tol)["attributed"]
     # the "forced next" branch with no next contributor: the median stays unset in that implementation
     st = _hand_state(0.3)
-    st["conic_opacity"][0, 3] = 0.5 * (1 + 4e-6)
+    st["conic_opacity"][0, 3] = 0.5 * (1 + 1.2e-7)
     st["ranges"] = np.array([[0, 1]], np.uint32)
     al = [float(st["conic_opacity"][0, 3])]
     a = _pixel8(al, rgb[:1], dep[:1], [0], 0)

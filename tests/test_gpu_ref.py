@@ -175,6 +175,7 @@ def _noise_floor(hs, runs, W, H):
                                        radii_a=a["radii"].numpy())
     fl["attribution"] = {k: rep[k] for k in ("flagged", "attributed", "by_kind", "max_margin")}
     fl["attribution"]["unattributed"] = len(rep["unattributed"])
+    fl["attribution"]["unattributed_detail"] = rep["unattributed"][:3]
     fl["grads_build_vs_build"], fl["grads_run_vs_run"] = {}, {}
     for k in GRAD_KEYS:
         if a[k].numel() == 0:
@@ -214,7 +215,7 @@ def test_hip_vs_reference_kernels_at_baseline_configs(request, P, W, H, D, fast_
     if not fast_exp:
         floor = _noise_floor(hs, runs, W, H)
         _dump_parity(config, floor, section="reference_vs_reference")
-        assert floor["attribution"]["unattributed"] == 0, "two builds of the reference differ at a pixel that is no threshold event"
+        assert floor["attribution"]["unattributed"] == 0, f"two builds of the reference differ at a pixel that is no threshold event: {floor['attribution']['unattributed_detail']}"
     if config == "C3" and not fast_exp:
         # report: how often the reference's backward would route the median-depth gradient differently
         stats["median_gradient_census"] = attribution.median_gradient_census(hs, W, H)
