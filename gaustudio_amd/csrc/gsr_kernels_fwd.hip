@@ -139,18 +139,29 @@ __device__ __forceinline__ uint32_t gs_sh_to_rgb(const float* sh, float3 p_orig,
 #ifndef GSR_PRE_WAVES
 #define GSR_PRE_WAVES 4   // waves per SIMD the register allocation is held to (round 5: 5 gains 0.015 ms at C4-inside and loses at C3 / C4, 6 spills)
 #endif
+#ifndef GSR_PRE_COOP
+#define GSR_PRE_COOP 1    // wave-cooperative SH rows through LDS (0: every lane fetches its own row, rounds 1-5)
+#endif
+#ifndef GSR_PRE_COOP_LD
+#define GSR_PRE_COOP_LD(p) gs_ld_stream(p)   // nontemporal: every line is read once, by one instruction (A/B: (*(p)) = plain loads)
+#endif
+#ifndef GSR_PRE_COOP_MIN
+#define GSR_PRE_COOP_MIN 32   // visible Gaussians a wave needs for the cooperative copy; below, each visible lane fetches its own row
+#endif
 template <int D, bool RAW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAVES, GSR_PRE_WAVES))) void preprocess_fwd_kernel(
     int P, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     const float* __restrict__ shs_rest, int act_arg, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const GsCam* __restrict__ cam, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
-    int gx, int gy, int prefiltered, int sh_vec4, int tight, int band_lo, int band_hi, int* __restrict__ radii,
+    int gx, int gy, int prefiltered, int sh_vec4, int sh_coop, int tight, int band_lo, int band_hi, int* __restrict__ radii,
     GsRec* __restrict__ recs, float* __restrict__ shjac, uint4* __restrict__ binfo,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ bsums, uint32_t* __restrict__ refsums,
     uint32_t* __restrict__ tile_count, GsCtl* __restrict__ ctl)
 {
 	constexpr int NC = (D + 1) * (D + 1);
+	constexpr int PRE_SLAB = (GSR_PRE_COOP && D == 3 && !RAW) ? 32 * 52 : 4;   // floats per wave: 32 padded coefficient rows (cooperative copy below)
+	__shared__ __attribute__((aligned(16))) float s_rows[4][PRE_SLAB];
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	const int act = RAW ? act_arg : 0;
 	bool vis = false;
@@ -248,8 +259,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_PRE_WAV
 			depth = p_view.z;
 			vis = true;
 		} while (0);
-		if (vis && colors_precomp == nullptr) load_sh();
 	}
+	// wave-uniform choice between the two ways of fetching the coefficient rows (below)
+	const unsigned long long vmask = __ballot(vis && colors_precomp == nullptr);
+	const bool coop_wave = GSR_PRE_COOP && !RAW && D == 3 && sh_coop && __popcll(vmask) >= GSR_PRE_COOP_MIN;
+	if (vis && colors_precomp == nullptr && !coop_wave) load_sh();
+#if GSR_PRE_COOP
+	// Round 6 (north_star: "coalesced HBM loads of xyz/scale/rot/SH"): WAVE-COOPERATIVE coefficient rows.  With one
+	// lane fetching its own 192-B row, each of the lane's twelve dwordx4 loads touches 64 different rows (16 B of each): 768 cache-line
+	// requests per wave for 96 lines of data.  Here the wave copies the rows of its 64 consecutive Gaussians as ONE contiguous
+	// 12-KiB chunk (twelve fully coalesced 1-KiB loads; a float4 whose row is not visible is not requested -- the late,
+	// visibility-gated request of round 5 is kept), transposes it through a padded LDS slab of 32 rows in two halves (a 64-row slab
+	// would hold the kernel to 3 waves per SIMD: 13.3 KiB x 16 waves > 160 KiB), and every lane picks its row out of the slab.
+	// Only when a row is exactly the (D+1)^2 coefficients used (M == NC, 16-B aligned): lower degrees of a 16-coefficient tensor
+	// would over-fetch and keep the per-lane path, and so does a wave with fewer than GSR_PRE_COOP_MIN visible Gaussians (a camera
+	// inside the scene sees 16 %: the copy's barriers and LDS passes for ten rows cost more than they save: C4-inside 0.176 ->
+	// 0.190 ms without this gate).  Same values in the same registers: no result bit changes.
+	// Measured (profiles/r06_preprocess_fwd_experiments.txt): C3 0.0712 -> 0.0688 (plain loads) -> 0.0657 ms (nontemporal);
+	// C4 0.373 -> 0.362 -> 0.3446; C5 0.179 -> 0.155; C4-inside 0.176 -> 0.177.  Not kept: the 64-B records of a dense wave through
+	// the same slab as four coalesced 1-KiB stores (C3 0.0642, C4 0.363: +5 % where it matters); gates of 16 / 48 instead of 32
+	// visible Gaussians (no difference).
+	if constexpr (!RAW && D == 3) if (coop_wave) {
+		constexpr int RF = NC * 3, RFP = gs_row_stride<RF>(), NV = (RF * 64) / 4 / 64;   // NV float4 per lane for the wave's 64 rows
+		static_assert(32 * RFP <= PRE_SLAB, "slab");
+		{
+			const int lane = threadIdx.x & 63;
+			float* slab = s_rows[threadIdx.x >> 6];
+			const float4* chunk = reinterpret_cast<const float4*>(shs + (size_t)(blockIdx.x * 256 + (threadIdx.x & ~63)) * RF);
+			float4 st[NV];
+#pragma unroll
+			for (int it = 0; it < NV; it++) {
+				const int j = it * 64 + lane;           // float4 j of the chunk lies inside row (4 j) / RF (RF % 4 == 0)
+				st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+				if ((vmask >> ((4 * j) / RF)) & 1ull) st[it] = GSR_PRE_COOP_LD(chunk + j);
+			}
+#pragma unroll
+			for (int half = 0; half < 2; half++) {
+#pragma unroll
+				for (int it = 0; it < NV / 2; it++) {
+					const int j = it * 64 + lane;       // float4 j of this half's 32 rows
+					const int r = (4 * j) / RF;
+					*reinterpret_cast<float4*>(slab + r * RFP + (4 * j - r * RF)) = st[half * (NV / 2) + it];
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				if ((lane >> 5) == half) gs_row_from_lds<RF>(slab + (lane & 31) * RFP, sh);
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	}
+#endif
 
 	uint32_t my_tiles = 0, dead = 0;
 	if (vis) {
@@ -345,12 +404,14 @@ void launch_preprocess_fwd(const FwdArgs& a, const GsCam* cam, const ImgLayout& 
 	const float focal_x = a.W / (2.0f * a.tan_fovx);
 	const int sh_vec4 = (a.shs != nullptr && ((uintptr_t)a.shs % 16 == 0) && ((size_t)a.M * 12) % 16 == 0) ? 1 : 0;
 	const int D = a.colors_precomp ? 0 : a.D;
+	// cooperative rows: a row must be exactly the coefficients the degree uses (else the copy over-fetches) and 16-B aligned
+	const int sh_coop = (sh_vec4 && !a.colors_precomp && a.shs_rest == nullptr && a.act == 0 && a.M == (D + 1) * (D + 1) && D == 3) ? 1 : 0;   // (degree 3 of a 16-coefficient tensor: the training / extraction case)
 	dim3 grid((a.P + 255) / 256), block(256);
 #define GSR_LAUNCH_PRE(DEG, RAW)                                                                                   \
 	hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, RAW>), grid, block, 0, s, a.P, a.M, a.means3D, a.scales,        \
 	                   a.scale_modifier, a.rotations, a.opacities, a.shs, a.shs_rest, a.act, a.cov3D_precomp,       \
 	                   a.colors_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, focal_x, focal_y, il.gx, il.gy,     \
-	                   a.prefiltered, sh_vec4, a.tight, a.band_lo, a.band_hi > 0 ? a.band_hi : il.gy, radii, recs, shjac, binfo,   \
+	                   a.prefiltered, sh_vec4, sh_coop, a.tight, a.band_lo, a.band_hi > 0 ? a.band_hi : il.gy, radii, recs, shjac, binfo,   \
 	                   tiles_touched, bsums, refsums, tile_count, ctl)
 #define GSR_LAUNCH_PRE_D(RAW)                          \
 	switch (D) {                                       \
