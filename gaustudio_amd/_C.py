@@ -201,7 +201,7 @@ def sh_grad_from_packed(means3D, campos, msgs, offsets, degree, out):
     return out
 
 
-def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None, colors_out=None):
+def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None, colors_out=None, band_split=0, band_hook=None, class_hook=None):
     """One-shot destination tensors [dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations] for the next
     rasterize_gaussians_backward whose inputs [means3D, sh, scales, rotations] have the data pointers `keys`
     (0 / empty = any); see gaustudio_amd/parallel.py.  With sh_chunks > 1 and a hook, the SH stage of that backward
@@ -210,8 +210,28 @@ def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None, colors_out=None):
     dL_dsh is None (outs may then be [] or five tensors whose second is ignored); a `hook` given together with colors_out is
     called (no arguments) once the geometry stage -- which then already leaves the masked colour gradient in colors_out -- has
     been enqueued and BEFORE the SH-direction stage: the caller starts the all-gather of the slot there.
+    band_split > 0 with band_hook (and colors_out + hook): that backward runs BANDED (include/gsrast.h GSR_BWD_PART_BAND_*): the image
+    is cut at tile row band_split; class_hook(first[P], second[P]) receives the two Gaussian classes of the cut before anything runs,
+    band_hook() is called once the first band -- compositing above the cut + the per-Gaussian stage of the Gaussians that end there,
+    whose rows of colors_out are final then -- has been enqueued, hook() after the second band.  Same bits as the unbanded backward.
     [] without colors_out disarms."""
-    native().set_grad_arena(list(outs), [int(k) for k in keys], int(sh_chunks), hook, colors_out)
+    native().set_grad_arena(list(outs), [int(k) for k in keys], int(sh_chunks), hook, colors_out, int(band_split), band_hook, class_hook)
+
+
+def band_classes(radii, geom_buffer, split_tile_row):
+    """(first[P], second[P]) int32: the two Gaussian classes of a banded backward cut at tile row `split_tile_row`
+    (include/gsrast.h gsr_band_classes)."""
+    import torch
+    L = lib()
+    P = int(radii.shape[0])
+    first = torch.empty(P, dtype=torch.int32, device=radii.device)
+    second = torch.empty(P, dtype=torch.int32, device=radii.device)
+    with torch.cuda.device(radii.device):
+        rc = L.gsr_band_classes(ctypes.c_int(P), _ptr(radii), _ptr(geom_buffer), ctypes.c_int(int(split_tile_row)), _ptr(first), _ptr(second),
+                                _stream(radii.device))
+    if rc < 0:
+        raise _err(L, rc)
+    return first, second
 
 
 def set_option(name, value):

@@ -847,7 +847,19 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	float* rows = reinterpret_cast<float*>(scratch + wl.rows);
 	uint8_t* row_flags = reinterpret_cast<uint8_t*>(scratch + wl.flags);
 
+	// banded backward (GSR_BWD_PART_BAND_FIRST / _SECOND; sh_g0 carries the split tile row): see include/gsrast.h
+	const int band_phase = (parts & GSR_BWD_PART_BAND_FIRST) ? 0 : ((parts & GSR_BWD_PART_BAND_SECOND) ? 1 : -1);
+	int band_split = 0;
+	if (band_phase >= 0) {
+		if ((parts & GSR_BWD_PART_BAND_FIRST) && (parts & GSR_BWD_PART_BAND_SECOND))
+			return fail(GSR_ERR_ARG, "gsr_backward: GSR_BWD_PART_BAND_FIRST and _SECOND are two calls", __FILE__, __LINE__);
+		if (!(parts & GSR_BWD_PART_MAIN) || (parts & GSR_BWD_PART_SH))
+			return fail(GSR_ERR_ARG, "gsr_backward: a band call runs GSR_BWD_PART_MAIN only (the SH stage follows the second band as its own call)", __FILE__, __LINE__);
+		band_split = sh_g0 < 0 ? 0 : (sh_g0 > il.gy ? il.gy : sh_g0);
+	}
 	BwdArgs a;
+	a.cls_mode = band_phase + 1;
+	a.cls_split = band_split;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
 	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
 	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
@@ -899,15 +911,17 @@ static int backward_impl(const gsr_options* opt, int parts, int sh_g0, int sh_g1
 	bgv.flag_dst = reinterpret_cast<uint32_t*>(bg_dev + 8);
 	bgv.flag = flagged ? 1u : 0u;
 	bgv.tile_order = nullptr;
+	bgv.tile_lo = band_phase == 1 ? (uint32_t)band_split * (uint32_t)il.gx : 0u;
+	bgv.tile_hi = band_phase == 0 ? (uint32_t)band_split * (uint32_t)il.gx : 0xffffffffu;
 	if (R <= 0) {
 		const float* const src[4] = {nullptr, nullptr, nullptr, nullptr};
 		float* const dst[4] = {nullptr, nullptr, nullptr, nullptr};
 		const int n[4] = {0, 0, 0, 0};
 		HIP_TRY(stage_small(src, dst, n, s, bgv.flag_dst, bgv.flag));
 	}
-	if (flagged)
-		HIP_TRY(hipMemsetAsync(row_flags, 0, (size_t)R, s));
-	else
+	if (flagged) {
+		if (band_phase != 1) HIP_TRY(hipMemsetAsync(row_flags, 0, (size_t)R, s));   // (the second band adds to the first band's flags)
+	} else
 		row_flags = nullptr;
 
 	tm.mark();
@@ -1018,6 +1032,17 @@ int gsr_backward_ex(const gsr_options* opt, int parts, int sh_g0, int sh_g1, int
 	                     radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dpix_median_depth,
 	                     dL_dpix_final_opacity, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dsh_rest,
 	                     dL_dscale, dL_drot, scratch, debug, stream);
+}
+
+int gsr_band_classes(int P, const int* radii, const char* geom_buffer, int split_tile_row, int* first, int* second, void* stream)
+{
+	g_err.clear();
+	if (P <= 0) return GSR_OK;
+	if (!radii || !geom_buffer) return fail(GSR_ERR_ARG, "gsr_band_classes: NULL argument", __FILE__, __LINE__);
+	const GeomLayout gl((size_t)P);
+	launch_band_classes(P, radii, reinterpret_cast<const GsRec*>(geom_buffer + gl.recs), split_tile_row, first, second, (hipStream_t)stream);
+	STAGE_CHECK("band_classes", 0, (hipStream_t)stream);
+	return GSR_OK;
 }
 
 int gsr_sh_grad_from_colors(int P, int D, int M, int N, const float* means3D, const float* campos, const float* colors,

@@ -150,6 +150,10 @@ struct BwdArgs {
 	const int* radii;
 	const float* shs_rest;
 	int act;
+	// banded backward (gsr_backward_ex with a GSR_BWD_PART_BAND_* bit): the per-Gaussian geometry stage writes only the Gaussians of one
+	// CLASS -- 1: invisible, or the tile rect ends at or before tile row `cls_split` (every row of theirs exists once the first band
+	// has been composited); 2: the others; 0: all
+	int cls_mode = 0, cls_split = 0;
 };
 // Backward data flow (no global atomics): composite_bwd leaves ONE 48-B row of partial sums per
 // (tile, Gaussian) instance, stored in GAUSSIAN-MAJOR order: row index = goff[g] + k, where goff is
@@ -189,7 +193,9 @@ struct GsBg {
 	uint32_t* flag_dst;    // word 8 of the scratch's background block
 	uint32_t flag;
 	const uint32_t* tile_order;   // nullptr: workgroup b -> tile by XCD band; else workgroup b -> tile_order[b] (longest walk first)
+	uint32_t tile_lo, tile_hi;    // banded backward: only the tiles [tile_lo, tile_hi) are walked (whole image: 0, 0xffffffff)
 };
+void launch_band_classes(int P, const int* radii, const GsRec* recs, int split, int* first, int* second, hipStream_t s);
 // Longest-first tile order for composite_bwd on SKEWED frames (a few tiles with walks many times the mean: a workgroup that
 // starts such a tile late is the kernel's tail): work[t] = the tile's longest walk (max n_contrib), tiles ordered by
 // descending work class (counting sort, 4 classes per octave).  Two small launches, only when the forward saw skew.

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	// XCD-banded static order, or (skewed frames) longest walk first: launch_tile_order
 	const int tile = bgv.tile_order ? ((int)blockIdx.x < T ? (int)bgv.tile_order[blockIdx.x] : T) : (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((!bgv.tile_order && (int)(blockIdx.x >> 3) >= chunk) || tile >= T) return;
+	if ((uint32_t)tile < bgv.tile_lo || (uint32_t)tile >= bgv.tile_hi) return;   // banded backward (GSR_BWD_PART_BAND_*): another call walks this tile
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
 	const int tx = tile % gx, ty = tile / gx;
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	// XCD-banded static order, or (skewed frames) longest walk first: launch_tile_order
 	const int tile = bgv.tile_order ? ((int)blockIdx.x < T ? (int)bgv.tile_order[blockIdx.x] : T) : (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((!bgv.tile_order && (int)(blockIdx.x >> 3) >= chunk) || tile >= T) return;
+	if ((uint32_t)tile < bgv.tile_lo || (uint32_t)tile >= bgv.tile_hi) return;   // banded backward (GSR_BWD_PART_BAND_*): another call walks this tile
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6, qd = lane >> 4;
 	TM_DECL
@@ -930,6 +932,22 @@ void launch_bwd_selftest(const float* in, uint32_t* out, hipStream_t s)
 	hipLaunchKernelGGL(bwd_selftest_kernel, dim3(1), dim3(1), 0, s, in, out);
 }
 
+// ---- banded backward: the two Gaussian classes of a split row (include/gsrast.h gsr_band_classes; same predicate as preprocess_bwd_kernel) ----
+__global__ __launch_bounds__(256) void band_classes_kernel(int P, const int* __restrict__ radii, const GsRec* __restrict__ recs, int split,
+                                                           int* __restrict__ first, int* __restrict__ second)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	const bool vis = radii[idx] > 0;
+	const bool c1 = vis && (int)(recs[idx].q3.y >> 16) <= split;
+	if (first != nullptr) first[idx] = c1 ? 1 : 0;
+	if (second != nullptr) second[idx] = (vis && !c1) ? 1 : 0;
+}
+void launch_band_classes(int P, const int* radii, const GsRec* recs, int split, int* first, int* second, hipStream_t s)
+{
+	hipLaunchKernelGGL(band_classes_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, recs, split, first, second);
+}
+
 // ---- longest-first tile order (skewed frames) ----
 __device__ __forceinline__ uint32_t gs_work_class(uint32_t m)   // 4 classes per octave, monotone in m; < 128
 {
@@ -1014,9 +1032,20 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const uint32_t* __restrict__ goff, const float* __restrict__ rows, const uint8_t* __restrict__ row_flags,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmeans, float* __restrict__ dL_dcov, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int mask_colors)
+    float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int mask_colors, int cls_mode, int cls_split)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
+	// banded backward: this launch writes the Gaussians of ONE class only (BwdArgs::cls_mode) -- class 1 = invisible, or the tile
+	// rect ends at or before tile row cls_split (all their rows exist after the first band); class 2 = the rest.  The two launches of a
+	// banded backward together write every Gaussian exactly once, each from exactly the rows, in exactly the order, of the
+	// single-call backward: bit-identical outputs.
+	bool mine = true;
+	if (cls_mode != 0) {
+		const bool v_ = idx < P && radii[idx] > 0;
+		const int rmaxy = v_ ? (int)(recs[idx].q3.y >> 16) : 0;
+		mine = ((!v_ || rmaxy <= cls_split) ? 1 : 2) == cls_mode;
+		if (__ballot(mine && idx < P) == 0ull) return;   // wave-uniform: nothing of this wave belongs to the class
+	}
 	float a_[GSR_ROW_STRIDE];
 	{
 		// Same sums, same order as gs_sum_rows, but the rows are fetched wave-cooperatively: the rows of 64
@@ -1029,7 +1058,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 		const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 		const int g0 = blockIdx.x * 256 + wv * 64;
 		if (g0 >= P) return;   // wave-uniform
-		const uint32_t b = goff[min(idx, P)], e = idx < P ? goff[idx + 1] : b;   // goff has P + 1 entries
+		const uint32_t b = goff[min(idx, P)], e = (idx < P && mine) ? goff[idx + 1] : b;   // goff has P + 1 entries; a Gaussian of the other class: no rows
 		const uint32_t wb = goff[g0], we = goff[min(g0 + 64, P)];
 		const bool is_long = e - b > (uint32_t)GSR_SUM_LONG;
 #pragma unroll
@@ -1066,7 +1095,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 		}
 		gs_sum_long_rows(b, e, rows, FLAGS ? row_flags : nullptr, lane, a_);   // spans > GSR_SUM_LONG rows: the whole wave per Gaussian
 	}
-	if (idx >= P) return;
+	if (idx >= P || !mine) return;
 	const bool vis = radii[idx] > 0;
 	// user-facing copies of the composite-stage gradients (rasterize_points.cu:209 returns them)
 	dL_dmean2D[3 * (size_t)idx] = a_[0];
@@ -1503,7 +1532,7 @@ void launch_preprocess_bwd(const BwdArgs& a, const GsCam* cam, const GsRec* recs
 	hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, FL>), grid, block, 0, s, a.P, a.M, a.means3D, a.radii, a.shs, a.scales, \
 	                   a.rotations, a.scale_modifier, a.cov3D_precomp, cam, a.W, a.H, a.tan_fovx, a.tan_fovy, h_x,   \
 	                   h_y, sh_vec4, a.act, recs, goff, rows, row_flags, dL_dmean2D, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,  \
-	                   dL_drot, (parts & GSR_PART_COLORS_EARLY) ? 1 : 0)
+	                   dL_drot, (parts & GSR_PART_COLORS_EARLY) ? 1 : 0, a.cls_mode, a.cls_split)
 	if (parts & GSR_PART_GEOM) {
 		if (row_flags != nullptr) { GSR_LAUNCH_PB(0, true); } else { GSR_LAUNCH_PB(0, false); }
 	}

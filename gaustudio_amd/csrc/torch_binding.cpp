@@ -103,6 +103,13 @@ struct GradArena {
 	// two calls (GSR_BWD_PART_COLORS_EARLY): the geometry stage already leaves dRGB in the slot, `hook()` is called -- the
 	// caller starts the all-gather of this view's slot -- and only then the SH-direction stage is enqueued
 	torch::Tensor colors_out;
+	// BANDED form of that (round 6; FactoredGradExchange(bands=2)): band_split > 0 = the tile row the backward is cut at.  The
+	// backward then (1) tells the two Gaussian classes of the split apart and hands them to class_hook(first[P], second[P]) --
+	// the caller builds the headers of the view's two colour messages from them --, (2) runs the first band (compositing of the
+	// tile rows above the split + the per-Gaussian stage of the Gaussians that end there) and calls band_hook(): their dRGB rows are
+	// final, the caller packs and all-gathers them WHILE (3) the second band runs; then hook() and the SH-direction stage as above
+	int band_split = 0;
+	py::object band_hook, class_hook;
 };
 GradArena& g_arena = *new GradArena();   // never destroyed: holds a Python object, must not outlive the interpreter's teardown
 std::mutex g_arena_mutex;                // armed on the caller's thread, consumed on an autograd worker thread
@@ -152,7 +159,7 @@ void check_small(const torch::Tensor& t, int64_t n, const char* name)
 }  // namespace
 
 void set_grad_arena(std::vector<torch::Tensor> outs, std::vector<int64_t> keys, int sh_chunks, py::object hook,
-                    c10::optional<torch::Tensor> colors_out)
+                    c10::optional<torch::Tensor> colors_out, int band_split, py::object band_hook, py::object class_hook)
 {
 	TORCH_CHECK(outs.empty() || outs.size() == 5, "set_grad_arena expects [means3D, sh, opacity, scales, rotations] gradients or []");
 	TORCH_CHECK(keys.empty() || keys.size() == 4, "set_grad_arena keys: data_ptr of [means3D, sh, scales, rotations] or []");
@@ -162,6 +169,9 @@ void set_grad_arena(std::vector<torch::Tensor> outs, std::vector<int64_t> keys, 
 	g_arena.sh_chunks = sh_chunks > 1 ? sh_chunks : 1;
 	g_arena.hook = std::move(hook);
 	g_arena.colors_out = colors_out.has_value() ? *colors_out : torch::Tensor();
+	g_arena.band_split = band_split > 0 ? band_split : 0;
+	g_arena.band_hook = std::move(band_hook);
+	g_arena.class_hook = std::move(class_hook);
 	g_pending = false;
 }
 
@@ -354,7 +364,23 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 			if (rc < 0) fail(rc);
 		};
 		const bool chunked = in_arena && !factored && arena.sh_chunks > 1 && !arena.hook.is_none() && M > 0 && sh.numel() != 0;
-		if (factored && !arena.hook.is_none()) {
+		if (factored && !arena.hook.is_none() && arena.band_split > 0 && !arena.band_hook.is_none()) {
+			// banded: the classes first (the caller's headers and count gathers leave on its side stream), then the two bands
+			const int S = arena.band_split;
+			if (!arena.class_hook.is_none()) {
+				const auto io = means3D.options().dtype(torch::kInt32);
+				torch::Tensor first = torch::empty({P}, io), second = torch::empty({P}, io);
+				const int rc = gsr_band_classes(P, radii.data_ptr<int>(), reinterpret_cast<const char*>(geomBuffer.data_ptr()), S,
+				                                first.data_ptr<int>(), second.data_ptr<int>(), current_stream(means3D));
+				if (rc < 0) fail(rc);
+				arena.class_hook(first, second);
+			}
+			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY | GSR_BWD_PART_BAND_FIRST, S, 0);
+			arena.band_hook();
+			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY | GSR_BWD_PART_BAND_SECOND, S, 0);
+			arena.hook();
+			run(GSR_BWD_PART_SH | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY, 0, P);
+		} else if (factored && !arena.hook.is_none()) {
 			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY, 0, 0);
 			arena.hook();
 			run(GSR_BWD_PART_SH | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY, 0, P);
@@ -508,7 +534,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 	      py::arg("image_width") = -1);
 	m.def("mark_visible", &markVisible);
 	m.def("set_grad_arena", &set_grad_arena, py::arg("outs"), py::arg("keys") = std::vector<int64_t>(), py::arg("sh_chunks") = 1,
-	      py::arg("hook") = py::none(), py::arg("colors_out") = py::none());
+	      py::arg("hook") = py::none(), py::arg("colors_out") = py::none(), py::arg("band_split") = 0, py::arg("band_hook") = py::none(),
+	      py::arg("class_hook") = py::none());
 	m.def("sh_grad_from_colors", &sh_grad_from_colors, py::arg("means3D"), py::arg("campos"), py::arg("colors"), py::arg("degree"),
 	      py::arg("dL_dsh"));
 	m.def("rasterize_gaussians_raw", &RasterizeGaussiansRaw, py::arg("background"), py::arg("means3D"), py::arg("f_dc"),

@@ -301,7 +301,7 @@ class FactoredGradExchange:
     Runs on CPU tensors with the "gloo" backend when `sh_from_colors` is given (tests; the product kernel is HIP only)."""
 
     def __init__(self, params_by_role: dict, views_per_rank: int = 1, sh_degree: Optional[int] = None, group=None, compact=False,
-                 sh_from_colors=None, early: bool = True, packed=None):
+                 sh_from_colors=None, early: bool = True, packed=None, bands: int = 1, band_split: Optional[int] = None):
         if set(params_by_role) != set(ARENA_ROLES):
             raise ValueError(f"params_by_role must name exactly {ARENA_ROLES}")
         self.p = dict(params_by_role)
@@ -314,6 +314,16 @@ class FactoredGradExchange:
             raise ValueError('compact must be False, True, "view" or "view+geometry"')
         self.by_view = compact in ("view", "view+geometry")      # per-view packed colour messages
         self.union_geometry = compact == "view+geometry"
+        # bands = 2 (round 6): every view's backward runs BANDED (include/gsrast.h GSR_BWD_PART_BAND_*): the image is cut at tile row
+        # `band_split`, and the colour rows of the Gaussians that END above the cut (class 1: final after the first band) leave in a
+        # message of their own while the second band is still being composited; the rest (class 2) follows as before.  Two packed
+        # messages per view instead of one, the same rows, the same order of views per Gaussian: bit-identical gradients.
+        if bands not in (1, 2):
+            raise ValueError("bands must be 1 or 2")
+        if bands == 2 and not self.by_view:
+            raise ValueError('bands=2 needs the packed per-view messages: compact="view" or "view+geometry"')
+        self.bands = int(bands)
+        self.band_split = None if band_split is None else int(band_split)
         self.compact = compact is True                            # round-3 form: union mask agreed by an all-reduce
         self.early = bool(early) and not self.compact
         self._pk = packed if packed is not None else _HipPacked
@@ -330,9 +340,10 @@ class FactoredGradExchange:
             self.Hw = int(self._pk.header_words(self.P))
             self.Lmax = self.Hw + 3 * self.P                           # words of a message whose view sees everything
             self.colors = torch.zeros((self.V, self.P, 3), dtype=torch.float32, device=dev)        # own views only, dense
-            self.hdr = torch.zeros((self.V, self.Hw), dtype=torch.int32, device=dev)
-            self.msgs = torch.zeros((self.V, self.world * self.Lmax), dtype=torch.int32, device=dev)
-            self.counts = torch.zeros((self.V, self.world), dtype=torch.int32, device=dev)
+            S = self.V * self.bands                                    # message slots: slot = local view * bands + part
+            self.hdr = torch.zeros((S, self.Hw), dtype=torch.int32, device=dev)
+            self.msgs = torch.zeros((S, self.world * self.Lmax), dtype=torch.int32, device=dev)
+            self.counts = torch.zeros((S, self.world), dtype=torch.int32, device=dev)
             self._scratch = torch.zeros((self.P + 255) // 256, dtype=torch.int32, device=dev)
             self.hdr_union = torch.zeros(self.Hw, dtype=torch.int32, device=dev)
             # the visible counts reach the HOST without touching the compute stream: header kernels, count all-gather and a
@@ -340,9 +351,9 @@ class FactoredGradExchange:
             # (long signalled by then), never for the compute stream it is being enqueued on
             self._cuda = dev.type == "cuda"
             self._side = torch.cuda.Stream(device=dev) if self._cuda else None
-            self._counts_host = torch.zeros((self.V, self.world), dtype=torch.int32, pin_memory=self._cuda)
-            self._off_host = torch.zeros(self.V * self.world, dtype=torch.int64, pin_memory=self._cuda)
-            self._off_dev = torch.zeros(self.V * self.world, dtype=torch.int64, device=dev)
+            self._counts_host = torch.zeros((S, self.world), dtype=torch.int32, pin_memory=self._cuda)
+            self._off_host = torch.zeros(S * self.world, dtype=torch.int64, pin_memory=self._cuda)
+            self._off_dev = torch.zeros(S * self.world, dtype=torch.int64, device=dev)
             self._count_events = {}
         else:
             self.colors = torch.zeros((self.V, self.world, self.P, 3), dtype=torch.float32, device=dev)     # view-major
@@ -357,6 +368,8 @@ class FactoredGradExchange:
         self._works = {}          # local view -> work handle of its early all-gather
         self._step_degrees = []   # degrees the step's armed backwards were rendered with
         self._order = torch.tensor(self.view_order(), dtype=torch.long, device=dev)
+        # one camera centre per MESSAGE, in the order the rebuilt SH gradient adds them: local view major, rank, then part
+        self._msg_order = self._order.repeat_interleave(self.bands)
 
     def geo_views(self):
         out, o = {}, 0
@@ -383,8 +396,8 @@ class FactoredGradExchange:
         if self.by_view:
             crow = self.stats["color_rows_sent"] / n               # sum over this rank's views of the agreed row capacity
             grow = self.stats["geometry_rows"] / n if self.union_geometry else self.P
-            hdrb = self.Hw * 4 * self.V
-            return {"payload_bytes_per_rank": int(crow * 12 + hdrb + grow * 44), "allreduce_bytes": int(grow * 44),
+            hdrb = self.Hw * 4 * self.V * self.bands
+            return {"bands": self.bands, "payload_bytes_per_rank": int(crow * 12 + hdrb + grow * 44), "allreduce_bytes": int(grow * 44),
                     "allgather_bytes_sent": int(crow * 12 + hdrb), "allgather_bytes_received": int((crow * 12 + hdrb) * (self.world - 1)),
                     "dense_payload_bytes_per_rank": self.P * (self.M * 3 + 11) * 4, "color_rows_per_view": crow / self.V,
                     "geometry_rows": grow, "rows_total": self.P, "compacted": "view+geometry" if self.union_geometry else "view",
@@ -397,11 +410,12 @@ class FactoredGradExchange:
                 "dense_payload_bytes_per_rank": self.P * (self.M * 3 + 11) * 4, "rows_per_step": rows, "rows_total": self.P,
                 "compacted": self.compact, "early_allgathers_per_step": self.stats["early_allgathers"] / n}
 
-    def arm(self, v: int, sh_degree: Optional[int] = None):
+    def arm(self, v: int, sh_degree: Optional[int] = None, band_split: Optional[int] = None):
         """Before the forward + backward of this rank's local view v: its colour gradients go to slot [v, rank] of the
         all-gather buffer.  The first view's geometry gradients are born in the all-reduce buffer when no p.grad exists
         yet; later views accumulate into them through autograd as usual.  sh_degree: the settings' sh_degree of this view's
-        render (checked against the step's other views and against exchange())."""
+        render (checked against the step's other views and against exchange()).  band_split (bands = 2): the tile row this
+        view's backward is cut at (default: the constructor's; typically half of ceil(height / 16))."""
         from . import _C
         if sh_degree is not None:
             self._step_degrees.append(int(sh_degree))
@@ -415,79 +429,114 @@ class FactoredGradExchange:
         hook = None
         if self.early and (_multi(self.group) or self.by_view):
             hook = lambda v=v: self._on_colors_ready(v)
+        if self.bands == 2:
+            S = self.band_split if band_split is None else int(band_split)
+            if S is None or S <= 0:
+                raise ValueError("FactoredGradExchange(bands=2): give the split tile row (band_split) to the constructor or to arm()")
+            _C.set_grad_arena(outs, keys, 1, hook, colors_out=slot, band_split=S, band_hook=lambda v=v: self._on_band_ready(v),
+                              class_hook=lambda first, second, v=v: self._on_classes(v, first, second))
+            return
         _C.set_grad_arena(outs, keys, 1, hook, colors_out=slot)
 
     def visible(self, v: int, radii: torch.Tensor):
         """compact="view": right after the FORWARD of local view v, with the `radii` it returned -- builds the view's
-        visibility header and gathers the visible counts of all ranks (asynchronously: nothing here waits)."""
-        if not self.by_view:
+        visibility header and gathers the visible counts of all ranks (asynchronously: nothing here waits).  With bands = 2 the
+        headers come from the two Gaussian classes the banded backward reports when it starts (_on_classes): a no-op here."""
+        if not self.by_view or self.bands == 2:
             return
-        radii = radii.detach().contiguous()
+        self._index_slot(v, radii.detach().contiguous())
 
+    def _on_classes(self, v: int, first: torch.Tensor, second: torch.Tensor):
+        """bands = 2: called by the banded backward of local view v (csrc/torch_binding.cpp) before its first kernel, with the two
+        classes of the cut (int32[P], 1 = member; include/gsrast.h gsr_band_classes): the headers of the view's two messages and
+        the gathers of their row counts leave on the side stream, as visible() does for the unbanded view."""
+        self._index_slot(2 * v, first)
+        self._index_slot(2 * v + 1, second)
+
+    def _index_slot(self, slot: int, member: torch.Tensor):
+        """Header of message slot `slot` from member[P] (> 0 = the Gaussian has a row in it) + the all-gather of the row counts."""
         def build():
-            self._pk.visible_index(radii, self.hdr[v], self._scratch)
+            self._pk.visible_index(member, self.hdr[slot], self._scratch)
             if _multi(self.group):
-                w = dist.all_gather_into_tensor(self.counts[v], self.hdr[v][0:1], group=self.group, async_op=True)
+                w = dist.all_gather_into_tensor(self.counts[slot], self.hdr[slot][0:1], group=self.group, async_op=True)
                 if self._cuda:
                     w.wait()                               # the side stream waits for the communicator's stream; the host does not
                 else:
-                    self._count_works[v] = w
+                    self._count_works[slot] = w
             else:
-                self.counts[v, 0:1].copy_(self.hdr[v][0:1])
+                self.counts[slot, 0:1].copy_(self.hdr[slot][0:1])
         if self._cuda:
             cur = torch.cuda.current_stream(self.geo.device)
             with torch.cuda.stream(self._side):
-                self._side.wait_stream(cur)                # radii come from the forward just enqueued
+                self._side.wait_stream(cur)                # radii / the classes come from kernels just enqueued
                 build()
-                self._counts_host[v].copy_(self.counts[v], non_blocking=True)
+                self._counts_host[slot].copy_(self.counts[slot], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
-            radii.record_stream(self._side)
-            self._count_events[v] = ev
+            member.record_stream(self._side)
+            self._count_events[slot] = ev
         else:
             build()
-        self._seen.add(v)
+        self._seen.add(slot)
 
     def _send_view(self, v: int):
-        """compact="view": packs view v's visible rows behind its header and starts the all-gather of the messages.  The
-        message length is the same on every rank: header + 3 floats x the LARGEST visible count of the view over the ranks
-        (known from the counts gathered after the forward; reading it is the only host synchronisation, and at that point
-        the device still has the rest of the backward queued)."""
-        if v not in self._seen:
+        """(bands = 1) the one message of local view v."""
+        self._send(v)
+
+    def _send(self, slot: int):
+        """compact="view": packs the rows of message slot `slot` (= local view * bands + part) behind its header and starts the
+        all-gather of the messages.  The message length is the same on every rank: header + 3 floats x the LARGEST row count of
+        the slot over the ranks (known from the counts gathered earlier; reading it is the only host synchronisation, and at that
+        point the device still has the rest of the backward queued)."""
+        v = slot // self.bands
+        if slot not in self._seen:
+            if self.bands == 2:
+                raise RuntimeError(f"FactoredGradExchange(bands=2): the classes of local view {v} have not arrived (its backward must run banded: arm())")
             raise RuntimeError(f'FactoredGradExchange(compact="view"): call visible({v}, radii) after the forward of local view {v}')
         if self._cuda:
-            ev = self._count_events.pop(v)
+            ev = self._count_events.pop(slot)
             ev.synchronize()                                                 # the side stream only: signalled long ago
             torch.cuda.current_stream(self.geo.device).wait_event(ev)        # the header is read by the kernels enqueued below
-            kcap = int(self._counts_host[v].max())
+            kcap = int(self._counts_host[slot].max())
         else:
-            w = self._count_works.pop(v, None)
+            w = self._count_works.pop(slot, None)
             if w is not None:
                 w.wait()
-            kcap = int(self.counts[v].max().item())
-            self._counts_host[v].copy_(self.counts[v])
+            kcap = int(self.counts[slot].max().item())
+            self._counts_host[slot].copy_(self.counts[slot])
         L = self.Hw + 3 * kcap
-        buf = self.msgs[v][: self.world * L].view(self.world, L)
+        buf = self.msgs[slot][: self.world * L].view(self.world, L)
         mine = buf[self.rank]
-        mine[: self.Hw].copy_(self.hdr[v])
+        mine[: self.Hw].copy_(self.hdr[slot])
         if kcap > 0:
-            self._pk.pack_rows(self.hdr[v], self.colors[v], mine[self.Hw:].view(torch.float32), 3, 0)
-        self._L[v] = L
+            self._pk.pack_rows(self.hdr[slot], self.colors[v], mine[self.Hw:].view(torch.float32), 3, 0)
+        self._L[slot] = L
         self.stats["color_rows_sent"] += kcap
         if _multi(self.group):
-            self._works[v] = _all_gather_in_place(buf, self.rank, 1, self.group)
+            self._works[slot] = _all_gather_in_place(buf, self.rank, 1, self.group)
         else:
-            self._works[v] = None
+            self._works[slot] = None
+
+    def _on_band_ready(self, v: int):
+        """bands = 2: called by the banded backward of local view v right after its FIRST band has been enqueued: the rows of
+        slot [v] of the Gaussians that end above the cut hold their final dRGB -- their message leaves now, stream-ordered behind
+        that band, while the second band is composited."""
+        slot = 2 * v
+        if slot in self._works:
+            return
+        self._send(slot)
+        self.stats["early_band_allgathers"] = self.stats.get("early_band_allgathers", 0) + 1
 
     def _on_colors_ready(self, v: int):
         """Called by the backward armed for local view v (csrc/torch_binding.cpp) right after its geometry stage has been
         enqueued: slot [v, rank] holds the view's final dRGB.  The all-gather of view v over all ranks is stream-ordered
         behind that kernel and runs on the communicator's stream while the backward's SH-direction stage -- and the
         step's remaining views -- compute."""
-        if v in self._works:
+        slot = v * self.bands + (self.bands - 1) if self.by_view else v      # bands = 2: the second message (class 2)
+        if slot in self._works:
             return
         if self.by_view:
-            self._send_view(v)
+            self._send(slot)
         else:
             self._works[v] = _all_gather_in_place(self.colors[v], self.rank, 1, self.group)
         self.stats["early_allgathers"] += 1
@@ -580,25 +629,29 @@ class FactoredGradExchange:
 
 def _exchange_by_view_impl(self, campos_all, D, views, multi):
     """compact="view" / "view+geometry" (FactoredGradExchange._exchange_by_view)."""
-    P, V, W, dev = self.P, self.V, self.world, self.geo.device
-    for v in range(V):                               # views whose message did not leave from inside their backward
-        if v not in self._works:
-            self._send_view(v)
+    P, V, W, B, dev = self.P, self.V, self.world, self.bands, self.geo.device
+    S = V * B
+    for slot in range(S):                            # messages that did not leave from inside their backward
+        if slot not in self._works:
+            self._send(slot)
     w2 = None
     if multi and not self.union_geometry:
         w2 = dist.all_reduce(self.geo, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-    for v in range(V):
-        if self._works[v] is not None:
-            self._works[v].wait()
-    # word offset of every message in memory order (local view major, rank minor): from the counts the host already holds,
-    # handed to the device by a non-blocking copy out of pinned memory
-    Lv = self.Hw + 3 * self._counts_host.max(dim=1).values.to(torch.int64)                                  # [V], host
-    self._off_host.copy_(((torch.arange(V, dtype=torch.int64) * (W * self.Lmax))[:, None] +
-                          torch.arange(W, dtype=torch.int64)[None, :] * Lv[:, None]).reshape(-1))
+    for slot in range(S):
+        if self._works[slot] is not None:
+            self._works[slot].wait()
+    # word offset of every message, in the order the SH gradient adds them: local view major, then rank, then part (a Gaussian has a
+    # row in exactly one part of a view, so per Gaussian this is the unbanded order of views: bit-identical sums) -- from the counts
+    # the host already holds, handed to the device by a non-blocking copy out of pinned memory.  Message (v, r, part) lies at word
+    # slot * (W * Lmax) + r * L_slot of `msgs`, slot = v * B + part.
+    Ls = self.Hw + 3 * self._counts_host.max(dim=1).values.to(torch.int64)                                  # [S], host
+    slot_of = (torch.arange(V, dtype=torch.int64)[:, None, None] * B + torch.arange(B, dtype=torch.int64)[None, None, :]).expand(V, W, B)
+    rank_of = torch.arange(W, dtype=torch.int64)[None, :, None].expand(V, W, B)
+    self._off_host.copy_((slot_of * (W * self.Lmax) + rank_of * Ls[slot_of]).reshape(-1))
     self._off_dev.copy_(self._off_host, non_blocking=True)
     offsets = self._off_dev
     msgs = self.msgs.view(-1)
-    campos = campos_all.detach().to(dev, torch.float32)[self._order].contiguous()
+    campos = campos_all.detach().to(dev, torch.float32)[self._msg_order].contiguous()
     kf_ev = None
     if self.union_geometry:
         # rows with a non-zero RASTERIZER geometry gradient anywhere in the step = the OR of the gathered masks (identical on

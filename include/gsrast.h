@@ -171,6 +171,24 @@ int gsr_backward(int P, int D, int M, int R,
  * gradients between them -- before the SH-direction stage has read 192 B of coefficients per Gaussian -- without a race on
  * the slot.  Same bits as the one-call form. */
 #define GSR_BWD_PART_COLORS_EARLY 8
+/* BANDED backward (round 6, gsr_backward_ex only; gaustudio_amd/parallel.py FactoredGradExchange(bands=2)): the compositing backward
+ * and the per-Gaussian geometry stage of GSR_BWD_PART_MAIN run as TWO calls on the same buffers and the same scratch, so that a
+ * caller can start exchanging the finished part of the gradients while the other half of the image is still composited:
+ *   parts = MAIN | GSR_BWD_PART_BAND_FIRST  [| SH_COLORS | COLORS_EARLY], sh_g0 = split tile row S (0 <= S <= tile rows):
+ *       composites the tile rows [0, S) and writes every output row except dL_dsh of the Gaussians of CLASS 1 = those that are
+ *       invisible (radii == 0: zeros) or whose tile rect ends at or before row S -- all of their per-instance rows exist now;
+ *   parts = MAIN | GSR_BWD_PART_BAND_SECOND [| ...], sh_g0 = the same S: composites the rows [S, tile rows) and writes the
+ *       Gaussians of CLASS 2 (the others).
+ * Together the two calls write every Gaussian exactly once, each from exactly the rows, in exactly the order, of the one-call
+ * backward: BIT-IDENTICAL outputs.  No SH part in a band call (it follows the second band: GSR_BWD_PART_SH over [0, P));
+ * gsr_band_classes tells the classes apart.  (With a forward that itself rendered a tile band, S counts tile rows of the
+ * whole image as the forward's tile_row_lo / tile_row_hi do.) */
+#define GSR_BWD_PART_BAND_FIRST 16
+#define GSR_BWD_PART_BAND_SECOND 32
+/* first[g] = 1 if Gaussian g is visible and of class 1 for split row S (its gradient rows are final after the FIRST band call),
+ * second[g] = 1 if visible and of class 2; 0 otherwise (int32[P] each, device memory; either may be NULL).  Fed to
+ * gsr_visible_index they give the headers of the two packed colour messages of a banded view. */
+int gsr_band_classes(int P, const int* radii, const char* geom_buffer, int split_tile_row, int* first, int* second, void* stream);
 int gsr_backward_parts(int parts, int sh_g0, int sh_g1, int P, int D, int M, int R, const float* background, int width,
                        int height, const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                        float scale_modifier, const float* rotations, const float* cov3D_precomp, float tan_fovx,

@@ -233,19 +233,31 @@ def _worker_factored_by_view(rank, world, out_dir, V, compact):
     views, means, campos, (P, M) = _factored_inputs(world, V)
     shapes = dict(means3D=(P, 3), shs=(P, M, 3), opacities=(P, 1), scales=(P, 3), rotations=(P, 4))
     params = {k: (means.clone() if k == "means3D" else torch.zeros(shp)).requires_grad_(True) for k, shp in shapes.items()}
-    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact.replace("+reg", ""), packed=TorchPacked)
-    assert fx.by_view and fx.colors.shape == (V, P, 3)
-    with pytest.raises(RuntimeError, match="call visible"):
-        fx._send_view(0)                                   # the radii of the view have not arrived
+    bands = 2 if compact.endswith("+bands2") else 1
+    compact = compact.replace("+bands2", "")
+    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact.replace("+reg", ""), packed=TorchPacked, bands=bands,
+                                       band_split=3 if bands == 2 else None)
+    assert fx.by_view and fx.colors.shape == (V, P, 3) and fx.hdr.shape[0] == V * bands
+    with pytest.raises(RuntimeError, match="call visible" if bands == 1 else "classes of local view 0 have not arrived"):
+        fx._send_view(0)                                   # the radii (the classes) of the view have not arrived
     for v in range(V):
         gv = views[rank * V + v]
-        radii = (gv["colors"].abs().amax(1) > 0).int() * 3          # culled rows of the inputs are all-zero rows
-        fx.visible(v, radii)                                         # right after the "forward"
+        vis = gv["colors"].abs().amax(1) > 0                         # culled rows of the inputs are all-zero rows
+        fx.visible(v, vis.int() * 3)                                 # right after the "forward" (bands = 2: a no-op)
+        if bands == 2:
+            # the banded backward of the real binding, driven by hand: the two classes of the cut (here: an arbitrary, per-rank and
+            # per-view different split of the visible rows), the first band's callback, then the second's
+            first = vis & (((torch.arange(P) * 7 + rank + v) % 3) != 0)
+            fx._on_classes(v, first.int(), (vis & ~first).int())
+            fx.colors[v].zero_()
+            fx.colors[v][first] = gv["colors"][first]                # only class 1 is final when the first band reports
+            fx._on_band_ready(v)
         fx.colors[v].copy_(gv["colors"])
         fx._on_colors_ready(v)                                       # the backward's callback: pack + all-gather start
         for k in parallel.GEOMETRY_ROLES:
             params[k].grad = gv[k].clone() if params[k].grad is None else params[k].grad + gv[k]
-    assert fx.stats["early_allgathers"] == V
+    assert fx.stats["early_allgathers"] == V and fx.stats.get("early_band_allgathers", 0) == (V if bands == 2 else 0)
+    assert fx.payload()["bands"] == bands
     regularised = compact == "view+geometry+reg"
     if regularised and rank == 1:
         # another loss term (a scale regulariser, say) leaves a gradient on a Gaussian NO view of the step sees -- on one rank only
@@ -261,7 +273,7 @@ def _worker_factored_by_view(rank, world, out_dir, V, compact):
 
 
 @pytest.mark.parametrize("V,compact", [(1, False), (2, False), (1, True), (1, "view"), (2, "view"), (2, "view+geometry"),
-                                       (1, "view+geometry+reg")])
+                                       (1, "view+geometry+reg"), (1, "view+bands2"), (2, "view+geometry+bands2")])
 def test_factored_exchange_equals_dense_accumulation(tmp_path, V, compact):
     """FactoredGradExchange (all-gather of per-view colour gradients + all-reduce of the geometry block + local rebuild of the
     SH gradient) == the sum over all world * V views of the dense per-view gradients, on every rank; with and without
@@ -270,6 +282,7 @@ def test_factored_exchange_equals_dense_accumulation(tmp_path, V, compact):
     mp.spawn(_worker_factored, args=(world, _free_port(), str(tmp_path), V, compact), nprocs=world, join=True)
     views, means, campos, (P, M) = _factored_inputs(world, V)
     want = {k: sum(v[k] for v in views) for k in parallel.GEOMETRY_ROLES}
+    # "+bands2" (round 6): every view leaves as TWO messages (the banded backward's classes) -- the very same sums, bit for bit
     if compact == "view+geometry+reg":     # "+reg": rank 1 adds a regulariser gradient on a row culled in every view:
         want["scales"][_culled_everywhere(views), 1] += 0.25   # it must arrive in the sum (the step falls back to the dense block)
     order = [r * V + v for v in range(V) for r in range(world)]          # FactoredGradExchange.view_order(): local view major, rank minor
@@ -376,10 +389,12 @@ def _accumulate_views_dense(sc, cams, dev, D=3):
     return {k: p.grad.cpu() for k, p in params.items()}
 
 
-def _factored_step(sc, my_cams, all_cams, dev, V, D=3, compact=False):
+def _factored_step(sc, my_cams, all_cams, dev, V, D=3, compact=False, bands=1):
     from gaustudio_amd import GaussianRasterizationSettings, GaussianRasterizer
     params = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in KEYS}
-    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact)
+    # bands = 2: every backward runs banded, cut in the middle of the image (tile rows)
+    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact=compact, bands=bands,
+                                       band_split=((my_cams[0].height + 15) // 16) // 2 if bands == 2 else None)
     m2 = torch.zeros_like(params["means3D"])
     for v, cam in enumerate(my_cams):
         rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, torch.zeros(3), 1.0,
@@ -396,8 +411,27 @@ def _factored_step(sc, my_cams, all_cams, dev, V, D=3, compact=False):
         assert all(params[r].grad.data_ptr() == gv[r].data_ptr() for r in parallel.GEOMETRY_ROLES)   # born in the all-reduce buffer
     if (parallel._multi(None) and not compact) or isinstance(compact, str):
         assert fx.stats["early_allgathers"] == V       # every view's all-gather started from inside its backward
+    if bands == 2:
+        assert fx.stats["early_band_allgathers"] == V  # ... and the first band's message before the second band was enqueued
     fx.exchange(torch.stack([c.campos for c in all_cams]).to(dev), sh_degree=D)
     return {k: p.grad.cpu() for k, p in params.items()}, fx
+
+
+@pytest.mark.gpu
+def test_banded_factored_exchange_single_process_bit_equal():
+    """bands = 2 (round 6): the banded backward + two packed messages per view give, bit for bit, what plain autograd accumulation of
+    the dense backward gives -- world_size 1, two local views, both packed forms."""
+    dev = torch.device("cuda", 0)
+    sc, cams = _scene_and_cams(2)
+    want = _accumulate_views_dense(sc, cams, dev, 3)
+    for compact in ("view", "view+geometry"):
+        got, fx = _factored_step(sc, cams, cams, dev, V=2, D=3, compact=compact, bands=2)
+        for k in KEYS:
+            assert torch.equal(got[k], want[k]), (compact, k)
+        pay = fx.payload()
+        assert pay["bands"] == 2 and 0 < pay["color_rows_per_view"] <= 1500
+    with pytest.raises(ValueError, match="bands=2 needs the packed"):
+        parallel.FactoredGradExchange({k: getattr(sc, k).to(dev) for k in KEYS}, bands=2)
 
 
 @pytest.mark.gpu
@@ -415,14 +449,14 @@ def test_factored_exchange_single_process_bit_equal(D):
     assert fx.payload()["payload_bytes_per_rank"] == 1500 * (44 + 24) and fx.payload()["dense_payload_bytes_per_rank"] == 1500 * 236
 
 
-def _gpu_worker_factored(rank, world, port, out_dir, compact):
+def _gpu_worker_factored(rank, world, port, out_dir, compact, bands=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)     # RCCL refuses two ranks on one device
     try:
         dev = torch.device("cuda", 0)
         sc, cams = _scene_and_cams(world)
-        got, fx = _factored_step(sc, parallel.shard_views(cams), cams, dev, V=1, compact=compact)
+        got, fx = _factored_step(sc, parallel.shard_views(cams), cams, dev, V=1, compact=compact, bands=bands)
         if compact is True:
             assert fx.payload()["rows_per_step"] <= 1500
         elif compact:
@@ -430,6 +464,21 @@ def _gpu_worker_factored(rank, world, port, out_dir, compact):
         torch.save(got, os.path.join(out_dir, f"fxgpu_rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compact", ["view", "view+geometry"])
+def test_two_ranks_banded_factored_exchange_real_kernels(tmp_path, compact):
+    """bands = 2 over two ranks (gloo, one GPU), one camera each, the HIP kernels: every rank ends with the gradients of both
+    views, bit-identical to single-process accumulation and to the unbanded exchange."""
+    world = 2
+    mp.spawn(_gpu_worker_factored, args=(world, _free_port(), str(tmp_path), compact, 2), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"fxgpu_rank{r}.pt")) for r in range(world)]
+    sc, cams = _scene_and_cams(world)
+    want = _accumulate_views_dense(sc, cams, torch.device("cuda", 0))
+    for k in KEYS:
+        assert torch.equal(got[0][k], got[1][k]), k
+        assert torch.equal(got[0][k], want[k]), k
 
 
 @pytest.mark.gpu
@@ -495,6 +544,9 @@ def _nccl_world1_worker(rank, world, port, out_dir):
             report[f"factored_compact{tag}"] = got
             got2, _ = _factored_step(sc, cams, cams, dev, V=2, compact=compact)
             report[f"factored2_compact{tag}"] = got2
+            if isinstance(compact, str):          # bands = 2: the banded backward, two messages per view
+                report[f"banded_compact{tag}"], _ = _factored_step(sc, cams[:1], cams[:1], dev, V=1, compact=compact, bands=2)
+                report[f"banded2_compact{tag}"], _ = _factored_step(sc, cams, cams, dev, V=2, compact=compact, bands=2)
         torch.save(report, os.path.join(out_dir, "nccl1.pt"))
     finally:
         dist.destroy_process_group()
@@ -525,7 +577,9 @@ def test_nccl_world1_every_collective_call_of_the_step(tmp_path):
     want2 = _accumulate_views_dense(sc, cams, dev)
     for name, want in (("dense", want1), ("dense2", want2), ("factored_compact0", want1), ("factored_compact1", want1),
                        ("factored2_compact0", want2), ("factored2_compact1", want2), ("factored_compactview", want1),
-                       ("factored2_compactview", want2), ("factored_compactviewgeo", want1), ("factored2_compactviewgeo", want2)):
+                       ("factored2_compactview", want2), ("factored_compactviewgeo", want1), ("factored2_compactviewgeo", want2),
+                       ("banded_compactview", want1), ("banded2_compactview", want2), ("banded_compactviewgeo", want1),
+                       ("banded2_compactviewgeo", want2)):
         for k in KEYS:
             assert torch.equal(got[name][k], want[k]), (name, k)
     assert float(want1["shs"].abs().max()) > 0

@@ -319,3 +319,48 @@ def test_backward_variants_of_the_kernel_agree():
                 continue
             scale = float(y.abs().max())
             assert float((x - y).abs().max()) <= 2e-5 * scale + 1e-30, (k, float((x - y).abs().max()), scale)
+
+
+@pytest.mark.parametrize("fast_exp", [0, 1], ids=["exact", "fast_exp"])
+def test_banded_backward_equals_the_one_call_backward_bit_for_bit(fast_exp):
+    """Round 6: gsr_backward_ex in two BANDS (GSR_BWD_PART_BAND_FIRST / _SECOND: compositing backward of the tile
+    rows above / below a cut + the per-Gaussian stage of the Gaussians that end above it / the others) followed by the SH stage
+    == the one-call backward, every output and the accumulator rows bit for bit -- short-list and long-list (row flags) regimes,
+    cuts at 0, inside the image and at its end, colour-only and full losses; gsr_band_classes partitions the visible Gaussians."""
+    import gaustudio_amd
+    from gaustudio_amd import _C
+    cases = [(scenes.make_camera(333, 211), dict(seed=4, sigma_px_median=3.0), 6000, None),
+             (scenes.make_camera(96, 64), dict(seed=5, sigma_px_median=9.0), 9000, torch.tensor([1.0, 0.5, 0.25]))]   # long lists: row flags
+    keys = GRAD_KEYS + ("acc",)
+    for cam, skw, P, bg in cases:
+        sc = scenes.make_scene(P, cam, **skw)
+        kw = scene_kwargs(sc, True, False)
+        full = scenes.make_output_grads(cam, seed=3)
+        gy = (cam.height + 15) // 16
+        with gaustudio_amd.options(fast_exp=fast_exp):
+            hs = hip_forward(sc, cam, 3, kw, bg=bg)
+        opt = dict(fast_exp=fast_exp)
+        for grads in (full, [full[0], None, None, None]):
+            want = hip_backward_raw(hs, sc, cam, 3, kw, grads, bg=bg, options=opt)
+            for S in (0, 1, gy // 2, gy - 1, gy, gy + 5):
+                first, second = _C.band_classes(hs["radii"], hs["geom"], S)
+                vis = hs["radii"] > 0
+                assert torch.equal((first + second) > 0, vis) and int((first * second).sum()) == 0
+                if S >= gy:
+                    assert int(second.sum()) == 0
+                if S == 0:
+                    assert int((first.bool() & (hs["tiles_touched"] > 0)).sum()) == 0
+                a = hip_backward_raw(hs, sc, cam, 3, kw, grads, bg=bg, options=opt, parts=1 | 16, sh_g0=S)
+                if 0 < S < gy:       # after the first band the Gaussians of class 1 are final, the others untouched (NaN-poisoned)
+                    m = ~second.bool()
+                    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations"):
+                        assert torch.equal(a[k][m], want[k][m]) and bool(torch.isnan(a[k][second.bool()]).all()), (S, k)
+                a = hip_backward_raw(hs, sc, cam, 3, kw, grads, bg=bg, options=opt, parts=1 | 32, sh_g0=S, reuse=a)
+                a = hip_backward_raw(hs, sc, cam, 3, kw, grads, bg=bg, options=opt, parts=2, reuse=a)
+                for k in keys:
+                    assert torch.equal(a[k], want[k]), (S, k, "colour-only" if grads[1] is None else "full")
+    # a band call with the SH part, or both bands at once, is refused
+    with pytest.raises(RuntimeError, match="band call runs GSR_BWD_PART_MAIN only"):
+        hip_backward_raw(hs, sc, cam, 3, kw, full, bg=bg, options=opt, parts=1 | 2 | 16, sh_g0=2)
+    with pytest.raises(RuntimeError, match="two calls"):
+        hip_backward_raw(hs, sc, cam, 3, kw, full, bg=bg, options=opt, parts=1 | 16 | 32, sh_g0=2)

@@ -131,10 +131,12 @@ def make_options(L, struct_bytes=None, **fields):
     return o
 
 
-def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False, options=None, no_dcov=False, parts=3):
+def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False, options=None, no_dcov=False, parts=3,
+                     sh_g0=0, sh_g1=None, reuse=None):
     """gsr_backward (or, with `options` = a GsrOptions / None-able dict, gsr_backward_ex) called straight through ctypes
     with a test-owned scratch buffer, so that the composite-stage accumulator rows (scratch[P,12]) can be inspected next
-    to the 8 outputs."""
+    to the 8 outputs.  `reuse`: the dict a previous call returned -- its output tensors and its scratch are used again (the
+    staged / banded forms of one backward: gsr_backward_ex `parts`, `sh_g0`, `sh_g1`)."""
     import ctypes
     from gaustudio_amd import _C
     L = _C.lib()
@@ -146,12 +148,16 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
     bg = torch.zeros(3) if bg is None else bg
     gc, gd, gm, go = [None if t is None else t.to(dev).contiguous() for t in grads]      # None: NULL = absent = zero (include/gsrast.h)
     fo = dict(dtype=torch.float32, device=dev)
-    out = dict(dL_dmeans2D=torch.full((P, 3), float("nan"), **fo), dL_dopacity=torch.full((P, 1), float("nan"), **fo),
-               dL_dcolors=torch.full((P, 3), float("nan"), **fo), dL_dmeans3D=torch.full((P, 3), float("nan"), **fo),
-               dL_dcov3D=torch.full((P, 6), float("nan"), **fo), dL_dsh=torch.full((P, M, 3), float("nan"), **fo),
-               dL_dscales=torch.full((P, 3), float("nan"), **fo), dL_drotations=torch.full((P, 4), float("nan"), **fo))
-    nscratch = L.gsr_backward_scratch_bytes(ctypes.c_int(P), ctypes.c_int(hs["num_rendered"]))
-    scratch = torch.full((nscratch,), 0xAB, dtype=torch.uint8, device=dev)   # poison: the library must zero it
+    if reuse is not None:
+        out = {k: reuse[k] for k in ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")}
+        scratch = reuse["scratch"]
+    else:
+        out = dict(dL_dmeans2D=torch.full((P, 3), float("nan"), **fo), dL_dopacity=torch.full((P, 1), float("nan"), **fo),
+                   dL_dcolors=torch.full((P, 3), float("nan"), **fo), dL_dmeans3D=torch.full((P, 3), float("nan"), **fo),
+                   dL_dcov3D=torch.full((P, 6), float("nan"), **fo), dL_dsh=torch.full((P, M, 3), float("nan"), **fo),
+                   dL_dscales=torch.full((P, 3), float("nan"), **fo), dL_drotations=torch.full((P, 4), float("nan"), **fo))
+        nscratch = L.gsr_backward_scratch_bytes(ctypes.c_int(P), ctypes.c_int(hs["num_rendered"]))
+        scratch = torch.full((nscratch,), 0xAB, dtype=torch.uint8, device=dev)   # poison: the library must zero it
     means = sc.means3D.to(dev); shs = g("shs"); col = g("colors_precomp"); scl = g("scales"); rot = g("rotations")
     cov = g("cov3D_precomp")
     dcov = None if no_dcov else out["dL_dcov3D"]     # NULL is allowed when cov3D_precomp is NULL (include/gsrast.h)
@@ -159,7 +165,7 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
     p = _C._ptr
     if options is not None:
         opt = options if isinstance(options, GsrOptions) else make_options(L, **options)
-        rc = L.gsr_backward_ex(ctypes.byref(opt), ctypes.c_int(parts), ctypes.c_int(0), ctypes.c_int(P), ctypes.c_int(P), ctypes.c_int(D),
+        rc = L.gsr_backward_ex(ctypes.byref(opt), ctypes.c_int(parts), ctypes.c_int(int(sh_g0)), ctypes.c_int(P if sh_g1 is None else int(sh_g1)), ctypes.c_int(P), ctypes.c_int(D),
                                ctypes.c_int(M), ctypes.c_int(hs["num_rendered"]), p(bg), ctypes.c_int(cam.width), ctypes.c_int(cam.height),
                                p(means), p(shs), p(None), p(col), p(scl), ctypes.c_float(scale_modifier), p(rot), p(cov), ctypes.c_int(0),
                                ctypes.c_float(cam.tanfovx), ctypes.c_float(cam.tanfovy), p(hs["radii"]), p(hs["geom"]), p(hs["binning"]),
@@ -187,4 +193,5 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
         raise _C._err(L, rc)
     torch.cuda.synchronize()
     out["acc"] = acc
+    out["scratch"] = scratch
     return out
