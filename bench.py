@@ -455,6 +455,10 @@ def main():
                     help="N > 1, --exchange factored: none = dense 12 B/Gaussian colour slots; view = per-view packed messages (header + "
                          "12 B per VISIBLE Gaussian, counts agreed off the critical path); view+geometry = also the geometry all-reduce "
                          "on the union of the step's views; union = the round-3 form (mask all-reduce + compacted buffers)")
+    ap.add_argument("--bands", type=int, default=1, choices=[1, 2],
+                    help="N > 1, --exchange factored --compact view|view+geometry: 2 = every backward runs BANDED (cut at the middle tile row): the "
+                         "colour rows of the Gaussians that end above the cut leave while the lower half is still being composited "
+                         "(FactoredGradExchange(bands=2); bit-identical gradients)")
     ap.add_argument("--epilogue-separate", action="store_true", help="C3-extract: mask, depth_to_points and depth_to_normals as separate steps (torch ops + two kernels) instead of the fused gsr_depth_epilogue")
     ap.add_argument("--tsdf-linear", action="store_true", help="C3-extract: integrate the point map as a flat list (256 consecutive points per workgroup) instead of 32x32 patches")
     ap.add_argument("--views-per-rank", type=int, default=1, help="cameras rendered (and accumulated) per rank and step")
@@ -558,13 +562,16 @@ def main():
     bucket = None if a.fwd_only else parallel.FlatGradBucket(list(params.values()), roles=params)
     fx = None
     if factored:
-        fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact={"none": False, "union": True}.get(a.compact, a.compact))
+        fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact={"none": False, "union": True}.get(a.compact, a.compact),
+                                           bands=a.bands, band_split=((H + 15) // 16) // 2 if a.bands == 2 else None)
         campos_all = torch.stack([c.campos for c in all_cams]).to(dev)
     state = {}
     comm_ev = []       # (backward enqueued, exchange finished) events of the timed steps, N > 1 only
     # compositing mode: the library default (fast_exp = v_exp_f32 unless GSR_FAST_EXP=0) or the one asked for
     if a.fast_exp and a.exact:
         raise SystemExit("--fast-exp and --exact exclude each other")
+    if a.bands == 2 and not (a.exchange == "factored" and a.compact in ("view", "view+geometry")):
+        raise SystemExit("--bands 2 needs --exchange factored --compact view|view+geometry")
     fast_mode = True if a.fast_exp else (False if a.exact else bool(_C.get_option("fast_exp")))
     mode = gaustudio_amd.options(fast_exp=fast_mode)
 
@@ -727,7 +734,8 @@ def main():
                 factored = False
             else:
                 if fx is None:
-                    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact={"none": False, "union": True}.get(a.compact, a.compact))
+                    fx = parallel.FactoredGradExchange(params, views_per_rank=V, compact={"none": False, "union": True}.get(a.compact, a.compact),
+                                           bands=a.bands, band_split=((H + 15) // 16) // 2 if a.bands == 2 else None)
                     campos_all = torch.stack([c.campos for c in all_cams]).to(dev)
                 factored = True
             with mode:

@@ -1025,7 +1025,7 @@ int gsr_backward_ex(const gsr_options* opt, int parts, int sh_g0, int sh_g1, int
 {
 	if (!(parts & (GSR_BWD_PART_MAIN | GSR_BWD_PART_SH)))
 		return fail(GSR_ERR_ARG, "gsr_backward_ex: nothing to do", __FILE__, __LINE__);
-	if ((parts & GSR_BWD_PART_SH) && sh_g0 % 256 != 0)
+	if ((parts & GSR_BWD_PART_SH) && !(parts & (GSR_BWD_PART_BAND_FIRST | GSR_BWD_PART_BAND_SECOND)) && sh_g0 % 256 != 0)
 		return fail(GSR_ERR_ARG, "gsr_backward_ex: sh_g0 must be a multiple of 256", __FILE__, __LINE__);
 	return backward_impl(opt, parts, sh_g0, sh_g1, P, D, M, R, background, width, height, means3D, shs, shs_rest,
 	                     colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, activation_flags, tan_fovx, tan_fovy,

@@ -460,7 +460,8 @@ def _gpu_worker_factored(rank, world, port, out_dir, compact, bands=1):
         if compact is True:
             assert fx.payload()["rows_per_step"] <= 1500
         elif compact:
-            assert fx.payload()["color_rows_per_view"] <= 1500 and fx.payload()["compacted"] == compact
+            # (bands = 2: each of a view's two messages is padded to ITS largest row count over the ranks)
+            assert fx.payload()["color_rows_per_view"] <= 1500 * bands and fx.payload()["compacted"] == compact
         torch.save(got, os.path.join(out_dir, f"fxgpu_rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
