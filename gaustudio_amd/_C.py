@@ -211,7 +211,8 @@ def set_grad_arena(outs, keys=(), sh_chunks=1, hook=None, colors_out=None, band_
     called (no arguments) once the geometry stage -- which then already leaves the masked colour gradient in colors_out -- has
     been enqueued and BEFORE the SH-direction stage: the caller starts the all-gather of the slot there.
     band_split > 0 with band_hook (and colors_out + hook): that backward runs BANDED (include/gsrast.h GSR_BWD_PART_BAND_*): the image
-    is cut at tile row band_split; class_hook(first[P], second[P]) receives the two Gaussian classes of the cut before anything runs,
+    is cut at tile row band_split; class_hook(first[P], second[P]) receives the two Gaussian classes of the cut from the FORWARD of these
+    parameters (on the caller's thread, right behind the forward's kernels),
     band_hook() is called once the first band -- compositing above the cut + the per-Gaussian stage of the Gaussians that end there,
     whose rows of colors_out are final then -- has been enqueued, hook() after the second band.  Same bits as the unbanded backward.
     [] without colors_out disarms."""

@@ -249,9 +249,13 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 	__shared__ int s_max[4];
 	if (blockIdx.x == 0 && threadIdx.x == 0 && bgv.flag_dst != nullptr) *bgv.flag_dst = bgv.flag;   // regime word (GsBg)
 	// XCD-banded static order, or (skewed frames) longest walk first: launch_tile_order
-	const int tile = bgv.tile_order ? ((int)blockIdx.x < T ? (int)bgv.tile_order[blockIdx.x] : T) : (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-	if ((!bgv.tile_order && (int)(blockIdx.x >> 3) >= chunk) || tile >= T) return;
-	if ((uint32_t)tile < bgv.tile_lo || (uint32_t)tile >= bgv.tile_hi) return;   // banded backward (GSR_BWD_PART_BAND_*): another call walks this tile
+	// (a banded backward, GSR_BWD_PART_BAND_*, walks the tiles [tile_lo, tile_hi) only: the XCD bands are cut out of THAT range, so
+	// that a band still runs on all eight XCDs -- cut out of the whole image, the upper half of the tiles lives on four of them)
+	const int tb_lo = (int)bgv.tile_lo, tb_n = (int)min(bgv.tile_hi, (uint32_t)T) - tb_lo;
+	const int local = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	const int tile = bgv.tile_order ? ((int)blockIdx.x < T ? (int)bgv.tile_order[blockIdx.x] : T) : tb_lo + local;
+	if ((!bgv.tile_order && ((int)(blockIdx.x >> 3) >= chunk || local >= tb_n)) || tile >= T) return;
+	if ((uint32_t)tile < bgv.tile_lo || (uint32_t)tile >= bgv.tile_hi) return;   // (longest-first order of a skewed frame: every tile is offered to both bands)
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6;
 	const int tx = tile % gx, ty = tile / gx;
@@ -543,9 +547,13 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) __attribute__((amdgpu_waves_per_eu
 	__shared__ int s_max[4];
 	if (blockIdx.x == 0 && threadIdx.x == 0 && bgv.flag_dst != nullptr) *bgv.flag_dst = bgv.flag;   // regime word (GsBg)
 	// XCD-banded static order, or (skewed frames) longest walk first: launch_tile_order
-	const int tile = bgv.tile_order ? ((int)blockIdx.x < T ? (int)bgv.tile_order[blockIdx.x] : T) : (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-	if ((!bgv.tile_order && (int)(blockIdx.x >> 3) >= chunk) || tile >= T) return;
-	if ((uint32_t)tile < bgv.tile_lo || (uint32_t)tile >= bgv.tile_hi) return;   // banded backward (GSR_BWD_PART_BAND_*): another call walks this tile
+	// (a banded backward, GSR_BWD_PART_BAND_*, walks the tiles [tile_lo, tile_hi) only: the XCD bands are cut out of THAT range, so
+	// that a band still runs on all eight XCDs -- cut out of the whole image, the upper half of the tiles lives on four of them)
+	const int tb_lo = (int)bgv.tile_lo, tb_n = (int)min(bgv.tile_hi, (uint32_t)T) - tb_lo;
+	const int local = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	const int tile = bgv.tile_order ? ((int)blockIdx.x < T ? (int)bgv.tile_order[blockIdx.x] : T) : tb_lo + local;
+	if ((!bgv.tile_order && ((int)(blockIdx.x >> 3) >= chunk || local >= tb_n)) || tile >= T) return;
+	if ((uint32_t)tile < bgv.tile_lo || (uint32_t)tile >= bgv.tile_hi) return;   // (longest-first order of a skewed frame: every tile is offered to both bands)
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wv = tid >> 6, qd = lane >> 4;
 	TM_DECL
@@ -992,7 +1000,8 @@ void launch_composite_bwd(const ImgLayout& il, int W, int H, const GsBg& bg, con
                           const float* dL_dpix_median, const float* dL_dpix_opacity, float* rows, uint8_t* row_flags,
                           const GsCtl* ctl, int variant, hipStream_t s)
 {
-	const int chunk = (il.T + 7) / 8;
+	const int tb_n = (int)std::min(bg.tile_hi, (uint32_t)il.T) - (int)bg.tile_lo;   // tiles of this call (a band, or all of them)
+	const int chunk = bg.tile_order ? (il.T + 7) / 8 : std::max(1, (tb_n + 7) / 8);      // (at least one workgroup: it stores the regime word)
 	const bool tsel = (variant & 1) != 0, wave_lists = (variant & 2) != 0;
 	const bool fx = (variant & 8) != 0;   // the forward ran in fast_exp mode (per-quarter kernels only)
 	const bool flags = row_flags != nullptr;

@@ -103,9 +103,9 @@ struct GradArena {
 	// two calls (GSR_BWD_PART_COLORS_EARLY): the geometry stage already leaves dRGB in the slot, `hook()` is called -- the
 	// caller starts the all-gather of this view's slot -- and only then the SH-direction stage is enqueued
 	torch::Tensor colors_out;
-	// BANDED form of that (round 6; FactoredGradExchange(bands=2)): band_split > 0 = the tile row the backward is cut at.  The
-	// backward then (1) tells the two Gaussian classes of the split apart and hands them to class_hook(first[P], second[P]) --
-	// the caller builds the headers of the view's two colour messages from them --, (2) runs the first band (compositing of the
+	// BANDED form of that (round 6; FactoredGradExchange(bands=2)): band_split > 0 = the tile row the backward is cut at.  (1) The
+	// FORWARD of these parameters tells the two Gaussian classes of the cut apart and hands them to class_hook(first[P], second[P]) --
+	// the caller builds the headers of the view's two colour messages from them --, (2) the backward runs the first band (compositing of the
 	// tile rows above the split + the per-Gaussian stage of the Gaussians that end there) and calls band_hook(): their dRGB rows are
 	// final, the caller packs and all-gathers them WHILE (3) the second band runs; then hook() and the SH-direction stage as above
 	int band_split = 0;
@@ -258,6 +258,31 @@ RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D
 	                           out_depth.data_ptr<float>(), out_median.data_ptr<float>(), out_opacity.data_ptr<float>(),
 	                           P ? radii.data_ptr<int>() : nullptr, debug ? 1 : 0, current_stream(means3D));
 	if (rc < 0) fail(rc);
+	// A BANDED backward is armed for these parameters (set_grad_arena(band_split > 0, class_hook)): the two Gaussian classes of its cut
+	// are known as soon as the forward is -- computed here and handed to class_hook(first, second) on the CALLER'S thread, right
+	// behind the forward (as FactoredGradExchange.visible() gets the radii of an unbanded view): the caller's headers, count gathers
+	// and their copy to the host are long finished when the backward's first band reports.  The arena itself stays armed.
+	if (P != 0) {
+		py::object hook = py::none();
+		int S = 0;
+		{
+			const int64_t keys[4] = {(int64_t)(uintptr_t)means3D_.data_ptr(), (int64_t)(uintptr_t)sh_.data_ptr(),
+			                         (int64_t)(uintptr_t)scales_.data_ptr(), (int64_t)(uintptr_t)rotations_.data_ptr()};
+			std::lock_guard<std::mutex> lock(g_arena_mutex);
+			bool match = g_arena.band_split > 0 && !g_arena.class_hook.is_none() && g_arena.colors_out.defined();
+			for (size_t i = 0; match && i < g_arena.keys.size() && i < 4; i++)
+				if (g_arena.keys[i] != 0 && g_arena.keys[i] != keys[i]) match = false;
+			if (match) { hook = g_arena.class_hook; S = g_arena.band_split; }
+		}
+		if (!hook.is_none()) {
+			const auto io = means3D.options().dtype(torch::kInt32);
+			torch::Tensor first = torch::empty({P}, io), second = torch::empty({P}, io);
+			const int rc2 = gsr_band_classes(P, radii.data_ptr<int>(), reinterpret_cast<const char*>(geom.data_ptr()), S, first.data_ptr<int>(),
+			                                 second.data_ptr<int>(), current_stream(means3D));
+			if (rc2 < 0) fail(rc2);
+			hook(first, second);
+		}
+	}
 	return std::make_tuple(rc, out_color, out_depth, out_median, out_opacity, radii, geom, binning, img);
 }
 
@@ -365,16 +390,8 @@ RasterizeGaussiansBackward(const torch::Tensor& background, const torch::Tensor&
 		};
 		const bool chunked = in_arena && !factored && arena.sh_chunks > 1 && !arena.hook.is_none() && M > 0 && sh.numel() != 0;
 		if (factored && !arena.hook.is_none() && arena.band_split > 0 && !arena.band_hook.is_none()) {
-			// banded: the classes first (the caller's headers and count gathers leave on its side stream), then the two bands
+			// banded (the classes of the cut went to class_hook behind the forward): the two bands, a callback after each
 			const int S = arena.band_split;
-			if (!arena.class_hook.is_none()) {
-				const auto io = means3D.options().dtype(torch::kInt32);
-				torch::Tensor first = torch::empty({P}, io), second = torch::empty({P}, io);
-				const int rc = gsr_band_classes(P, radii.data_ptr<int>(), reinterpret_cast<const char*>(geomBuffer.data_ptr()), S,
-				                                first.data_ptr<int>(), second.data_ptr<int>(), current_stream(means3D));
-				if (rc < 0) fail(rc);
-				arena.class_hook(first, second);
-			}
 			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY | GSR_BWD_PART_BAND_FIRST, S, 0);
 			arena.band_hook();
 			run(GSR_BWD_PART_MAIN | GSR_BWD_PART_SH_COLORS | GSR_BWD_PART_COLORS_EARLY | GSR_BWD_PART_BAND_SECOND, S, 0);

@@ -402,6 +402,7 @@ class FactoredGradExchange:
                     "dense_payload_bytes_per_rank": self.P * (self.M * 3 + 11) * 4, "color_rows_per_view": crow / self.V,
                     "geometry_rows": grow, "rows_total": self.P, "compacted": "view+geometry" if self.union_geometry else "view",
                     "geometry_fallbacks": self.stats.get("geometry_fallbacks", 0),
+                    "first_band_rows_per_view": self.stats.get("color_rows_sent_first_band", 0) / n / self.V if self.bands == 2 else None,
                     "early_allgathers_per_step": self.stats["early_allgathers"] / n}
         rows = self.stats["rows_exchanged"] / n if self.compact else self.P
         sent = rows * (44 + 12 * self.V)
@@ -444,40 +445,52 @@ class FactoredGradExchange:
         headers come from the two Gaussian classes the banded backward reports when it starts (_on_classes): a no-op here."""
         if not self.by_view or self.bands == 2:
             return
-        self._index_slot(v, radii.detach().contiguous())
+        self._index_slots(v, [radii.detach().contiguous()])
 
     def _on_classes(self, v: int, first: torch.Tensor, second: torch.Tensor):
-        """bands = 2: called by the banded backward of local view v (csrc/torch_binding.cpp) before its first kernel, with the two
-        classes of the cut (int32[P], 1 = member; include/gsrast.h gsr_band_classes): the headers of the view's two messages and
-        the gathers of their row counts leave on the side stream, as visible() does for the unbanded view."""
-        self._index_slot(2 * v, first)
-        self._index_slot(2 * v + 1, second)
+        """bands = 2: called by the FORWARD of local view v (csrc/torch_binding.cpp, on the caller's thread, right behind the forward's
+        kernels) with the two classes of the cut its armed banded backward will use (int32[P], 1 = member; include/gsrast.h
+        gsr_band_classes): the headers of the view's two messages and the gathers of their row counts leave on the side stream, as
+        visible() does for the unbanded view.  (A first version computed the classes at the start of the BACKWARD, on the autograd
+        thread: the host then waited on an event recorded microseconds earlier on the same thread, and the step stalled for 9-90 ms at
+        a time on the MI355X -- tools/band_exchange_timing.py.)"""
+        self._index_slots(2 * v, [first, second])
 
-    def _index_slot(self, slot: int, member: torch.Tensor):
-        """Header of message slot `slot` from member[P] (> 0 = the Gaussian has a row in it) + the all-gather of the row counts."""
+    def _index_slots(self, slot0: int, members):
+        """Headers of the consecutive message slots slot0, slot0 + 1, ... from members[i][P] (> 0 = the Gaussian has a row in that
+        message) + the all-gathers of their row counts -- ONE excursion to the side stream, ONE copy of the counts to pinned host
+        memory and ONE event for all of them (two excursions per view, each with its own wait on the compute stream, its own 4-byte
+        copy and its own event, stalled the compute stream for ~9 ms per step on the MI355X: tools/band_exchange_timing.py)."""
+        n = len(members)
+
         def build():
-            self._pk.visible_index(member, self.hdr[slot], self._scratch)
-            if _multi(self.group):
-                w = dist.all_gather_into_tensor(self.counts[slot], self.hdr[slot][0:1], group=self.group, async_op=True)
-                if self._cuda:
-                    w.wait()                               # the side stream waits for the communicator's stream; the host does not
+            for i, member in enumerate(members):
+                slot = slot0 + i
+                self._pk.visible_index(member, self.hdr[slot], self._scratch)
+                if _multi(self.group):
+                    w = dist.all_gather_into_tensor(self.counts[slot], self.hdr[slot][0:1], group=self.group, async_op=True)
+                    if self._cuda:
+                        w.wait()                           # the side stream waits for the communicator's stream; the host does not
+                    else:
+                        self._count_works[slot] = w
                 else:
-                    self._count_works[slot] = w
-            else:
-                self.counts[slot, 0:1].copy_(self.hdr[slot][0:1])
+                    self.counts[slot, 0:1].copy_(self.hdr[slot][0:1])
         if self._cuda:
             cur = torch.cuda.current_stream(self.geo.device)
             with torch.cuda.stream(self._side):
                 self._side.wait_stream(cur)                # radii / the classes come from kernels just enqueued
                 build()
-                self._counts_host[slot].copy_(self.counts[slot], non_blocking=True)
+                self._counts_host[slot0:slot0 + n].copy_(self.counts[slot0:slot0 + n], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
-            member.record_stream(self._side)
-            self._count_events[slot] = ev
+            for member in members:
+                member.record_stream(self._side)
+            for i in range(n):
+                self._count_events[slot0 + i] = ev
         else:
             build()
-        self._seen.add(slot)
+        for i in range(n):
+            self._seen.add(slot0 + i)
 
     def _send_view(self, v: int):
         """(bands = 1) the one message of local view v."""
@@ -497,7 +510,7 @@ class FactoredGradExchange:
             ev = self._count_events.pop(slot)
             ev.synchronize()                                                 # the side stream only: signalled long ago
             torch.cuda.current_stream(self.geo.device).wait_event(ev)        # the header is read by the kernels enqueued below
-            kcap = int(self._counts_host[slot].max())
+            kcap = max(self._counts_host[slot].tolist())          # (plain Python: see _exchange_by_view on host-side torch reductions)
         else:
             w = self._count_works.pop(slot, None)
             if w is not None:
@@ -512,6 +525,8 @@ class FactoredGradExchange:
             self._pk.pack_rows(self.hdr[slot], self.colors[v], mine[self.Hw:].view(torch.float32), 3, 0)
         self._L[slot] = L
         self.stats["color_rows_sent"] += kcap
+        if self.bands == 2 and slot % 2 == 0:
+            self.stats["color_rows_sent_first_band"] = self.stats.get("color_rows_sent_first_band", 0) + kcap
         if _multi(self.group):
             self._works[slot] = _all_gather_in_place(buf, self.rank, 1, self.group)
         else:
@@ -644,10 +659,12 @@ def _exchange_by_view_impl(self, campos_all, D, views, multi):
     # row in exactly one part of a view, so per Gaussian this is the unbanded order of views: bit-identical sums) -- from the counts
     # the host already holds, handed to the device by a non-blocking copy out of pinned memory.  Message (v, r, part) lies at word
     # slot * (W * Lmax) + r * L_slot of `msgs`, slot = v * B + part.
-    Ls = self.Hw + 3 * self._counts_host.max(dim=1).values.to(torch.int64)                                  # [S], host
-    slot_of = (torch.arange(V, dtype=torch.int64)[:, None, None] * B + torch.arange(B, dtype=torch.int64)[None, None, :]).expand(V, W, B)
-    rank_of = torch.arange(W, dtype=torch.int64)[None, :, None].expand(V, W, B)
-    self._off_host.copy_((slot_of * (W * self.Lmax) + rank_of * Ls[slot_of]).reshape(-1))
+    # (plain Python integers: a torch reduction over this [S, W] host tensor enters an OpenMP region -- on the 128-core host of an
+    # MI355X box `counts.max(dim=1)` of a 2 x 1 tensor took 26 ms per step, tools/band_exchange_timing.py)
+    cnt = self._counts_host.tolist()                                                                        # [S][W], host
+    Ls = [self.Hw + 3 * max(row) for row in cnt]
+    self._off_host.copy_(torch.tensor([(v * B + part) * (W * self.Lmax) + r * Ls[v * B + part]
+                                       for v in range(V) for r in range(W) for part in range(B)], dtype=torch.int64))
     self._off_dev.copy_(self._off_host, non_blocking=True)
     offsets = self._off_dev
     msgs = self.msgs.view(-1)
