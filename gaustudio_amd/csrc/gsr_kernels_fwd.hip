@@ -1958,8 +1958,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 // FX: exp on the transcendental unit (gs_exp_hw) instead of the reproducible 9-instruction gs_exp -- the opt-in
 // `fast_exp` mode: outputs then agree with the bit-exact mode to ~1e-6 relative except at threshold
 // flips (tests/test_gpu_fastexp.py attributes every one of them), and the backward must run in the same mode.
+#ifndef GSR_FWD_WAVES
+#define GSR_FWD_WAVES 7      // waves per SIMD the register allocation is held to
+#endif
 template <bool NOCULL, bool FX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void composite_fwd_quarter_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_FWD_WAVES, GSR_FWD_WAVES))) void composite_fwd_quarter_kernel(
     int T, int chunk, int gx, int W, int H, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const GsRec* __restrict__ recs, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_median, float* __restrict__ out_opacity,
@@ -2013,6 +2016,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 		staged += cnt;
 		uint32_t mk = 0;
 		if (tid < cnt) {
+			// (round 6: requesting the NEXT batch's records before the walk of the current one, as composite_bwd does, needs 14 more
+			// VGPRs at 72 of 72 -- 11 spilled at 7 waves / SIMD, or 6 waves: +3 % at C3, +10 % at C4, +4 % at C5 either way;
+			// profiles/r06_composite_fwd_experiments.txt.  Seven workgroups per CU already overlap one another's gathers.)
 			const uint32_t id = point_list[range.x + base + tid];
 			const GsRec* rr = recs + id;
 			const float4 a = rr->q0;

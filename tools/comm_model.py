@@ -27,6 +27,14 @@ Collectives on one communicator run one after the other.
   step_N(factored)       = pg1 + max(0, allgather(12 B x P) - tail) + max(0, allreduce(44 B x P) - rebuild)
   step_N(view)           = pg1 + max(0, allgather(hdr + 12 B x vis_view P) - tail) + max(0, allreduce(44 B x P) - rebuild)
   step_N(view+geometry)  = its own pg1 + the view gather + max(0, allreduce(44 B x vis_union P) - rebuild)
+  step_N(view, 2 bands)  = pg1 of the BANDED code path (round 6: FactoredGradExchange(bands=2), measured at world 1 like the others: the
+                           second preprocess_bwd pass, the class kernel, two more header builds, two pack launches and the second
+                           composite_bwd launch are all inside it) + what is left of  [msg A | msg B | all-reduce(44 B x P)]  on the wire,
+                           where msg A = hdr + 12 B x first-band rows leaves when the first band is done -- `window_A` = half of
+                           composite_bwd + preprocess_bwd + tail + rebuild of compute still to come -- and msg B and the geometry
+                           all-reduce when the second band's geometry stage is done (`window_B` = tail + rebuild to come).  The geometry
+                           all-reduce CANNOT be split: a Gaussian is final early only on the ranks whose view sees it above the cut,
+                           and an all-reduce needs the same rows on every rank.
   speed-up               = N t1 / step_N          (what a driver computes from `value` at N and at 1; one view per GPU)
 
     python tools/comm_model.py                      # the table of DESIGN.md s7
@@ -51,18 +59,25 @@ SCENARIOS = {
         P=1_000_000, t1=0.9778, t1_src="final_bench_c3.json", vis_view=0.8535, vis_union=0.87,
         preprocess_bwd=0.1101,
         pg1=dict(dense=(1.1453, 0.0527, "s3_pg1_C3_dense_none.json"), factored=(1.0555, 0.0741, "s5_pg1_C3_factored_none.json"),
-                 view=(1.1207, 0.0675, "s5_pg1_C3_factored_view.json"), view_geometry=(1.2642, 0.0675, "s5_pg1_C3_factored_view+geometry.json"))),
+                 view=(1.1207, 0.0675, "s5_pg1_C3_factored_view.json"), view_geometry=(1.2642, 0.0675, "s5_pg1_C3_factored_view+geometry.json")),
+        # round 6 (profiles/r06_pg1/): the same code path re-measured on the round-6 tree, unbanded and banded; first-band rows / visible rows
+        r06=dict(t1=0.9693, view=1.1117, view_b2=1.3152, rebuild=0.0671, rebuild_b2=0.0858, fA=424400 / 853514, composite_bwd=0.4852,
+                 preprocess_bwd=0.1025)),
     "C4 share, ALL 5 M in the frustum (0.87 visible per view)": dict(
         P=5_000_000, t1=1.8093, t1_src="final_bench_C4.json", vis_view=0.8737, vis_union=0.90,
         preprocess_bwd=0.4954,
         pg1=dict(dense=(2.0436, 0.0514, "s3_pg1_C4_dense_none.json"), factored=(1.9192, 0.2228, "s5_pg1_C4_factored_none.json"),
-                 view=(2.0950, 0.2702, "s5_pg1_C4_factored_view.json"), view_geometry=(2.3994, 0.2702, "s5_pg1_C4_factored_view+geometry.json"))),
+                 view=(2.0950, 0.2702, "s5_pg1_C4_factored_view.json"), view_geometry=(2.3994, 0.2702, "s5_pg1_C4_factored_view+geometry.json")),
+        r06=dict(t1=1.7179, view=2.0158, view_b2=2.6279, rebuild=0.2648, rebuild_b2=0.3401, fA=2130311 / 4368742, composite_bwd=0.3149,
+                 preprocess_bwd=0.4533)),
     "C4-inside (5 M ball, cameras INSIDE the scene: 0.158 visible per view)": dict(
         P=5_000_000, t1=1.1303, t1_src="final_bench_C4-inside.json", vis_view=0.1576, vis_union=0.54,
         preprocess_bwd=0.4843,
         pg1=dict(dense=(1.3001, 0.0524, "s3_pg1_C4-inside_dense_none.json"), factored=(1.2314, 0.2231, "s5_pg1_C4-inside_factored_none.json"),
                  view=(1.3644, 0.2378, "s5_pg1_C4-inside_factored_view.json"),
-                 view_geometry=(1.5452, 0.2378, "s5_pg1_C4-inside_factored_view+geometry.json"))),
+                 view_geometry=(1.5452, 0.2378, "s5_pg1_C4-inside_factored_view+geometry.json")),
+        r06=dict(t1=1.1225, view=1.3385, view_b2=1.7725, rebuild=0.2128, rebuild_b2=0.2918, fA=383115 / 788012, composite_bwd=0.1833,
+                 preprocess_bwd=0.4733)),
 }
 
 
@@ -94,6 +109,31 @@ def model(sc, N, B):
     return out
 
 
+def model_bands(sc, N, B):
+    """Round 6: the `view` exchange unbanded and banded, both with THIS round's measured world-1 steps (profiles/r06_pg1/).
+    -> {name: (step_N ms, speed-up, exposed ms)}"""
+    r = sc["r06"]
+    P, t1 = sc["P"], r["t1"]
+    hdr = P / 8.0 + P / 64.0 + 16
+    vis = sc["vis_view"] * P
+    tail = 0.46 * r["preprocess_bwd"]
+    ar = allreduce_ms(P * 44, N, B)
+    out = {}
+    # unbanded: [message | all-reduce] from the end of the geometry stage; tail + rebuild of compute still to come
+    wire = allgather_ms(hdr + 12 * vis, N, B) + ar
+    exp1 = max(0.0, wire - (tail + r["rebuild"]))
+    out["view"] = (r["view"] + exp1, N * t1 / (r["view"] + exp1), exp1)
+    # banded: message A from the end of the first band; B and the all-reduce from the end of the second band's geometry stage
+    win_b = tail + r["rebuild_b2"]
+    win_a = 0.5 * r["composite_bwd"] + 0.54 * r["preprocess_bwd"] + win_b
+    end_a = allgather_ms(hdr + 12 * vis * r["fA"], N, B)
+    start_b = max(end_a, win_a - win_b)
+    end_all = start_b + allgather_ms(hdr + 12 * vis * (1.0 - r["fA"]), N, B) + ar
+    exp2 = max(0.0, end_all - win_a)
+    out["view, 2 bands"] = (r["view_b2"] + exp2, N * t1 / (r["view_b2"] + exp2), exp2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--N", type=int, nargs="*", default=[8, 4, 2])
@@ -113,12 +153,23 @@ def main():
             for B in a.B:
                 m = model(sc, N, B)
                 print(f"  N = {N}, B = {B:.0f} GB/s: " + "   ".join(f"{k} {m[k][2]:4.2f}x ({m[k][1]:.2f} ms, {m[k][0]:.0f} MB)" for k in names))
+        if "r06" in sc:
+            r = sc["r06"]
+            print(f"  round 6 (profiles/r06_pg1/): t1 {r['t1']:.4f}; world-1 step of `view` {r['view']:.4f}, banded {r['view_b2']:.4f} ms "
+                  f"(+{r['view_b2'] - r['view']:.3f}); first-band rows {r['fA']:.3f} of the visible ones")
+            for N in a.N[:1]:
+                for B in a.B:
+                    m = model_bands(sc, N, B)
+                    print(f"  N = {N}, B = {B:.0f} GB/s: " + "   ".join(f"{k} {v[1]:4.2f}x (step {v[0]:.2f} ms, exposed {v[2]:.2f})" for k, v in m.items()))
         print()
     print("Reading: at C3 the factored exchange leaves ~0.4-0.5 ms exposed behind a 1.06-ms rank step (5.3-5.7x at 8 GPUs; the dense single")
     print("all-reduce 3.3-3.6x); at 5 M Gaussians the 44 B per Gaussian of the geometry all-reduce alone (220 MB: 1.0-1.2 ms on the wire) is as")
     print("long as a whole C4-inside step: there its restriction to the union of the step's views (view+geometry: 0.54 of the rows, +0.18 ms of")
     print("machinery per step at world 1) is the best form, 4.5-4.9x; with every Gaussian in every frustum (the synthetic C4 share) nothing can")
     print("be left out: 3.7-4.2x.  north_star's >= 6x is NOT reached on paper with one view per GPU and replicated parameters.")
+    print("Round 6, the two-band overlap (built, bit-equal, measured at world 1): it hides ~0.10 ms of the colour all-gather at C3 and costs")
+    print("+0.20 ms of rank step (second per-Gaussian pass over the rows, class / header / pack launches, two kernel tails, a host-bound")
+    print("enqueue) -- a net LOSS in this model in every scenario; the geometry all-reduce, half of the exposed time, cannot be banded.")
 
 if __name__ == "__main__":
     main()
