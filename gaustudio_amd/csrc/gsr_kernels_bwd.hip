@@ -500,7 +500,9 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 //   waves/SIMD against 0.59 ms at 4); one float4 per lane and turn instead of three floats (spills: 0.69 ms); a fused
 //   v_add_f32_dpp fold by inline assembly and skipping the steps past the longest list (no change); branch-free turns
 //   (every lane reads / adds / writes in every turn, the other quarters' lanes into a dummy word, so that a group of four
-//   steps is one basic block: bit-equal, 0.5111 against 0.5097 ms).  profiles/r03_composite_bwd_phases.txt: a wave walks
+//   steps is one basic block: bit-equal, 0.5111 against 0.5097 ms); round 6: s_setprio by phase (walk above or below the staging /
+//   flush phases: +-0.3 %) and a length-balanced assignment of the sixteen quarters to the four waves (census: -2.8 % wave-steps at
+//   C3, profiles/r06_quarter_balance_census.txt; profiles/r06_composite_bwd_experiments.txt).  profiles/r03_composite_bwd_phases.txt: a wave walks
 //   for 68 % of its life, and the walk is sensitive to VALU and LDS at once with neither saturated.
 // A wave walks max over its quarters (C3: 0.73x the steps of the 8x8 walk), and phase 2 touches only hit quarters.
 // The median-depth gradient (one Gaussian per pixel, the list position the forward recorded) is added once per pixel,
