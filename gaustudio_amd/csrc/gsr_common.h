@@ -89,7 +89,7 @@ __device__ __forceinline__ float gs_exp(float p)
 
 // exp(p) on the transcendental unit: v_mul_f32 + v_exp_f32 (2 VALU instead of 9).  1 ulp of 2^x plus the rounding of
 // p * log2(e): within 1e-6 relative of gs_exp for p in [-6, 0], the range in which the alpha >= 1/255 decision is taken.
-// NOT reproducible on a CPU: used only in the opt-in `fast_exp` mode of both compositing kernels and,
+// NOT reproducible on a CPU: used only in the opt-in `fast_exp` mode of both compositing kernels (docs/DESIGN_history_r1-r4.md s4.5) and,
 // with an exact-decision fallback (FX = 2 in composite_bwd), in the backward of a bit-exact forward.
 __device__ __forceinline__ float gs_exp_hw(float p) { return __builtin_amdgcn_exp2f(p * 0x1.715476p+0f); }
 
@@ -387,7 +387,7 @@ __device__ __forceinline__ void cov2d_common(const float3 mean, float fx, float 
 // pixel (lx, ly) of 8x8 quadrant q = s>>6 = (ly>>3)*2 + (lx>>3), lane l = s&63 = (ly&7)*8 + (lx&7).
 // composite_fwd and composite_bwd both run 4 wave64 per tile, wave q on quadrant q (slot = thread id).
 // (A 2-pixel-per-lane forward was measured in round 1: 0.55 ms vs 0.46 ms at C3 -- the larger culling box costs
-// more than packed arithmetic saves; round 2 moved the backward to this layout as well)
+// more than packed arithmetic saves; round 2 moved the backward to this layout as well, docs/DESIGN_history_r1-r4.md s4.3.)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gs_pixel_of_thread(int tid, int& lx, int& ly)
 {

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(GSR_BWD_THREADS) void composite_bwd_kernel(
 // stayed the forward's -- was built, passed the summation-bound tests and measured 0.5346 ms: removed.)
 // TM_DECL / TM(k) / TM_END: phase timing of a diagnostic build (gsr_bwd_timing.h); empty in the product
 #ifndef GSR_BWQ_WAVES
-#define GSR_BWQ_WAVES 4      // waves per SIMD the register allocation is held to (experiment: 5 with GSR_BWQ_BATCH=96)
+#define GSR_BWQ_WAVES 4      // waves per SIMD the register allocation is held to (experiment: 5 with GSR_BWQ_BATCH=96, docs/DESIGN_history_r1-r4.md s4.3)
 #endif
 // CONLY: only the colour gradient is supplied (dL_dpix_depth / _median / _opacity NULL = zero: a colour-only loss, the usual
 // 3DGS training call): their loads, their two FMAs of the step and the four of phase 2 are left out.  The remaining

@@ -1956,7 +1956,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 #define GSR_FWD_NONE 0xffffu
 
 // FX: exp on the transcendental unit (gs_exp_hw) instead of the reproducible 9-instruction gs_exp -- the opt-in
-// `fast_exp` mode: outputs then agree with the bit-exact mode to ~1e-6 relative except at threshold
+// `fast_exp` mode (docs/DESIGN_history_r1-r4.md s4.5): outputs then agree with the bit-exact mode to ~1e-6 relative except at threshold
 // flips (tests/test_gpu_fastexp.py attributes every one of them), and the backward must run in the same mode.
 #ifndef GSR_FWD_WAVES
 #define GSR_FWD_WAVES 7      // waves per SIMD the register allocation is held to

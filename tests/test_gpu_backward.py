@@ -33,6 +33,17 @@ def _check(oracle, sc, cam, D, kw, scale_modifier=1.0, bg=None, seed=1, e2e_tol=
     ob = oracle.backward(os_, *[g.numpy() for g in grads])
     hs = hip_forward(sc, cam, D, kw, scale_modifier, bg)
     hb = hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier, bg)
+    # (0) round 6: the same backward in two BANDS (cut at a seed-dependent tile row) + the SH stage: every output bit for bit
+    if hs["num_rendered"] > 0:
+        gy = (cam.height + 15) // 16
+        S = (seed * 7 + 3) % (gy + 1)
+        hbb = hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier, bg, options={}, parts=1 | 16, sh_g0=S)
+        hbb = hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier, bg, options={}, parts=1 | 32, sh_g0=S, reuse=hbb)
+        hbb = hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier, bg, options={}, parts=2, reuse=hbb)
+        for k in GRAD_KEYS + ("acc",):
+            if k == "dL_dsh" and "shs" not in kw:
+                continue
+            assert torch.equal(hbb[k], hb[k]), f"banded backward (cut at tile row {S} of {gy}) differs in {k}"
     # (1) composite-stage sums
     acc = to_np(hb["acc"]).astype(np.float64)
     err = np.abs(acc - ob["acc"])

@@ -4,7 +4,7 @@
 Generates one kernel per pattern (an unrolled block of inline-asm instructions, 8 waves per SIMD unless --waves says
 otherwise, every CU busy), times it with HIP events and prints ns x 2.4 per instruction per SIMD (= cycles at 2.4 GHz;
 the sustained clock is a little lower, so "2.4" reads as 2 issue cycles and "4.2" as 4).  Used to build the VALU
-cost model in DESIGN.md s5: plain FP32 / logic ops with VGPR, inline-constant or literal sources issue at ~2 cycles,
+cost model in docs/DESIGN_history_r1-r4.md s4.4: plain FP32 / logic ops with VGPR, inline-constant or literal sources issue at ~2 cycles,
 everything else (compares, selects, min/max, shifts, conversions, DPP, packed FP32, ANY op with an SGPR source) at ~4,
 transcendentals and lane swaps at ~8; scalar ALU instructions cost ~4 cycles of a SIMD's issue turns and overlap VALU.
 
