@@ -44,6 +44,20 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):
         print(os.path.basename(f), "unreadable:", e)
 PY
 fi
+if [ "$what" = "dc" ] || [ "$what" = "all" ]; then
+  # rocprofv3 kernel stats of the DEFAULT command's timed loop (settle + warm-up + timed + stage steps at warm clocks): its average
+  # for composite_fwd must agree with the live HIP-event figure of the same run (`roofline.avg_ms`)
+  echo "== rocprofv3 --kernel-trace --stats -- python bench.py --no-extras" | tee -a "$out/summary.txt"
+  root="$(pwd)"
+  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/dc" -o k -- python "$root/bench.py" --no-extras --no-cpu-baseline --no-ref-ab > "$root/$out/dc.log" 2>&1 )
+  grep '^{"metric"' "$out/dc.log" | tail -1 > "$out/c3_default_command_bench_line.json"
+  db=$(ls "$out"/dc/*/k_results.db "$out"/dc/k_results.db 2>/dev/null | head -1)
+  python tools/rocpd_summary.py "$db" > "$out/c3_default_command_kernel_stats.txt" 2>&1
+  rm -rf "$out/dc"
+  head -12 "$out/c3_default_command_kernel_stats.txt" | cut -c1-170 | tee -a "$out/summary.txt"
+  python -c "
+import json; j=json.load(open('$out/c3_default_command_bench_line.json')); print('live composite avg_ms', j['roofline']['avg_ms'], 'frac', j['roofline']['frac'], 'step', j['ms_per_step'])" | tee -a "$out/summary.txt"
+fi
 if [ "$what" = "fuzz" ] || [ "$what" = "all" ]; then
   echo "== fuzz" | tee -a "$out/summary.txt"
   timeout 1500 python tests/tools/fuzz_campaign.py --n 300 --first 2600 > "$out/fuzz_campaign.log" 2>&1; tail -3 "$out/fuzz_campaign.log" | tee -a "$out/summary.txt"
