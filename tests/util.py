@@ -131,6 +131,10 @@ def make_options(L, struct_bytes=None, **fields):
     return o
 
 
+class _BackwardOut(dict):
+    """hip_backward_raw's result: the gradient tensors by name (+ "acc"); `.scratch` = the backward's scratch buffer, for `reuse`."""
+
+
 def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, debug=False, options=None, no_dcov=False, parts=3,
                      sh_g0=0, sh_g1=None, reuse=None):
     """gsr_backward (or, with `options` = a GsrOptions / None-able dict, gsr_backward_ex) called straight through ctypes
@@ -150,7 +154,7 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
     fo = dict(dtype=torch.float32, device=dev)
     if reuse is not None:
         out = {k: reuse[k] for k in ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")}
-        scratch = reuse["scratch"]
+        scratch = reuse.scratch
     else:
         out = dict(dL_dmeans2D=torch.full((P, 3), float("nan"), **fo), dL_dopacity=torch.full((P, 1), float("nan"), **fo),
                    dL_dcolors=torch.full((P, 3), float("nan"), **fo), dL_dmeans3D=torch.full((P, 3), float("nan"), **fo),
@@ -193,5 +197,6 @@ def hip_backward_raw(hs, sc, cam, D, kw, grads, scale_modifier=1.0, bg=None, deb
         raise _C._err(L, rc)
     torch.cuda.synchronize()
     out["acc"] = acc
-    out["scratch"] = scratch
+    out = _BackwardOut(out)
+    out.scratch = scratch          # (an attribute, not a key: callers iterate over the gradient tensors)
     return out
