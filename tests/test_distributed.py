@@ -587,7 +587,8 @@ def test_nccl_world1_every_collective_call_of_the_step(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange,compact", [("dense", "none"), ("factored", "none"), ("factored", "view"), ("factored", "view+geometry")])
+@pytest.mark.parametrize("exchange,compact", [("dense", "none"), ("factored", "none"), ("factored", "view"), ("factored", "view+geometry"),
+                                              ("factored", "view/bands2")])
 def test_nccl_world1_through_bench_py(tmp_path, exchange, compact):
     """`bench.py --gpus 1` with GSR_BENCH_FORCE_PG=1: the exact code path of the driver's N > 1 runs (init_process_group("nccl",
     device_id=...), armed bucket / FactoredGradExchange, barrier + MAX all-reduce of the clock, comm block) on one GPU.
@@ -598,9 +599,11 @@ def test_nccl_world1_through_bench_py(tmp_path, exchange, compact):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GSR_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    bands = 2 if compact.endswith("/bands2") else 1          # round 6: `--bands 2`, the banded exchange (comm.bands on the line)
+    compact = compact.split("/")[0]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "C2", "--steps", "4", "--warmup", "2",
-                        "--exchange", exchange, "--compact", compact, "--no-cpu-baseline", "--no-ref-ab"], env=env, capture_output=True,
-                       text=True, timeout=300)
+                        "--exchange", exchange, "--compact", compact, "--bands", str(bands), "--no-cpu-baseline", "--no-ref-ab"], env=env,
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["comm"]["exchange"] == exchange and line["comm"]["exchange_fallback"] is None, line["comm"]
@@ -609,7 +612,9 @@ def test_nccl_world1_through_bench_py(tmp_path, exchange, compact):
         assert line["comm"]["chunks_per_step"] == 4 and line["comm"]["tail_bytes_per_step"] > 0
     elif compact != "none":
         assert line["comm"]["compacted"] == compact and line["comm"]["color_rows_per_view"] < line["comm"]["rows_total"]
-        assert line["comm"]["early_allgathers_per_step"] == 1
+        assert line["comm"]["early_allgathers_per_step"] == 1 and line["comm"]["bands"] == bands
+        if bands == 2:
+            assert 0 < line["comm"]["first_band_rows_per_view"] < line["comm"]["color_rows_per_view"]
 
 
 @pytest.mark.gpu
