@@ -55,6 +55,12 @@ GRAD_KEYS = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov
 # tensor, and the floor of every pair, are in profiles/r05_parity.json (`max_rel_over_config_floor`,
 # `reference_floor_pairs_max_rel_any_tensor`).
 GRAD_K = 3.0
+# round 6: gradients of the Gaussians that are in no flagged pixel's list, with the median-depth gradient absent on both sides
+# (_away_from_events), relative to each tensor's largest element.  Measured on the MI355X over C1-C5
+# (profiles/r06_parity.json `grads_no_median_away_from_events`): at most 9.5e-6 in the reproducible mode (C2, dL_dmeans2D; flips below
+# the 1e-5 image tolerance are not exempt) and 1.6e-6 in the default fast_exp mode, with 0-1.1 % of the Gaussians exempt; the same
+# tensors reach 1e-5 .. 4e-4 INSIDE the event lists.  Bound = 3x the largest observation.
+AWAY_TOL = float(os.environ.get("GSR_AWAY_TOL", "3e-5"))
 
 
 def _compare(hs, ref, config, W, H):
@@ -88,7 +94,41 @@ def _compare(hs, ref, config, W, H):
     stats["attribution"]["windows"] = {"alpha_rel": attribution.WIN_ALPHA, "T_rel": attribution.WIN_T, "power_rel": attribution.WIN_POWER,
                                        "median_rel": attribution.WIN_MEDIAN}
     assert not rep["unattributed"], f"{config}: {len(rep['unattributed'])} of {rep['flagged']} differing pixels are NOT threshold events: {rep['unattributed'][:3]}"
+    stats["_event_pixels"] = [tuple(e["pixel"]) for e in rep["events"]]
     return stats
+
+
+def _away_from_events(hs, sc, cam, D, kw, grads, runs_ref, event_pixels, W, fast_exp):
+    """Round 6: the gradients AWAY from the threshold events, without the median-depth gradient.  The two things that make the
+    GRAD_K x floor bound above loose are (1) the frame's handful of threshold flips -- a flip at a pixel changes T for everything
+    behind it there, i.e. the gradients of the Gaussians in that pixel's list -- and (2) the median-depth gradient, which the
+    reference routes by a transmittance reconstructed by division (backward.cu:566-569, ill-conditioned at 0.5) and this library
+    by the forward's own decision.  Take both away -- the median gradient absent in BOTH implementations, the
+    Gaussians of the flagged pixels' lists exempt -- and what remains is arithmetic: fp32 sums in another order, ocml expf vs the
+    polynomial / v_exp_f32, rcp vs divide.  Returns {tensor: (max_rel away from events, max_rel in event lists, exempt count)}."""
+    g_nm = [grads[0], grads[1], torch.zeros_like(grads[2]), grads[3]]
+    ref = ref_util.run(sc, cam, D, kw, g_nm)
+    hb = hip_backward_raw(hs, sc, cam, D, kw, [g_nm[0], g_nm[1], None, g_nm[3]], options=dict(fast_exp=fast_exp))
+    P = sc.means3D.shape[0]
+    exempt = np.zeros(P, bool)
+    gx = (W + 15) // 16
+    nc = to_np(hs["n_contrib"]).astype(np.int64)
+    for (x, y) in event_pixels:
+        ids = attribution.tile_list(hs, (y // 16) * gx + x // 16)
+        exempt[ids[:int(nc[y, x]) + 2]] = True          # (+2: the flipped contributor may be the one just behind the last one this side applied)
+    out = {}
+    for k in GRAD_KEYS:
+        b = ref[k].numpy()
+        if b.size == 0:
+            continue
+        a = to_np(hb[k]).reshape(P, -1).astype(np.float64)
+        b = b.reshape(P, -1).astype(np.float64)
+        scale = max(float(np.abs(b).max()), 1e-30)
+        d = np.abs(a - b).max(1) / scale
+        out[k] = {"max_rel_away_from_events": float(d[~exempt].max(initial=0.0)), "max_rel_in_event_lists": float(d[exempt].max(initial=0.0)),
+                  "mean_rel": float(d.mean())}
+    out["_exempt_gaussians"] = int(exempt.sum())
+    return out
 
 
 def _dump_parity(config, stats, section="configs"):
@@ -241,6 +281,12 @@ def test_hip_vs_reference_kernels_at_baseline_configs(request, P, W, H, D, fast_
         assert mn <= GRAD_K * max(floors[k][1], 1e-9), (k, mode, mn, floors[k][1])
         assert mx <= GRAD_K * floor2_max, (k, mode, mx, floor2_max, "round 4's two-pair floor")
         assert mn <= GRAD_K * max(floors2[k][1], 1e-9), (k, mode, mn, floors2[k][1], "round 4's two-pair floor")
+    # round 6: away from the events, without the median gradient (see _away_from_events): a bound on the ARITHMETIC difference
+    event_pixels = stats.pop("_event_pixels")
+    stats["grads_no_median_away_from_events"] = away = _away_from_events(hs, sc, cam, D, kw, grads, runs, event_pixels, W, fast_exp)
+    for k in GRAD_KEYS:
+        if k in away:
+            assert away[k]["max_rel_away_from_events"] <= AWAY_TOL, (k, mode, away[k])
     _dump_parity(config, stats, section="configs" if not fast_exp else "configs_fast_exp")
 
 
