@@ -29,7 +29,8 @@ campos = cam.campos.to(dev)[None]
 
 SEQ = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else '1,2,1,2').split(',')]
 for bands in SEQ:
-    fx = parallel.FactoredGradExchange(params, views_per_rank=1, compact="view", bands=bands, band_split=((H + 15) // 16) // 2 if bands == 2 else None)
+    COMPACT = {"none": False, "view": "view", "view+geometry": "view+geometry"}[os.environ.get("BAND_COMPACT", "view")]
+    fx = parallel.FactoredGradExchange(params, views_per_rank=1, compact=COMPACT, bands=bands, band_split=((H + 15) // 16) // 2 if bands == 2 else None)
     log = []
 
     def wrap(name):
